@@ -1,0 +1,313 @@
+"""Golden-vector generator.  TEST INFRASTRUCTURE ONLY -- runs in the BUILD CONTAINER only.
+
+Imports the real reference from /root/reference (never copied, never shipped to the GPU box)
+and records inputs + outputs of its hot path as small .npz fixtures under tests/golden/.
+
+  python oracle/gen_golden.py            # regenerates every fixture
+
+How the reference is loaded:
+  * models/gaussian_diffusion.py imports as-is (`sys.path.insert(0, "/root/reference")`).
+  * models/DNN.py and evaluate_utils.py import modules absent from this image
+    (torch_geometric, bottleneck) at module level, and lightGCN.py runs a training script at
+    import.  We therefore `ast`-extract ONLY the hot-path definitions (class DNN +
+    timestep_embedding; computeTopNAccuracy; class LightGCN) from the files where they lie
+    and exec those definitions unmodified.  No stand-in libraries are created.
+Fixtures are data only: inputs (weights, rows, timesteps, noise, dropout keep-masks, initial
+Lt_history) and the reference's outputs.
+"""
+import ast
+import math
+import os
+import sys
+
+import numpy as np
+import pandas as pd
+import scipy.sparse as sp
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+
+
+def _extract(path, names, ns):
+    tree = ast.parse(open(path).read())
+    keep = [n for n in tree.body if isinstance(n, (ast.ClassDef, ast.FunctionDef)) and n.name in names]
+    assert {n.name for n in keep} == set(names), (path, names)
+    exec(compile(ast.Module(body=keep, type_ignores=[]), path, "exec"), ns)
+    return [ns[n] for n in names]
+
+
+import models.gaussian_diffusion as gd  # noqa: E402  (the real reference)
+
+_ns = dict(torch=torch, nn=nn, F=F, np=np, math=math)
+RefDNN, ref_timestep_embedding = _extract(f"{REF}/models/DNN.py", ["DNN", "timestep_embedding"], _ns)
+(ref_topn,) = _extract(f"{REF}/evaluate_utils.py", ["computeTopNAccuracy"], dict(math=math, np=np, torch=torch))
+
+
+def npy(t):
+    return t.detach().cpu().numpy().copy()
+
+
+def make_rows(B, I, density, gen):
+    x = (torch.rand(B, I, generator=gen) < density).float()
+    if B >= 4:
+        x[1] = 0.0  # an empty user row
+        x[2, : max(1, I // 3)] = 1.0  # a heavy user row
+    return x
+
+
+def sd_np(model, prefix="sd."):
+    return {prefix + k: npy(v) for k, v in model.state_dict().items()}
+
+
+# ----------------------------------------------------------------------------------------
+def gen_schedules():
+    out = {}
+    combos = [
+        ("linear-var", 0.01, 0.001, 0.01, 5),
+        ("linear-var", 0.1, 0.001, 0.01, 100),
+        ("linear-var", 0.005, 0.0005, 0.005, 40),
+        ("linear", 0.1, 0.001, 0.01, 10),
+        ("linear", 1.0, 0.0001, 0.02, 50),
+        ("cosine", 1.0, 0.0, 0.0, 20),
+        ("binomial", 1.0, 0.0, 0.0, 8),
+    ]
+    names = []
+    for i, (sch, scale, mn, mx, T) in enumerate(combos):
+        d = gd.GaussianDiffusion(gd.ModelMeanType.START_X, sch, scale, mn, mx, T, "cpu")
+        key = f"c{i}"
+        names.append(f"{key}|{sch}|{scale}|{mn}|{mx}|{T}")
+        for tab in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "alphas_cumprod_next",
+                    "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod", "log_one_minus_alphas_cumprod",
+                    "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod", "posterior_variance",
+                    "posterior_log_variance_clipped", "posterior_mean_coef1", "posterior_mean_coef2"):
+            out[f"{key}.{tab}"] = npy(getattr(d, tab))
+        t = torch.arange(T)
+        w = d.SNR(t - 1) - d.SNR(t)
+        out[f"{key}.snr_weight_x0"] = npy(torch.where(t == 0, 1.0, w))
+    out["combos"] = np.array(names)
+    # timestep embedding + normal_kl known answers
+    ts = torch.tensor([0, 1, 2, 3, 4, 7, 39, 99])
+    for dim in (10, 7, 16):
+        out[f"temb.{dim}"] = npy(ref_timestep_embedding(ts, dim))
+    out["temb.ts"] = npy(ts)
+    g = torch.Generator().manual_seed(5)
+    m1, lv1, m2, lv2 = [torch.randn(6, 9, generator=g) for _ in range(4)]
+    out["kl.m1"], out["kl.lv1"], out["kl.m2"], out["kl.lv2"] = map(npy, (m1, lv1, m2, lv2))
+    out["kl.out"] = npy(gd.normal_kl(m1, lv1, m2, lv2))
+    np.savez_compressed(os.path.join(OUT, "schedules.npz"), **out)
+
+
+# ----------------------------------------------------------------------------------------
+def gen_train(name, B, I, dims, T, mean_type, schedule="linear-var", scale=0.01, nmin=0.001, nmax=0.01,
+              n_steps=3, lr=1e-3, wd=0.0, seed=0, density=0.1, importance=False, emb=10, norm=False):
+    torch.manual_seed(seed)
+    g = torch.Generator().manual_seed(seed + 100)
+    model = RefDNN([I] + dims, dims[::-1] + [I], emb, time_type="cat", norm=norm)
+    mt = {"x0": gd.ModelMeanType.START_X, "eps": gd.ModelMeanType.EPSILON}[mean_type]
+    diff = gd.GaussianDiffusion(mt, schedule, scale, nmin, nmax, T, "cpu")
+    opt = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=wd)
+    out = dict(sd_np(model))
+    out["meta"] = np.array([f"{B}|{I}|{','.join(map(str, dims))}|{T}|{mean_type}|{schedule}|{scale}|{nmin}|{nmax}|"
+                            f"{n_steps}|{lr}|{wd}|{emb}|{int(norm)}"])
+    if importance:  # pre-fill the ring buffer so that the importance branch is live
+        diff.Lt_history = torch.rand(T, 10, generator=g, dtype=torch.float64) * 50 + 0.5
+        diff.Lt_count = torch.full((T,), 10, dtype=torch.int64)
+    out["Lt_history0"], out["Lt_count0"] = npy(diff.Lt_history), npy(diff.Lt_count)
+
+    cap = {}
+    orig_st, orig_q, orig_mn = diff.sample_timesteps, diff.q_sample, gd.th.multinomial
+
+    def st(*a, **k):
+        t, pt = orig_st(*a, **k)
+        cap["ts"], cap["pt"] = t.clone(), pt.clone()
+        return t, pt
+
+    def q(x, t, noise=None):
+        cap["noise"] = noise.clone()
+        r = orig_q(x, t, noise)
+        cap["x_t"] = r.clone()
+        return r
+
+    def mn(p, *a, **k):
+        cap["p_all"] = p.clone()
+        return orig_mn(p, *a, **k)
+
+    diff.sample_timesteps, diff.q_sample = st, q
+    gd.th.multinomial = mn
+    model.drop.register_forward_hook(lambda m, i, o: cap.update(drop_in=i[0].clone(), drop_out=o.clone()))
+    model.in_layers[-1].register_forward_hook(lambda m, i, o: cap.update(h_pre=o.clone()))
+    model.register_forward_hook(lambda m, i, o: cap.update(model_output=o.clone()))
+
+    model.train()
+    for s in range(n_steps):
+        x = make_rows(B, I, density, g)
+        opt.zero_grad()
+        terms = diff.training_losses(model, x, True)
+        loss = terms["loss"].mean()
+        loss.backward()
+        mask = (cap["drop_out"] != 0)
+        # the keep-mask is only ambiguous where the dropout input is exactly 0 (never with noise on)
+        assert (cap["drop_in"] != 0).all()
+        assert torch.equal(cap["drop_out"], cap["drop_in"] * mask.float() * 2.0)
+        p = f"s{s}."
+        out[p + "x_start"] = npy(x).astype(np.uint8)
+        out[p + "ts"], out[p + "pt"] = npy(cap["ts"]), npy(cap["pt"])
+        out[p + "noise"] = npy(cap["noise"])
+        out[p + "drop_mask"] = npy(mask).astype(np.uint8)
+        out[p + "x_t"] = npy(cap["x_t"])
+        out[p + "h"] = npy(torch.tanh(cap["h_pre"]))
+        out[p + "model_output"] = npy(cap["model_output"])
+        out[p + "loss_vec"] = npy(terms["loss"])
+        out[p + "loss"] = npy(loss)
+        if "p_all" in cap:
+            out[p + "p_all"] = npy(cap.pop("p_all"))
+        if s == 0:
+            for k, v in model.named_parameters():
+                out["g0." + k] = npy(v.grad)
+        opt.step()
+        out[p + "Lt_history"], out[p + "Lt_count"] = npy(diff.Lt_history), npy(diff.Lt_count)
+        if s == n_steps - 1:
+            for k, v in model.named_parameters():
+                out["pN." + k] = npy(v)
+    for k, v in model.named_parameters():
+        st_ = opt.state[v]
+        out["m." + k], out["v." + k] = npy(st_["exp_avg"]), npy(st_["exp_avg_sq"])
+    gd.th.multinomial = orig_mn
+    np.savez_compressed(os.path.join(OUT, f"train_{name}.npz"), **out)
+    ts_all = np.concatenate([out[f"s{s}.ts"] for s in range(n_steps)])
+    print(f"train_{name}: loss0={float(out['s0.loss']):.6g} has_t0={bool((ts_all == 0).any())}")
+
+
+# ----------------------------------------------------------------------------------------
+def gen_sample(name, B, I, dims, T, mean_type, seed=0, density=0.08, scale=0.01, nmin=0.001, nmax=0.01, k=20):
+    torch.manual_seed(seed)
+    g = torch.Generator().manual_seed(seed + 7)
+    model = RefDNN([I] + dims, dims[::-1] + [I], 10, time_type="cat", norm=False)
+    # spread the outputs so that top-k gaps are far above fp32 summation-order noise
+    with torch.no_grad():
+        model.out_layers[-1].bias.normal_(0.0, 0.5, generator=g)
+    model.eval()
+    mt = {"x0": gd.ModelMeanType.START_X, "eps": gd.ModelMeanType.EPSILON}[mean_type]
+    diff = gd.GaussianDiffusion(mt, "linear-var", scale, nmin, nmax, T, "cpu")
+    x = make_rows(B, I, density, g)
+    out = dict(sd_np(model))
+    out["meta"] = np.array([f"{B}|{I}|{','.join(map(str, dims))}|{T}|{mean_type}|{scale}|{nmin}|{nmax}|{k}"])
+    out["x_start"] = npy(x).astype(np.uint8)
+    cap = {"noises": []}
+    orig_randn = gd.th.randn_like
+
+    def rl(t):
+        n = orig_randn(t)
+        cap["noises"].append(n.clone())
+        return n
+
+    gd.th.randn_like = rl
+    with torch.no_grad():
+        # (a) steps=0, deterministic (what the shipped YAML uses)
+        out["pred_steps0"] = npy(diff.p_sample(model, x, 0, False))
+        # (b) steps=T: q_sample at t=T-1 first (one randn_like), deterministic reverse loop
+        cap["noises"].clear()
+        out["pred_stepsT"] = npy(diff.p_sample(model, x, T, False))
+        out["noise_stepsT"] = npy(cap["noises"][0])
+        assert len(cap["noises"]) == 1
+        # (c) steps=2 with sampling noise: 1 + T draws
+        cap["noises"].clear()
+        out["pred_noisy"] = npy(diff.p_sample(model, x, 2, True))
+        assert len(cap["noises"]) == 1 + T
+        out["noise_noisy0"] = npy(cap["noises"][0])
+        out["noise_noisy_steps"] = np.stack([npy(n) for n in cap["noises"][1:]])
+        # per-step pred_xstart / mean of case (a)
+        x_t = x
+        preds, means = [], []
+        for i in list(range(T))[::-1]:
+            o = diff.p_mean_variance(model, x_t, torch.tensor([i] * B))
+            preds.append(npy(o["pred_xstart"]))
+            means.append(npy(o["mean"]))
+            x_t = o["mean"]
+        out["step_pred_xstart"], out["step_mean"] = np.stack(preds), np.stack(means)
+    gd.th.randn_like = orig_randn
+
+    # masked top-k exactly as reference main.py:296-301 (history = the training rows themselves)
+    pred = torch.from_numpy(out["pred_steps0"]).clone()
+    his = sp.csr_matrix(npy(x))
+    pred[his.nonzero()] = -np.inf
+    vals, idx = torch.topk(pred, k + 1)
+    out["topk_idx"] = npy(idx[:, :k])
+    out["topk_gap"] = npy(vals[:, k - 1] - vals[:, k])
+    out["topk_min_adjacent_gap"] = npy((vals[:, :-1] - vals[:, 1:]).min(dim=1).values)
+    # ground truth for the metric: random held-out items per user
+    gt = []
+    for b in range(B):
+        n = int(torch.randint(0, 6, (1,), generator=g))
+        gt.append(sorted(set(torch.randint(0, I, (n,), generator=g).tolist())))
+    topN = [1, 5, 10, k]
+    res = ref_topn(gt, idx[:, :k].tolist(), topN)
+    out["gt_flat"] = np.array([i for r in gt for i in r], dtype=np.int64)
+    out["gt_ptr"] = np.cumsum([0] + [len(r) for r in gt]).astype(np.int64)
+    out["topN"] = np.array(topN)
+    out["metrics"] = np.array(res, dtype=np.float64)  # rows: precision, recall, NDCG, MRR
+    np.savez_compressed(os.path.join(OUT, f"sample_{name}.npz"), **out)
+    print(f"sample_{name}: min top-k gap {out['topk_gap'].min():.3g}, min adjacent {out['topk_min_adjacent_gap'].min():.3g}")
+
+
+# ----------------------------------------------------------------------------------------
+def gen_lightgcn(name, U, It, d, L, nnz, seed=0):
+    import __main__
+    rng = np.random.default_rng(seed)
+    users = rng.integers(0, U, nnz)
+    items = np.minimum((rng.pareto(1.2, nnz) * It / 20).astype(np.int64), It - 1)  # skewed popularity
+    # every node gets at least one edge except the last user / item (zero-degree edge case)
+    users = np.concatenate([users, np.arange(U - 1)])
+    items = np.concatenate([items, rng.integers(0, It - 1, U - 1)])
+    items = np.where(items == It - 1, 0, items)
+    df = pd.DataFrame({"user_id_idx": users, "item_id_idx": items})
+    ns = dict(torch=torch, nn=nn, sp=sp, np=np, n_users=U, n_items=It)
+    (RefLightGCN,) = _extract(f"{REF}/lightGCN.py", ["LightGCN"], ns)
+    torch.manual_seed(seed)
+    m = RefLightGCN(df, U, It, L, d)
+    A = m.norm_adj_mat_sparse_tensor.coalesce()
+    with torch.no_grad():
+        fu, fi, iu, ii = m.propagate_through_layers()
+        E = m.E0.weight
+        layers = []
+        for _ in range(L):
+            E = torch.sparse.mm(m.norm_adj_mat_sparse_tensor, E)
+            layers.append(npy(E))
+    out = dict(users=users, items=items, meta=np.array([f"{U}|{It}|{d}|{L}"]), E0=npy(m.E0.weight),
+               A_row=npy(A.indices()[0]), A_col=npy(A.indices()[1]), A_val=npy(A.values()),
+               layers=np.stack(layers), final_user=npy(fu), final_item=npy(fi))
+    np.savez_compressed(os.path.join(OUT, f"lightgcn_{name}.npz"), **out)
+    print(f"lightgcn_{name}: nnz(A)={A.values().numel()}")
+
+
+def gen_metrics():
+    """Known-answer vectors for computeTopNAccuracy incl. the survey's hand case."""
+    out = {}
+    gt = [[1, 2], [3], []]
+    pred = [[1, 5, 2], [4, 3, 9], [0, 1, 2]]
+    out["hand"] = np.array(ref_topn(gt, pred, [1, 3]), dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "metrics_hand.npz"), **out)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    gen_schedules()
+    gen_metrics()
+    gen_train("tiny_x0", 8, 64, [16], 5, "x0", seed=1)
+    gen_train("tiny_eps", 8, 64, [16], 5, "eps", seed=3)
+    gen_train("ragged_x0", 32, 515, [100], 5, "x0", seed=2, density=0.03)
+    gen_train("ragged_eps_wd", 24, 515, [100], 5, "eps", seed=4, density=0.03, wd=0.01, schedule="linear", scale=0.1, n_steps=2)
+    gen_train("imp_T40", 16, 600, [64], 40, "x0", seed=5, density=0.02, importance=True, scale=0.005,
+              nmin=0.0005, nmax=0.005)
+    gen_train("deep_x0", 16, 200, [48, 24], 5, "x0", seed=6, density=0.05, n_steps=2)
+    gen_train("norm_x0", 8, 96, [32], 5, "x0", seed=8, norm=True, n_steps=1)
+    gen_sample("tiny_x0", 8, 64, [16], 5, "x0", seed=11, k=10)
+    gen_sample("ragged_x0", 32, 515, [100], 5, "x0", seed=12, k=20)
+    gen_sample("ragged_eps", 16, 515, [100], 5, "eps", seed=13, k=20, scale=50.0)
+    gen_lightgcn("small", 50, 40, 8, 3, 300, seed=0)
+    gen_lightgcn("mid", 600, 400, 64, 3, 6000, seed=1)
