@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Benchmark of the GDMCF diffusion hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload yelp|amazon-book]
+
+One "step" = the body of the reference training loop (main.py:345-351): zero_grad ->
+GaussianDiffusion.training_losses -> mean -> backward -> AdamW.step on one batch of 400 dense user
+rows resident in HBM.  Metric: training users/sec (BASELINE.json), fp32, synthetic Yelp-shape rows
+(the reference ships no dataset), random-init weights.  N > 1: one process per GPU (torchrun), each
+rank takes its own 400-row batch (weak scaling), gradients all-reduced with RCCL.
+
+Besides the contract fields the JSON line carries
+  roofline     -- the dominant kernel's achieved rate, timed live with HIP events on the launch
+                  stream inside the timed region (gdmcf_prof_*), against the gfx950 peak;
+  cpu_baseline -- the oracle (a PyTorch-CPU restatement of the reference path, parity-pinned to
+                  the reference by tests/golden) timed on this host's cores on the same workload.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_* = 64 FLOP/clk/SIMD
+PEAK_HBM_GBPS = 8000.0
+TAGS = {1: "linear_fwd_gemm", 2: "loss_fwd_gemm", 3: "posterior_gemm", 4: "bwd_input_gemm", 5: "bwd_weight_gemm",
+        6: "adamw", 7: "prep_input", 8: "spmm_csr", 9: "topk"}
+GEMM_TAGS = (1, 2, 3, 4, 5)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="yelp", choices=["yelp", "amazon-book"])
+    ap.add_argument("--batch", type=int, default=400)
+    ap.add_argument("--hidden", type=int, default=1000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--spmm", action="store_true", help="also time the LightGCN SpMM (reported under 'spmm')")
+    return ap.parse_args()
+
+
+def collect_prof(lib, cap=65536):
+    tags = (ctypes.c_int * cap)()
+    ms = (ctypes.c_float * cap)()
+    work = (ctypes.c_double * cap)()
+    n = lib.gdmcf_prof_collect(cap, tags, ms, work)
+    out = {}
+    for i in range(n):
+        d = out.setdefault(int(tags[i]), dict(ms=0.0, work=0.0, n=0))
+        d["ms"] += float(ms[i])
+        d["work"] += float(work[i])
+        d["n"] += 1
+    return out
+
+
+def cpu_baseline(args, I, x_batches, seconds):
+    """The oracle's train step on the host cores, same shape / same rows (bounded sample)."""
+    from oracle import gdmcf_oracle as O
+    torch.manual_seed(0)
+    om = O.DNN([I, args.hidden], [args.hidden, I], 10)
+    od = O.GaussianDiffusion(O.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, 5)
+    opt = O.make_optimizer(om, 1e-5)
+    om.train()
+    xs = [torch.from_numpy(b) for b in x_batches[:2]]
+    O.train_step(od, om, opt, xs[0], True)  # warm-up (allocations, thread pool)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        O.train_step(od, om, opt, xs[n % len(xs)], True)
+        n += 1
+        el = time.perf_counter() - t0
+        if (el >= seconds and n >= 3) or n >= 50:
+            break
+    return dict(value=round(args.batch * n / el, 2), unit="users/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{n} train steps of B={args.batch}, I={I}, dims=[{args.hidden}], T=5 (oracle, PyTorch-CPU eager)",
+                ms_per_step=round(1e3 * el / n, 2))
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
+
+    import gdmcf_amd
+    from gdmcf_amd import _lib, data
+    from gdmcf_amd.parallel import DataParallelStep
+    lib = _lib.load()
+
+    B, hid, T = args.batch, args.hidden, 5
+    n_pool = 4
+    indptr, indices, I = data.synth_csr(args.workload, n_rows=(world * n_pool) * B, seed=0)
+    lo = rank * n_pool * B
+    sub_ptr = indptr[lo:lo + n_pool * B + 1] - indptr[lo]
+    sub_idx = indices[indptr[lo]:indptr[lo + n_pool * B]]
+    x_host = data.dense_batches(sub_ptr, sub_idx, I, B, n_pool)
+    x_dev = torch.from_numpy(x_host).to(dev)  # batches resident in HBM before the timed region
+
+    torch.manual_seed(0)
+    model = gdmcf_amd.DNN([I, hid], [hid, I], 10, time_type="cat", norm=False).to(dev)
+    diffusion = gdmcf_amd.GaussianDiffusion(gdmcf_amd.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, T, dev)
+    opt = gdmcf_amd.FusedAdamW(model.parameters(), lr=1e-5, weight_decay=0.0)
+    model.train()
+    torch.manual_seed(1234 + rank)
+    step = DataParallelStep(diffusion, model, opt)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    loss = None
+    for i in range(args.warmup):
+        loss = step(x_dev[i % n_pool], True)
+    sync()
+    prof = not args.no_prof
+    if prof:
+        lib.gdmcf_prof_enable(1)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(x_dev[i % n_pool], True)
+    sync()
+    el = time.perf_counter() - t0
+    kernels = collect_prof(lib) if prof else {}
+    lib.gdmcf_prof_enable(0)
+    final_loss = float(loss)
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t)
+
+    # ---- roofline of the dominant kernel (rank 0's events) ----
+    roofline, klist = None, []
+    for tag, d in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"]):
+        sec = d["ms"] * 1e-3
+        if tag in GEMM_TAGS:
+            ach, peak, unit, bound = d["work"] / sec / 1e12, PEAK_F32_MATRIX_TFLOPS, "TFLOP/s", "mfma"
+        else:
+            ach, peak, unit, bound = d["work"] / sec / 1e9, PEAK_HBM_GBPS, "GB/s", "hbm"
+        e = dict(kernel=TAGS.get(tag, str(tag)), bound=bound, achieved=round(ach, 2), peak=peak, unit=unit,
+                 frac=round(ach / peak, 4), avg_ms=round(d["ms"] / d["n"], 4), launches=d["n"],
+                 share_of_step=round(d["ms"] / (el * 1e3), 4))
+        klist.append(e)
+    if klist:
+        k0 = klist[0]
+        roofline = dict(bound=k0["bound"], achieved=k0["achieved"], peak=k0["peak"], unit=k0["unit"], frac=k0["frac"],
+                        traffic=None, kernel=k0["kernel"], avg_ms=k0["avg_ms"])
+
+    spmm = None
+    if args.spmm and rank == 0:
+        spmm = bench_spmm(gdmcf_amd, lib, args.workload, dev)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args, I, x_host, args.cpu_seconds)
+
+    if rank == 0:
+        users = world * B * args.steps
+        out = {
+            "metric": "training users/sec", "value": round(users / el, 1), "unit": "users/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}-shape synthetic rows, batch={B}/GPU, dims=[{hid}], T=5, "
+                                   f"noise_scale=0.01, linear-var, mean_type=x0, reweight, AdamW lr=1e-5 "
+                                   f"(BASELINE configs[1])",
+                       "n_items": I, "global_batch": world * B, "parallelism": f"dp{world}"},
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": klist, "final_loss": final_loss,
+        }
+        if cpu:
+            out["speedup_vs_cpu"] = round(out["value"] / cpu["value"], 1)
+        if spmm:
+            out["spmm"] = spmm
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def bench_spmm(gdmcf_amd, lib, workload, dev, layers=3, d=64, iters=20):
+    """LightGCN propagation over the whole synthetic graph: ms per layer and HBM-roofline fraction
+    (algorithmic bytes = nnz*8 + (N+1)*8 + 2*N*d*4; rowptr is int64 here)."""
+    from gdmcf_amd import data
+    cfg = data.SHAPES[workload]
+    indptr, indices, I = data.synth_csr(workload, seed=0)
+    users = np.repeat(np.arange(cfg["n_users"]), np.diff(indptr))
+    m = gdmcf_amd.LightGCN({"user_id_idx": users, "item_id_idx": indices}, cfg["n_users"], I, layers, d, device=dev).to(dev)
+    nnz = int(m.norm_adj_csr[1].numel())
+    N = cfg["n_users"] + I
+    for _ in range(3):
+        m.propagate_through_layers()
+    torch.cuda.synchronize()
+    lib.gdmcf_prof_enable(1)
+    for _ in range(iters):
+        m.propagate_through_layers()
+    torch.cuda.synchronize()
+    k = collect_prof(lib).get(8)
+    lib.gdmcf_prof_enable(0)
+    ms = k["ms"] / k["n"]
+    alg = nnz * 8.0 + (N + 1) * 8.0 + 2.0 * N * d * 4.0
+    gbps = alg / (ms * 1e-3) / 1e9
+    return dict(ms_per_layer=round(ms, 4), nnz=nnz, nodes=N, d=d, algorithmic_MB=round(alg / 1e6, 2),
+                achieved=round(gbps, 1), peak=PEAK_HBM_GBPS, unit="GB/s", frac=round(gbps / PEAK_HBM_GBPS, 4), bound="hbm")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,110 @@
+"""ctypes binding of libgdmcf_hip.so (C ABI: include/gdmcf_hip.h).
+
+The product path has NO CPU fallback: if the HIP library is missing, or a kernel is asked to run
+without a GPU, this module raises -- it never routes through PyTorch eager or the oracle.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgdmcf_hip.so")
+
+GDMCF_OK, E_SHAPE, E_ARG, E_UNSUPPORTED, E_HIP, E_WORKSPACE = 0, -1, -2, -3, -4, -5
+N_TABLES = 13
+TABLE_NAMES = (
+    "betas", "alphas_cumprod", "alphas_cumprod_prev", "alphas_cumprod_next", "sqrt_alphas_cumprod",
+    "sqrt_one_minus_alphas_cumprod", "log_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod",
+    "sqrt_recipm1_alphas_cumprod", "posterior_variance", "posterior_log_variance_clipped",
+    "posterior_mean_coef1", "posterior_mean_coef2",
+)
+
+P = c_void_p
+_SIGNATURES = {
+    "gdmcf_version": (c_int, []),
+    "gdmcf_last_error": (c_char_p, []),
+    "gdmcf_device_info": (c_int, [P, P, c_char_p, c_int]),
+    "gdmcf_prof_enable": (c_int, [c_int]),
+    "gdmcf_prof_collect": (c_int, [c_int, P, P, P]),
+    "gdmcf_schedule_build": (c_int, [c_int, c_double, c_double, c_double, c_int, c_int, P]),
+    "gdmcf_dnn_prep_input_f32": (c_int, [P, c_int64, P, P, P, c_int, P, c_int64, c_int, P, c_int64, c_float, c_uint64,
+                                         c_uint64, c_int, P, P, c_int, c_int, c_int, P, c_int64, P, c_int64, P, P, P]),
+    "gdmcf_dnn_emb_cols_f32": (c_int, [P, P, P, c_int, c_int, c_int, P, c_int64, P, P]),
+    "gdmcf_linear_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "gdmcf_linear_fwd_f32": (c_int, [P, c_int64, P, c_int64, P, c_int, c_int, c_int, c_int, P, c_int64, P, c_size_t, P]),
+    "gdmcf_loss_tiles": (c_int, [c_int]),
+    "gdmcf_linear_loss_fwd_f32": (c_int, [P, c_int64, P, c_int64, P, P, c_int64, P, c_int, c_int, c_int, P, c_int64, P,
+                                          c_int64, P, P, P]),
+    "gdmcf_linear_posterior_fwd_f32": (c_int, [P, c_int64, P, c_int64, P, P, c_int64, P, P, P, P, P, P, c_int64, c_int,
+                                               c_int, c_int, P, c_int64, P, c_int64, P]),
+    "gdmcf_linear_bwd_input_f32": (c_int, [P, c_int64, P, c_int64, P, P, c_int64, c_int, c_int, c_int, c_int, P,
+                                           c_int64, P, c_size_t, P]),
+    "gdmcf_linear_bwd_weight_f32": (c_int, [P, c_int64, P, c_int64, P, c_int, c_int, c_int, P, c_int64, P, c_int, P]),
+    "gdmcf_rowscale_f32": (c_int, [P, c_int64, P, c_int, c_int, P, c_int64, P]),
+    "gdmcf_emb_bwd_f32": (c_int, [P, c_int64, P, c_int64, c_int, c_int, P, c_int, c_int, P, P, P, P]),
+    "gdmcf_row_loss_finish_f64": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, P, P, c_int, P, P, P, P]),
+    "gdmcf_lt_history_update": (c_int, [P, P, c_int, c_int, c_int, P, P, P]),
+    "gdmcf_adamw_f32": (c_int, [P, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_int, c_float, P]),
+    "gdmcf_topk_masked_f32": (c_int, [P, c_int64, c_int, c_int, P, P, c_int, P, P, P]),
+    "gdmcf_spmm_csr_f32": (c_int, [P, P, P, c_int, P, c_int64, c_int, P, c_int64, P, c_int64, P]),
+    "gdmcf_scale_f32": (c_int, [P, c_int64, c_float, P, P]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load():
+    """Loads the shared library (building nothing).  Raises ImportError when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -m gdmcf_amd.build` (hipcc, gfx950). "
+            "gdmcf_amd has no CPU / PyTorch fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError -> the .so is stale; rebuild
+        fn.restype = res
+        fn.argtypes = args
+    if lib.gdmcf_version() != 1:
+        raise ImportError("libgdmcf_hip.so ABI version mismatch; rebuild with `python -m gdmcf_amd.build --force`")
+    _lib = lib
+    return lib
+
+
+_EXC = {E_SHAPE: AssertionError, E_ARG: ValueError, E_UNSUPPORTED: NotImplementedError, E_HIP: RuntimeError,
+        E_WORKSPACE: RuntimeError}
+
+
+def check(rc):
+    if rc != GDMCF_OK:
+        msg = load().gdmcf_last_error().decode(errors="replace")
+        raise _EXC.get(rc, RuntimeError)(msg or f"gdmcf error {rc}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (or None)."""
+    return None if t is None else t.data_ptr()
+
+
+def require_gpu(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(f"gdmcf_amd: {what} must live on the MI355X (got device '{t.device}'); "
+                           "the HIP path has no CPU fallback")
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def schedule_tables(kind, noise_scale, noise_min, noise_max, steps, beta_fixed=True):
+    """Host float64 tables [13][T] via the C ABI (no GPU needed)."""
+    import numpy as np
+    out = np.zeros((N_TABLES, steps), dtype=np.float64)
+    rc = load().gdmcf_schedule_build(kind, float(noise_scale), float(noise_min), float(noise_max), int(steps),
+                                     int(bool(beta_fixed)), out.ctypes.data_as(c_void_p))
+    check(rc)
+    return out

@@ -1,0 +1,98 @@
+// Shared declarations for libgdmcf_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/gdmcf_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+void gdmcf_set_error(const char* fmt, ...);
+
+#define GD_CHECK_SHAPE(cond, msg)            \
+    do {                                     \
+        if (!(cond)) {                       \
+            gdmcf_set_error("%s", msg);      \
+            return GDMCF_E_SHAPE;            \
+        }                                    \
+    } while (0)
+
+#define GD_CHECK_ARG(cond, msg)              \
+    do {                                     \
+        if (!(cond)) {                       \
+            gdmcf_set_error("%s", msg);      \
+            return GDMCF_E_ARG;              \
+        }                                    \
+    } while (0)
+
+static inline int gd_launch_status(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        gdmcf_set_error("%s: %s", what, hipGetErrorString(e));
+        return GDMCF_E_HIP;
+    }
+    return GDMCF_OK;
+}
+
+// ---- optional event timing (capi.hip) ----------------------------------------------------
+extern bool g_gd_prof_on;
+void gd_prof_begin(int tag, double work, hipStream_t s);
+void gd_prof_end(hipStream_t s);
+struct GdProfScope {
+    hipStream_t s;
+    bool on;
+    GdProfScope(int tag, double work, hipStream_t st) : s(st), on(g_gd_prof_on) {
+        if (on) gd_prof_begin(tag, work, s);
+    }
+    ~GdProfScope() {
+        if (on) gd_prof_end(s);
+    }
+};
+
+static inline int gd_cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline bool gd_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- GEMM core (gemm_f32.hip) -----------------------------------------------------------
+enum { GD_LAY_KC = 0, GD_LAY_MC = 1 };  // operand stored [rows][K] (K contiguous) / [K][rows]
+enum { GD_EPI_SLAB = 0, GD_EPI_BIAS_ACT = 1, GD_EPI_LOSS = 2, GD_EPI_POST = 3, GD_EPI_STORE = 4 };
+
+struct GdGemm {
+    const float* A;
+    int64_t lda;
+    const float* B;
+    int64_t ldb;
+    int M, N, K;
+    int kchunk;  // K range per split (multiple of the kernel's BK)
+    int splits;
+    int tiles_m, tiles_n;
+    int m_fastest;  // tile order inside one split
+    int veca, vecb;  // 16-byte vector loads legal for A / B
+    float* C;
+    int64_t ldc;
+    int64_t slab_stride;
+    const float* bias;
+    int act;
+    const float* aux;  // target (LOSS) / x_t (POST)
+    int64_t ldaux;
+    const float* aux2;  // z noise (POST)
+    int64_t ldaux2;
+    const float* r0;  // LOSS: alpha[m];  POST: c1[m]
+    const float* r1;  // POST: c2
+    const float* r2;  // POST: r1 (eps) or NULL
+    const float* r3;  // POST: r2 (eps)
+    const float* r4;  // POST: sigma
+    float* out2;  // LOSS: raw model output;  POST: pred_xstart
+    int64_t ldout2;
+    float* rowpart;
+    int ld_rowpart;
+    int accumulate;
+    int prof_tag;
+};
+
+// shape classes: 0 = "batch-M" (BM=80, BN=128), 1 = square 128x128, 2 = small 64x64
+int gd_gemm_launch(int layA, int layB, int epi, int shape_class, GdGemm& g, hipStream_t s);
+int gd_gemm_tile_m(int shape_class);
+int gd_gemm_tile_n(int shape_class);
+int gd_gemm_bk(int layA, int layB);
+int gd_pick_shape_class(int M, int N);

@@ -1,0 +1,542 @@
+// HBM-bound kernels of the diffusion hot path: denoiser-input builder (q_sample + normalize +
+// dropout + timestep embedding + cat), split-K reducers, bias/embedding gradients, the float64
+// per-row loss tail with the Lt-history FIFO, and the fused multi-tensor AdamW.
+#include <math.h>
+
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 (counter-based: any element can be regenerated in any kernel, so noise and
+// dropout masks never have to be stored).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+    constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint32_t hi0 = __umulhi(M0, c.x), lo0 = M0 * c.x;
+        const uint32_t hi1 = __umulhi(M1, c.z), lo1 = M1 * c.z;
+        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+        k.x += W0;
+        k.y += W1;
+    }
+    return c;
+}
+
+__device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& z0, float& z1) {
+    const float u1 = ((float)a + 1.0f) * 2.3283064365386963e-10f;  // (0,1]
+    const float u2 = (float)b * 2.3283064365386963e-10f;
+    const float rad = sqrtf(-2.0f * logf(u1));
+    float s, c;
+    sincosf(6.283185307179586f * u2, &s, &c);
+    z0 = rad * c;
+    z1 = rad * s;
+}
+
+struct PrepArgs {
+    const float* x;
+    int64_t ldx;
+    const int64_t* ts;
+    const float* ca;
+    const float* cb;
+    int noise_mode;
+    const float* noise;
+    int64_t ldn;
+    int drop_mode;
+    const uint8_t* keep;
+    int64_t ldkeep;
+    float drop_scale;  // 1/(1-p)
+    uint32_t keep_thresh;  // Philox: keep iff u < thresh
+    uint64_t seed, offset;
+    const float* rownorm;  // [B] L2 norms of x_t rows (normalize) or NULL
+    const float* emb_w;
+    const float* emb_b;
+    int E, B, I;
+    float* xin;
+    int64_t ldxin;
+    float* xt_out;
+    int64_t ldxt;
+    float* temb_out;
+};
+
+__device__ __forceinline__ float temb_value(float t, int f, int E) {
+    // reference models/DNN.py:1817-1825: [cos(t*freqs), sin(t*freqs), (0 if E odd)]
+    const int half = E / 2;
+    if (f >= 2 * half) return 0.f;
+    const int j = (f < half) ? f : f - half;
+    const float freq = expf(-9.210340371976184f * (float)j / (float)half);
+    const float a = t * freq;
+    return (f < half) ? cosf(a) : sinf(a);
+}
+
+// x_t for 4 consecutive columns of one row (shared by the row-norm pass and the main pass)
+__device__ __forceinline__ void xt4(const PrepArgs& a, int b, int col, float ca, float cb, float (&v)[4]) {
+    const float* xr = a.x + (int64_t)b * a.ldx;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = (col + j < a.I) ? xr[col + j] : 0.f;
+    if (a.ca) {
+        float nz[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a.noise_mode == 1) {
+            const float* nr = a.noise + (int64_t)b * a.ldn;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (col + j < a.I) nz[j] = nr[col + j];
+        } else if (a.noise_mode == 2) {
+            const uint4 r = philox4x32_10(make_uint4((uint32_t)(col >> 2), (uint32_t)b, 0u, (uint32_t)a.offset),
+                                          make_uint2((uint32_t)a.seed, (uint32_t)(a.seed >> 32)));
+            box_muller(r.x, r.y, nz[0], nz[1]);
+            box_muller(r.z, r.w, nz[2], nz[3]);
+        }
+#pragma unroll
+        // two rounded products + one rounded sum, exactly as the reference's mul, mul, add (:403-407)
+        for (int j = 0; j < 4; ++j) v[j] = __fadd_rn(__fmul_rn(ca, v[j]), __fmul_rn(cb, nz[j]));
+    }
+}
+
+__global__ __launch_bounds__(256) void prep_rowss_kernel(const PrepArgs a, float* __restrict__ rownorm) {
+    const int b = blockIdx.x;
+    float ca = 1.f, cb = 0.f;
+    if (a.ca) {
+        const int64_t t = a.ts[b];
+        ca = a.ca[t];
+        cb = a.cb[t];
+    }
+    float ss = 0.f;
+    for (int col = threadIdx.x * 4; col < a.I; col += 256 * 4) {
+        float v[4];
+        xt4(a, b, col, ca, cb, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ss += v[j] * v[j];
+    }
+    __shared__ float red[4];
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) rownorm[b] = sqrtf(red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void prep_input_kernel(const PrepArgs a) {
+    const int b = blockIdx.y;
+    const int col = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (col >= a.ldxin) return;
+    const int64_t t = a.ts ? a.ts[b] : 0;
+    float ca = 1.f, cb = 0.f;
+    if (a.ca) {
+        ca = a.ca[t];
+        cb = a.cb[t];
+    }
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (col < a.I) {
+        xt4(a, b, col, ca, cb, v);
+        if (a.xt_out) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (col + j < a.I) a.xt_out[(int64_t)b * a.ldxt + col + j] = v[j];
+        }
+        if (a.rownorm) {
+            const float dn = fmaxf(a.rownorm[b], 1e-12f);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = v[j] / dn;
+        }
+        if (a.drop_mode == 1) {
+            const uint8_t* kr = a.keep + (int64_t)b * a.ldkeep;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (col + j < a.I) v[j] = kr[col + j] ? v[j] * a.drop_scale : 0.f;
+        } else if (a.drop_mode == 2) {
+            const uint4 r = philox4x32_10(make_uint4((uint32_t)(col >> 2), (uint32_t)b, 1u, (uint32_t)a.offset),
+                                          make_uint2((uint32_t)a.seed, (uint32_t)(a.seed >> 32)));
+            const uint32_t u[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (u[j] < a.keep_thresh) ? v[j] * a.drop_scale : 0.f;
+        }
+    }
+    // timestep-embedding columns [I, I+E) and zero padding up to ldxin
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = col + j;
+        if (i >= a.I) {
+            float e = 0.f;
+            if (i < a.I + a.E) {
+                const int eo = i - a.I;
+                e = a.emb_b[eo];
+                for (int f = 0; f < a.E; ++f) e += a.emb_w[eo * a.E + f] * temb_value((float)t, f, a.E);
+                if (a.temb_out) a.temb_out[(int64_t)b * a.E + eo] = temb_value((float)t, eo, a.E);
+            }
+            v[j] = e;
+        }
+    }
+    *reinterpret_cast<f32x4*>(a.xin + (int64_t)b * a.ldxin + col) = f32x4{v[0], v[1], v[2], v[3]};
+}
+
+__global__ void emb_cols_kernel(const int64_t* __restrict__ ts, const float* __restrict__ emb_w,
+                                const float* __restrict__ emb_b, int E, int I, float* __restrict__ xin, int64_t ldxin,
+                                float* __restrict__ temb_out) {
+    const int b = blockIdx.x;
+    const float t = (float)ts[b];
+    for (int i = I + threadIdx.x; i < ldxin; i += blockDim.x) {
+        float e = 0.f;
+        if (i < I + E) {
+            const int eo = i - I;
+            e = emb_b[eo];
+            for (int f = 0; f < E; ++f) e += emb_w[eo * E + f] * temb_value(t, f, E);
+            if (temb_out) temb_out[(int64_t)b * E + eo] = temb_value(t, eo, E);
+        }
+        xin[(int64_t)b * ldxin + i] = e;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// split-K slab reducers (fixed slab order -> deterministic)
+// ---------------------------------------------------------------------------------------------
+// mode 0: out = act(sum + bias[n]);  mode 1: out = rowscale[m] * sum * (act ? 1 - aact^2 : 1)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int64_t slab_stride,
+                                                            int splits, int64_t ld_slab, int M, int N, int mode,
+                                                            const float* __restrict__ bias,
+                                                            const float* __restrict__ rowscale,
+                                                            const float* __restrict__ aact, int64_t ldact, int act,
+                                                            float* __restrict__ out, int64_t ldo) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)M * N) return;
+    const int m = (int)(e / N), n = (int)(e % N);
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += slabs[(int64_t)k * slab_stride + (int64_t)m * ld_slab + n];
+    if (mode == 0) {
+        if (bias) s += bias[n];
+        if (act == 1) s = tanhf(s);
+    } else {
+        if (rowscale) s *= rowscale[m];
+        if (act == 1) {
+            const float h = aact[(int64_t)m * ldact + n];
+            s *= (1.f - h * h);
+        }
+    }
+    out[(int64_t)m * ldo + n] = s;
+}
+
+__global__ __launch_bounds__(256) void rowscale_kernel(const float* __restrict__ A, int64_t lda,
+                                                       const float* __restrict__ rs, int M, int K,
+                                                       float* __restrict__ out, int64_t ldo) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)M * K) return;
+    const int m = (int)(e / K), k = (int)(e % K);
+    out[(int64_t)m * ldo + k] = A[(int64_t)m * lda + k] * rs[m];
+}
+
+// db[n] = sum_m rs[m]*dZ[m,n]; rows in fixed order, 8 independent loads in flight per thread
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dZ, int64_t ld,
+                                                     const float* __restrict__ rs, int M, int N,
+                                                     float* __restrict__ db) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    int m = 0;
+    for (; m + 8 <= M; m += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = dZ[(int64_t)(m + j) * ld + n] * (rs ? rs[m + j] : 1.f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[j];
+    }
+    for (; m < M; ++m) s += dZ[(int64_t)m * ld + n] * (rs ? rs[m] : 1.f);
+    db[n] = s;
+}
+
+// demb[m,e] = sum_n dZ1[m,n] * W1[n, I+e]   (one workgroup per row m, one wave slice per e)
+__global__ __launch_bounds__(256) void emb_bwd_demb_kernel(const float* __restrict__ dZ1, int64_t lddz,
+                                                           const float* __restrict__ W1, int64_t ldw, int I, int E,
+                                                           int N, float* __restrict__ demb) {
+    const int m = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int e = wave; e < E; e += 4) {
+        float s = 0.f;
+        for (int n = lane; n < N; n += 64) s += dZ1[(int64_t)m * lddz + n] * W1[(int64_t)n * ldw + I + e];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) demb[(int64_t)m * E + e] = s;
+    }
+}
+
+// dWe[e,f] = sum_m demb[m,e]*temb[m,f];  dbe[e] = sum_m demb[m,e]
+__global__ void emb_bwd_w_kernel(const float* __restrict__ demb, const float* __restrict__ temb, int M, int E,
+                                 float* __restrict__ dWe, float* __restrict__ dbe) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < E * E) {
+        const int e = idx / E, f = idx % E;
+        float s = 0.f;
+        for (int m = 0; m < M; ++m) s += demb[(int64_t)m * E + e] * temb[(int64_t)m * E + f];
+        dWe[idx] = s;
+    } else if (idx < E * E + E) {
+        const int e = idx - E * E;
+        float s = 0.f;
+        for (int m = 0; m < M; ++m) s += demb[(int64_t)m * E + e];
+        dbe[e] = s;
+    }
+}
+
+// rowsum[m] = sum_j rowpart[m, j] in fixed order
+__global__ __launch_bounds__(256) void rowpart_reduce_kernel(const float* __restrict__ rowpart, int ld, int M, int nt,
+                                                             float* __restrict__ rowsum) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    float s = 0.f;
+    for (int j = 0; j < nt; ++j) s += rowpart[(int64_t)m * ld + j];
+    rowsum[m] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// float64 loss tail + Lt-history FIFO (reference gaussian_diffusion.py:339-370)
+// ---------------------------------------------------------------------------------------------
+__device__ void lt_history_serial(const int64_t* ts, const double* lu, int B, int H, double* hist, int64_t* cnt) {
+    // strictly in batch order: the FIFO is order dependent (reference :355-368)
+    for (int b = 0; b < B; ++b) {
+        const int64_t t = ts[b];
+        double* row = hist + t * H;
+        if (cnt[t] == H) {
+            for (int j = 0; j + 1 < H; ++j) row[j] = row[j + 1];
+            row[H - 1] = lu[b];
+        } else {
+            row[cnt[t]] = lu[b];
+            cnt[t] += 1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void row_loss_finish_kernel(const float* __restrict__ rowsum,
+                                                              const float* __restrict__ rowdiv,
+                                                              const float* __restrict__ alpha,
+                                                              float* __restrict__ gradcoef,
+                                                              const int64_t* __restrict__ ts,
+                                                              const double* __restrict__ weight_t,
+                                                              const double* __restrict__ pt, int B, int H,
+                                                              double* hist, int64_t* cnt, int update,
+                                                              double* __restrict__ lu, double* __restrict__ loss) {
+    for (int b = threadIdx.x; b < B; b += 256) {
+        const float mse = rowsum[b] / rowdiv[b];  // f32 mean, as mean_flat on f32 (:335)
+        lu[b] = weight_t[ts[b]] * (double)mse;    // f64 weight * f32 mse -> f64 (:352)
+        if (gradcoef)
+            gradcoef[b] = (float)(2.0 * (alpha ? (double)alpha[b] : 1.0) * weight_t[ts[b]] /
+                                  (pt[b] * (double)rowdiv[b]));
+    }
+    __syncthreads();
+    if (update && threadIdx.x == 0) lt_history_serial(ts, lu, B, H, hist, cnt);
+    for (int b = threadIdx.x; b < B; b += 256) loss[b] = lu[b] / pt[b];  // (:370)
+}
+
+__global__ void lt_history_update_kernel(const int64_t* ts, const double* lu, int B, int H, double* hist,
+                                         int64_t* cnt) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) lt_history_serial(ts, lu, B, H, hist, cnt);
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused multi-tensor AdamW (torch.optim.AdamW single-tensor math, reference main.py:258,351)
+// ---------------------------------------------------------------------------------------------
+constexpr int ADAM_BLOCK_ELEMS = 4096;
+
+struct AdamHyper {
+    float decay;      // 1 - lr*wd
+    float one_m_b1;   // 1 - beta1
+    float beta2;
+    float one_m_b2;
+    float bc2_sqrt;   // sqrt(1 - beta2^step)
+    float eps;
+    float neg_step;   // -lr / (1 - beta1^step)
+    float grad_scale;
+};
+
+__device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, const AdamHyper& h) {
+    g *= h.grad_scale;
+    p = p * h.decay;
+    m = m + (g - m) * h.one_m_b1;
+    v = v * h.beta2;
+    v = v + (h.one_m_b2 * g) * g;
+    const float denom = sqrtf(v) / h.bc2_sqrt + h.eps;
+    p = p + (h.neg_step * m) / denom;
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(const int64_t* __restrict__ table, int n_tensors,
+                                                    const AdamHyper h) {
+    int t = 0;
+    for (int i = 1; i < n_tensors; ++i)
+        if ((int64_t)blockIdx.x >= table[i * 6 + 5]) t = i;
+    float* p = reinterpret_cast<float*>(table[t * 6 + 0]);
+    const float* g = reinterpret_cast<const float*>(table[t * 6 + 1]);
+    float* m = reinterpret_cast<float*>(table[t * 6 + 2]);
+    float* v = reinterpret_cast<float*>(table[t * 6 + 3]);
+    const int64_t n = table[t * 6 + 4];
+    const int64_t base = ((int64_t)blockIdx.x - table[t * 6 + 5]) * ADAM_BLOCK_ELEMS;
+    const bool al = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                      reinterpret_cast<uintptr_t>(v)) & 15u) == 0;
+#pragma unroll
+    for (int it = 0; it < ADAM_BLOCK_ELEMS / (256 * 4); ++it) {
+        const int64_t i = base + (int64_t)(it * 256 + threadIdx.x) * 4;
+        if (al && i + 3 < n) {
+            f32x4 pp = *reinterpret_cast<f32x4*>(p + i);
+            const f32x4 gg = *reinterpret_cast<const f32x4*>(g + i);
+            f32x4 mm = *reinterpret_cast<f32x4*>(m + i);
+            f32x4 vv = *reinterpret_cast<f32x4*>(v + i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float pj = pp[j], mj = mm[j], vj = vv[j];
+                adam_elem(pj, gg[j], mj, vj, h);
+                pp[j] = pj;
+                mm[j] = mj;
+                vv[j] = vj;
+            }
+            *reinterpret_cast<f32x4*>(p + i) = pp;
+            *reinterpret_cast<f32x4*>(m + i) = mm;
+            *reinterpret_cast<f32x4*>(v + i) = vv;
+        } else {
+            for (int j = 0; j < 4; ++j)
+                if (i + j < n) adam_elem(p[i + j], g[i + j], m[i + j], v[i + j], h);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void scale_kernel(const float* __restrict__ a, int64_t n, float s,
+                                                    float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = a[i] * s;
+}
+
+}  // namespace
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+int gdmcf_dnn_prep_input_f32(const float* x, int64_t ldx, const int64_t* ts, const float* ca, const float* cb,
+                             int noise_mode, const float* noise, int64_t ldn, int drop_mode, const uint8_t* keep,
+                             int64_t ldkeep, float drop_p, uint64_t seed, uint64_t offset, int normalize,
+                             const float* emb_w, const float* emb_b, int E, int B, int I, float* xin, int64_t ldxin,
+                             float* xt_out, int64_t ldxt, float* temb_out, float* rownorm_ws, void* stream) {
+    GD_CHECK_SHAPE(B > 0 && I > 0 && E >= 0, "prep_input: empty batch");
+    GD_CHECK_SHAPE(ldxin >= I + E && (ldxin % 4) == 0 && gd_aligned16(xin), "prep_input: xin must be 16B aligned, ld%4==0");
+    GD_CHECK_SHAPE(ldx >= I, "prep_input: ldx < I");
+    GD_CHECK_ARG((ca == nullptr) == (cb == nullptr), "prep_input: ca/cb must both be set or both NULL");
+    GD_CHECK_ARG(noise_mode >= 0 && noise_mode <= 2 && drop_mode >= 0 && drop_mode <= 2, "prep_input: bad mode");
+    GD_CHECK_ARG(noise_mode != 1 || (noise && ldn >= I), "prep_input: explicit noise missing");
+    GD_CHECK_ARG(drop_mode != 1 || (keep && ldkeep >= I), "prep_input: explicit keep-mask missing");
+    GD_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "prep_input: dropout p out of range");
+    GD_CHECK_ARG(E == 0 || (emb_w && emb_b && ts), "prep_input: embedding weights / ts missing");
+    GD_CHECK_ARG(!ca || ts, "prep_input: ts missing");
+    PrepArgs a;
+    a.x = x; a.ldx = ldx; a.ts = ts; a.ca = ca; a.cb = cb; a.noise_mode = ca ? noise_mode : 0; a.noise = noise;
+    a.ldn = ldn; a.drop_mode = drop_mode; a.keep = keep; a.ldkeep = ldkeep; a.drop_scale = 1.0f / (1.0f - drop_p);
+    const double th = (1.0 - (double)drop_p) * 4294967296.0;
+    a.keep_thresh = th >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)th;
+    a.seed = seed; a.offset = offset; a.rownorm = nullptr; a.emb_w = emb_w; a.emb_b = emb_b; a.E = E; a.B = B;
+    a.I = I; a.xin = xin; a.ldxin = ldxin; a.xt_out = xt_out; a.ldxt = ldxt; a.temb_out = temb_out;
+    hipStream_t s = (hipStream_t)stream;
+    if (normalize) {
+        // F.normalize (reference models/DNN.py:75-76) needs the L2 norm of the noised row first
+        GD_CHECK_ARG(rownorm_ws != nullptr, "prep_input: normalize needs rownorm_ws [B]");
+        hipLaunchKernelGGL(prep_rowss_kernel, dim3(B), dim3(256), 0, s, a, rownorm_ws);
+        a.rownorm = rownorm_ws;
+    }
+    dim3 grid(gd_cdiv((int)(ldxin / 4), 256), B);
+    {
+        // algorithmic bytes: read x (+ explicit noise / keep-mask), write xin
+        const double bytes = (double)B * I * (4.0 + (a.noise_mode == 1 ? 4.0 : 0.0) + (drop_mode == 1 ? 1.0 : 0.0)) +
+                             (double)B * ldxin * 4.0;
+        GdProfScope prof(7, bytes, s);
+        hipLaunchKernelGGL(prep_input_kernel, grid, dim3(256), 0, s, a);
+    }
+    return gd_launch_status("prep_input");
+}
+
+int gdmcf_dnn_emb_cols_f32(const int64_t* ts, const float* emb_w, const float* emb_b, int E, int B, int I, float* xin,
+                           int64_t ldxin, float* temb_out, void* stream) {
+    GD_CHECK_SHAPE(B > 0 && I > 0 && E > 0 && ldxin >= I + E, "emb_cols: bad shape");
+    hipLaunchKernelGGL(emb_cols_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, ts, emb_w, emb_b, E, I, xin, ldxin,
+                       temb_out);
+    return gd_launch_status("emb_cols");
+}
+
+int gdmcf_rowscale_f32(const float* A, int64_t lda, const float* rowscale, int M, int K, float* out, int64_t ldo,
+                       void* stream) {
+    GD_CHECK_SHAPE(M > 0 && K > 0 && lda >= K && ldo >= K, "rowscale: bad shape");
+    const int64_t n = (int64_t)M * K;
+    hipLaunchKernelGGL(rowscale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, A, lda,
+                       rowscale, M, K, out, ldo);
+    return gd_launch_status("rowscale");
+}
+
+int gdmcf_emb_bwd_f32(const float* dZ1, int64_t lddz, const float* W1, int64_t ldw, int I, int E, const float* temb,
+                      int M, int N, float* demb_ws, float* dWe, float* dbe, void* stream) {
+    GD_CHECK_SHAPE(M > 0 && N > 0 && E > 0 && ldw >= I + E && lddz >= N, "emb_bwd: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(emb_bwd_demb_kernel, dim3(M), dim3(256), 0, s, dZ1, lddz, W1, ldw, I, E, N, demb_ws);
+    hipLaunchKernelGGL(emb_bwd_w_kernel, dim3(gd_cdiv(E * E + E, 128)), dim3(128), 0, s, demb_ws, temb, M, E, dWe, dbe);
+    return gd_launch_status("emb_bwd");
+}
+
+int gdmcf_row_loss_finish_f64(const float* rowsum, const float* rowdiv, const float* alpha, const int64_t* ts,
+                              const double* weight_t, const double* pt, int B, int T, int H, double* Lt_history,
+                              int64_t* Lt_count, int update_history, double* loss_unscaled, double* loss,
+                              float* gradcoef, void* stream) {
+    GD_CHECK_SHAPE(B > 0 && T > 0 && H > 0, "row_loss_finish: bad shape");
+    hipLaunchKernelGGL(row_loss_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, rowsum, rowdiv, alpha,
+                       gradcoef, ts, weight_t, pt, B, H, Lt_history, Lt_count, update_history, loss_unscaled, loss);
+    return gd_launch_status("row_loss_finish");
+}
+
+int gdmcf_lt_history_update(const int64_t* ts, const double* loss_unscaled, int B, int T, int H, double* Lt_history,
+                            int64_t* Lt_count, void* stream) {
+    GD_CHECK_SHAPE(B > 0 && T > 0 && H > 0, "lt_history_update: bad shape");
+    hipLaunchKernelGGL(lt_history_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ts, loss_unscaled, B, H,
+                       Lt_history, Lt_count);
+    return gd_launch_status("lt_history_update");
+}
+
+int gdmcf_adamw_f32(const int64_t* table, int n_tensors, int total_blocks, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, int step, float grad_scale, void* stream) {
+    GD_CHECK_ARG(n_tensors > 0 && total_blocks > 0 && step >= 1, "adamw: bad arguments");
+    AdamHyper h;
+    // scalars formed in double exactly as torch/optim/adamw.py does, then narrowed to f32
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    h.decay = (float)(1.0 - (double)lr * (double)weight_decay);
+    h.one_m_b1 = (float)(1.0 - (double)beta1);
+    h.beta2 = beta2;
+    h.one_m_b2 = (float)(1.0 - (double)beta2);
+    h.bc2_sqrt = (float)sqrt(bc2);
+    h.eps = eps;
+    h.neg_step = (float)(-((double)lr / bc1));
+    h.grad_scale = grad_scale;
+    {
+        GdProfScope prof(6, 28.0 * ADAM_BLOCK_ELEMS * (double)total_blocks, (hipStream_t)stream);
+        hipLaunchKernelGGL(adamw_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, table, n_tensors, h);
+    }
+    return gd_launch_status("adamw");
+}
+
+int gdmcf_scale_f32(const float* acc, int64_t n, float scale, float* out, void* stream) {
+    GD_CHECK_SHAPE(n > 0, "scale: empty");
+    hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, acc, n,
+                       scale, out);
+    return gd_launch_status("scale");
+}
+
+}  // extern "C"
+
+// ---- internal helpers used by linear.hip ---------------------------------------------------------
+int gd_splitk_reduce(const float* slabs, int64_t slab_stride, int splits, int64_t ld_slab, int M, int N, int mode,
+                     const float* bias, const float* rowscale, const float* aact, int64_t ldact, int act, float* out,
+                     int64_t ldo, hipStream_t s) {
+    const int64_t n = (int64_t)M * N;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, slabs, slab_stride,
+                       splits, ld_slab, M, N, mode, bias, rowscale, aact, ldact, act, out, ldo);
+    return gd_launch_status("splitk_reduce");
+}
+
+int gd_colsum(const float* dZ, int64_t ld, const float* rs, int M, int N, float* db, hipStream_t s) {
+    hipLaunchKernelGGL(colsum_kernel, dim3(gd_cdiv(N, 256)), dim3(256), 0, s, dZ, ld, rs, M, N, db);
+    return gd_launch_status("colsum");
+}
+
+int gd_rowpart_reduce(const float* rowpart, int ld, int M, int nt, float* rowsum, hipStream_t s) {
+    hipLaunchKernelGGL(rowpart_reduce_kernel, dim3(gd_cdiv(M, 256)), dim3(256), 0, s, rowpart, ld, M, nt, rowsum);
+    return gd_launch_status("rowpart_reduce");
+}

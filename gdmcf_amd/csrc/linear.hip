@@ -1,0 +1,159 @@
+// C-ABI entry points for the denoiser's dense layers: forward (plain / fused row-loss / fused
+// posterior mean) and backward (input grad, weight grad).  All of them drive gemm_f32.hip.
+#include "common.h"
+
+int gd_splitk_reduce(const float* slabs, int64_t slab_stride, int splits, int64_t ld_slab, int M, int N, int mode,
+                     const float* bias, const float* rowscale, const float* aact, int64_t ldact, int act, float* out,
+                     int64_t ldo, hipStream_t s);
+int gd_colsum(const float* dZ, int64_t ld, const float* rs, int M, int N, float* db, hipStream_t s);
+int gd_rowpart_reduce(const float* rowpart, int ld, int M, int nt, float* rowsum, hipStream_t s);
+
+namespace {
+
+constexpr int TARGET_WGS = 512;  // 256 CUs x 2 resident workgroups
+
+// number of K splits for an [M,N,K] product whose output is small (batch x hidden)
+int pick_splits(int M, int N, int K, int cls, int bk) {
+    const int tiles = gd_cdiv(M, gd_gemm_tile_m(cls)) * gd_cdiv(N, gd_gemm_tile_n(cls));
+    int s = TARGET_WGS / tiles;
+    const int max_by_k = K / (8 * bk);  // keep >= 8 K-tiles per split
+    if (s > max_by_k) s = max_by_k;
+    if (s < 1) s = 1;
+    if (s > 64) s = 64;
+    return s;
+}
+
+inline int64_t round4(int64_t x) { return (x + 3) & ~(int64_t)3; }
+
+inline int vec_ok(const float* p, int64_t ld) { return gd_aligned16(p) && (ld % 4) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+size_t gdmcf_linear_ws_bytes(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    // forward: slabs [splits][M][round4(N)];  backward-input: slabs [splits][M][round4(K)]
+    const int cf = gd_pick_shape_class(M, N), cb = gd_pick_shape_class(M, K);
+    const size_t f = (size_t)pick_splits(M, N, K, cf, 32) * M * round4(N);
+    const size_t b = (size_t)pick_splits(M, K, N, cb, 32) * M * round4(K);
+    return (f > b ? f : b) * sizeof(float) + 256;
+}
+
+int gdmcf_loss_tiles(int N) { return gd_cdiv(N, 64); }
+
+int gdmcf_linear_fwd_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, int act, int M,
+                         int N, int K, float* C, int64_t ldc, void* ws, size_t ws_bytes, void* stream) {
+    GD_CHECK_SHAPE(M > 0 && N > 0 && K > 0 && lda >= K && ldw >= K && ldc >= N, "linear_fwd: bad shape");
+    GD_CHECK_ARG(act == 0 || act == 1, "linear_fwd: bad activation");
+    hipStream_t s = (hipStream_t)stream;
+    const int cls = gd_pick_shape_class(M, N);
+    const int splits = pick_splits(M, N, K, cls, 32);
+    GdGemm g = {};
+    g.A = A; g.lda = lda; g.B = W; g.ldb = ldw; g.M = M; g.N = N; g.K = K;
+    g.veca = vec_ok(A, lda); g.vecb = vec_ok(W, ldw);
+    g.m_fastest = gd_cdiv(M, gd_gemm_tile_m(cls)) <= gd_cdiv(N, gd_gemm_tile_n(cls));
+    g.bias = bias; g.act = act; g.prof_tag = 1;
+    if (splits == 1) {
+        g.splits = 1; g.C = C; g.ldc = ldc;
+        return gd_gemm_launch(GD_LAY_KC, GD_LAY_KC, GD_EPI_BIAS_ACT, cls, g, s);
+    }
+    const int64_t lds_ = round4(N);
+    const size_t need = (size_t)splits * M * lds_ * sizeof(float);
+    if (ws == nullptr || ws_bytes < need) {
+        gdmcf_set_error("linear_fwd: workspace %zu < %zu bytes", ws_bytes, need);
+        return GDMCF_E_WORKSPACE;
+    }
+    g.splits = splits; g.C = (float*)ws; g.ldc = lds_; g.slab_stride = (int64_t)M * lds_;
+    int rc = gd_gemm_launch(GD_LAY_KC, GD_LAY_KC, GD_EPI_SLAB, cls, g, s);
+    if (rc) return rc;
+    const int real_splits = gd_cdiv(K, g.kchunk);
+    return gd_splitk_reduce((const float*)ws, g.slab_stride, real_splits, lds_, M, N, 0, bias, nullptr, nullptr, 0,
+                            act, C, ldc, s);
+}
+
+int gdmcf_linear_loss_fwd_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
+                              const float* target, int64_t ldt, const float* alpha, int M, int N, int K, float* out,
+                              int64_t ldo, float* diff, int64_t ldd, float* rowpart, float* rowsum, void* stream) {
+    GD_CHECK_SHAPE(M > 0 && N > 0 && K > 0 && lda >= K && ldw >= K && ldt >= N && ldd >= N, "linear_loss_fwd: bad shape");
+    GD_CHECK_SHAPE(out == nullptr || ldo >= N, "linear_loss_fwd: ldo < N");
+    hipStream_t s = (hipStream_t)stream;
+    const int cls = gd_pick_shape_class(M, N);
+    GdGemm g = {};
+    g.A = A; g.lda = lda; g.B = W; g.ldb = ldw; g.M = M; g.N = N; g.K = K; g.splits = 1;
+    g.veca = vec_ok(A, lda); g.vecb = vec_ok(W, ldw);
+    g.m_fastest = gd_cdiv(M, gd_gemm_tile_m(cls)) <= gd_cdiv(N, gd_gemm_tile_n(cls));
+    g.bias = bias; g.aux = target; g.ldaux = ldt; g.r0 = alpha; g.out2 = out; g.ldout2 = ldo;
+    g.prof_tag = 2;
+    g.C = diff; g.ldc = ldd; g.rowpart = rowpart; g.ld_rowpart = gdmcf_loss_tiles(N);
+    int rc = gd_gemm_launch(GD_LAY_KC, GD_LAY_KC, GD_EPI_LOSS, cls, g, s);
+    if (rc) return rc;
+    return gd_rowpart_reduce(rowpart, g.ld_rowpart, M, g.tiles_n, rowsum, s);
+}
+
+int gdmcf_linear_posterior_fwd_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
+                                   const float* x_t, int64_t ldxt, const float* c1, const float* c2, const float* r1,
+                                   const float* r2, const float* sigma, const float* z, int64_t ldz, int M, int N,
+                                   int K, float* x_next, int64_t ldxn, float* pred_out, int64_t ldp, void* stream) {
+    GD_CHECK_SHAPE(M > 0 && N > 0 && K > 0 && lda >= K && ldw >= K && ldxt >= N && ldxn >= N, "linear_posterior_fwd: bad shape");
+    GD_CHECK_ARG(c1 && c2, "linear_posterior_fwd: c1/c2 missing");
+    GD_CHECK_ARG((r1 == nullptr) == (r2 == nullptr), "linear_posterior_fwd: r1/r2 must both be set or both NULL");
+    GD_CHECK_ARG(z == nullptr || (sigma != nullptr && ldz >= N), "linear_posterior_fwd: sigma missing");
+    hipStream_t s = (hipStream_t)stream;
+    const int cls = gd_pick_shape_class(M, N);
+    GdGemm g = {};
+    g.A = A; g.lda = lda; g.B = W; g.ldb = ldw; g.M = M; g.N = N; g.K = K; g.splits = 1;
+    g.veca = vec_ok(A, lda); g.vecb = vec_ok(W, ldw);
+    g.m_fastest = gd_cdiv(M, gd_gemm_tile_m(cls)) <= gd_cdiv(N, gd_gemm_tile_n(cls));
+    g.bias = bias; g.aux = x_t; g.ldaux = ldxt; g.aux2 = z; g.ldaux2 = ldz;
+    g.r0 = c1; g.r1 = c2; g.r2 = r1; g.r3 = r2; g.r4 = sigma;
+    g.out2 = pred_out; g.ldout2 = ldp; g.C = x_next; g.ldc = ldxn; g.prof_tag = 3;
+    return gd_gemm_launch(GD_LAY_KC, GD_LAY_KC, GD_EPI_POST, cls, g, s);
+}
+
+int gdmcf_linear_bwd_input_f32(const float* dZ, int64_t lddz, const float* W, int64_t ldw, const float* rowscale,
+                               const float* Aact, int64_t ldact, int act, int M, int N, int K, float* dA,
+                               int64_t ldda, void* ws, size_t ws_bytes, void* stream) {
+    GD_CHECK_SHAPE(M > 0 && N > 0 && K > 0 && lddz >= N && ldw >= K && ldda >= K, "linear_bwd_input: bad shape");
+    GD_CHECK_ARG(act == 0 || (act == 1 && Aact && ldact >= K), "linear_bwd_input: activation output missing");
+    hipStream_t s = (hipStream_t)stream;
+    // product dims: [M x K_in] = dZ[M x N] * W[N x K_in]  -> gemm (M, K, reduction N)
+    const int cls = gd_pick_shape_class(M, K);
+    const int splits = pick_splits(M, K, N, cls, 32);
+    const int64_t lds_ = round4(K);
+    const size_t need = (size_t)splits * M * lds_ * sizeof(float);
+    if (ws == nullptr || ws_bytes < need) {
+        gdmcf_set_error("linear_bwd_input: workspace %zu < %zu bytes", ws_bytes, need);
+        return GDMCF_E_WORKSPACE;
+    }
+    GdGemm g = {};
+    g.A = dZ; g.lda = lddz; g.B = W; g.ldb = ldw; g.M = M; g.N = K; g.K = N;
+    g.veca = vec_ok(dZ, lddz); g.vecb = vec_ok(W, ldw);
+    g.m_fastest = gd_cdiv(M, gd_gemm_tile_m(cls)) <= gd_cdiv(K, gd_gemm_tile_n(cls));
+    g.splits = splits; g.C = (float*)ws; g.ldc = lds_; g.slab_stride = (int64_t)M * lds_; g.prof_tag = 4;
+    int rc = gd_gemm_launch(GD_LAY_KC, GD_LAY_MC, GD_EPI_SLAB, cls, g, s);
+    if (rc) return rc;
+    const int real_splits = gd_cdiv(N, g.kchunk);
+    return gd_splitk_reduce((const float*)ws, g.slab_stride, real_splits, lds_, M, K, 1, nullptr, rowscale, Aact,
+                            ldact, act, dA, ldda, s);
+}
+
+int gdmcf_linear_bwd_weight_f32(const float* dZ, int64_t lddz, const float* A, int64_t lda, const float* rowscale,
+                                int M, int N, int K, float* dW, int64_t lddw, float* db, int accumulate,
+                                void* stream) {
+    GD_CHECK_SHAPE(M > 0 && N > 0 && K > 0 && lddz >= N && lda >= K && lddw >= K, "linear_bwd_weight: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    // dW[N x K_in] = dZ[M x N]^T * A[M x K_in]  -> gemm (N, K, reduction M), both operands row-contiguous
+    const int cls = gd_pick_shape_class(N, K);
+    GdGemm g = {};
+    g.A = dZ; g.lda = lddz; g.B = A; g.ldb = lda; g.M = N; g.N = K; g.K = M; g.splits = 1;
+    g.veca = vec_ok(dZ, lddz); g.vecb = vec_ok(A, lda);
+    g.m_fastest = gd_cdiv(N, gd_gemm_tile_m(cls)) <= gd_cdiv(K, gd_gemm_tile_n(cls));
+    g.C = dW; g.ldc = lddw; g.accumulate = accumulate; g.prof_tag = 5;
+    int rc = gd_gemm_launch(GD_LAY_MC, GD_LAY_MC, GD_EPI_STORE, cls, g, s);
+    if (rc) return rc;
+    if (db) return gd_colsum(dZ, lddz, rowscale, M, N, db, s);
+    return GDMCF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,284 @@
+// Evaluation-side kernels: masked per-row top-k (reference main.py:296-301) and the LightGCN CSR
+// SpMM (reference lightGCN.py:184-189).  Both are HBM / cache-bandwidth bound.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// masked top-k: one 256-thread workgroup per row.
+//   1. history mask -> bitmap in LDS (I bits)
+//   2. 4-pass 8-bit radix select on order-preserving uint32 keys -> k-th largest key
+//   3. collect keys > threshold (any order) + the lowest-index ties == threshold
+//   4. bitonic sort of (key, ~index) pairs -> descending score, ascending index on ties
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t order_key(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_to_float(uint32_t k) {
+    const uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+
+constexpr uint32_t NEG_INF_KEY = 0x007FFFFFu;  // order_key(-inf)
+
+__device__ __forceinline__ uint32_t masked_key(const float* __restrict__ row, const uint32_t* bitmap, int i) {
+    if (bitmap[i >> 5] & (1u << (i & 31))) return NEG_INF_KEY;
+    return order_key(row[i]);
+}
+
+__global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ pred, int64_t ldp, int I,
+                                                   const int64_t* __restrict__ indptr,
+                                                   const int32_t* __restrict__ indices, int k, int KP,
+                                                   int64_t* __restrict__ idx_out, float* __restrict__ val_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned long long* cand = reinterpret_cast<unsigned long long*>(smem_raw);  // [KP]
+    uint32_t* hist = reinterpret_cast<uint32_t*>(cand + KP);                     // [256]
+    uint32_t* ctl = hist + 256;                                                  // [8]
+    uint32_t* bitmap = ctl + 8;                                                  // [ceil(I/32)]
+    const int tid = threadIdx.x;
+    const int row_id = blockIdx.x;
+    const float* row = pred + (int64_t)row_id * ldp;
+    const int nwords = (I + 31) >> 5;
+
+    for (int w = tid; w < nwords; w += 256) bitmap[w] = 0u;
+    for (int j = tid; j < KP; j += 256) cand[j] = 0ull;
+    __syncthreads();
+    if (indptr) {
+        const int64_t beg = indptr[row_id], end = indptr[row_id + 1];
+        for (int64_t j = beg + tid; j < end; j += 256) {
+            const int c = indices[j];
+            if (c >= 0 && c < I) atomicOr(&bitmap[c >> 5], 1u << (c & 31));
+        }
+    }
+    __syncthreads();
+
+    // radix select
+    uint32_t prefix = 0, pmask = 0;
+    int need = k;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        hist[tid] = 0u;
+        __syncthreads();
+        for (int i = tid; i < I; i += 256) {
+            const uint32_t key = masked_key(row, bitmap, i);
+            if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t cum = 0;
+            int b = 255;
+            for (; b > 0; --b) {
+                if (cum + hist[b] >= (uint32_t)need) break;
+                cum += hist[b];
+            }
+            ctl[0] = (uint32_t)b;
+            ctl[1] = cum;      // elements strictly above bin b (within the prefix)
+            ctl[2] = hist[b];  // elements in bin b
+        }
+        __syncthreads();
+        prefix |= ctl[0] << shift;
+        pmask |= 255u << shift;
+        need -= (int)ctl[1];
+        __syncthreads();
+    }
+    const uint32_t thr = prefix;       // k-th largest key
+    const int n_eq_total = (int)ctl[2];  // elements equal to thr
+    const int n_gt = k - need;         // elements strictly greater
+    // need = number of ties to take (>= 1)
+
+    if (tid == 0) ctl[3] = 0u;
+    __syncthreads();
+    if (n_eq_total == need) {
+        // no surplus ties: order of collection is irrelevant
+        for (int i = tid; i < I; i += 256) {
+            const uint32_t key = masked_key(row, bitmap, i);
+            if (key >= thr) {
+                const uint32_t slot = atomicAdd(&ctl[3], 1u);
+                cand[slot] = ((unsigned long long)key << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)i);
+            }
+        }
+    } else {
+        for (int i = tid; i < I; i += 256) {
+            const uint32_t key = masked_key(row, bitmap, i);
+            if (key > thr) {
+                const uint32_t slot = atomicAdd(&ctl[3], 1u);
+                cand[slot] = ((unsigned long long)key << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)i);
+            }
+        }
+        // ties in index order: chunked ordered scan, stop once `need` were taken
+        int taken = 0;
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int base = 0; base < I && taken < need; base += 256) {
+            const int i = base + tid;
+            const bool f = (i < I) && (masked_key(row, bitmap, i) == thr);
+            const unsigned long long bal = __ballot(f);
+            if (lane == 0) ctl[4 + wave] = (uint32_t)__popcll(bal);
+            __syncthreads();
+            int before = 0;
+            for (int w = 0; w < wave; ++w) before += (int)ctl[4 + w];
+            const int total = (int)(ctl[4] + ctl[5] + ctl[6] + ctl[7]);
+            const int rank = taken + before + (int)__popcll(bal & ((1ull << lane) - 1ull));
+            if (f && rank < need)
+                cand[n_gt + rank] = ((unsigned long long)thr << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)i);
+            taken += total;
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+
+    // bitonic sort, descending
+    for (int size = 2; size <= KP; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int j = tid; j < KP / 2; j += 256) {
+                const int lo = ((j / stride) * stride * 2) + (j % stride);
+                const int hi = lo + stride;
+                const bool desc = ((lo & size) == 0);
+                const unsigned long long a = cand[lo], b = cand[hi];
+                if ((a < b) == desc) {
+                    cand[lo] = b;
+                    cand[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int j = tid; j < k; j += 256) {
+        const unsigned long long c = cand[j];
+        idx_out[(int64_t)row_id * k + j] = (int64_t)(0xFFFFFFFFu - (uint32_t)(c & 0xFFFFFFFFull));
+        if (val_out) val_out[(int64_t)row_id * k + j] = key_to_float((uint32_t)(c >> 32));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// CSR SpMM, one wave per row.  LPR lanes cover one embedding row with 16-byte loads, so a wave
+// gathers 64/LPR neighbours per instruction (d = 64 -> 4 x 256 B rows = 1 KiB per wave-instruction).
+// The running layer sum (LightGCN layer mean) is fused as `acc += Y`.
+// ---------------------------------------------------------------------------------------------
+template <int LPR>
+__global__ __launch_bounds__(256) void spmm_vec_kernel(const int64_t* __restrict__ rowptr,
+                                                       const int32_t* __restrict__ col,
+                                                       const float* __restrict__ val, int n_rows,
+                                                       const float* __restrict__ X, int64_t ldx,
+                                                       float* __restrict__ Y, int64_t ldy, float* __restrict__ acc,
+                                                       int64_t ldacc) {
+    constexpr int NPAR = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rows) return;
+    const int sub = lane / LPR, cl = lane % LPR;
+    const int64_t beg = rowptr[r], end = rowptr[r + 1];
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+    int64_t j = beg + sub;
+    for (; j + NPAR < end; j += 2 * NPAR) {
+        const int c0 = col[j], c1 = col[j + NPAR];
+        const float w0 = val[j], w1 = val[j + NPAR];
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(X + (int64_t)c0 * ldx + cl * 4);
+        const f32x4 x1 = *reinterpret_cast<const f32x4*>(X + (int64_t)c1 * ldx + cl * 4);
+        s0 += w0 * x0;
+        s1 += w1 * x1;
+    }
+    if (j < end) {
+        const int c0 = col[j];
+        const float w0 = val[j];
+        s0 += w0 * *reinterpret_cast<const f32x4*>(X + (int64_t)c0 * ldx + cl * 4);
+    }
+    f32x4 s = s0 + s1;
+#pragma unroll
+    for (int o = LPR; o < 64; o <<= 1) {
+        s.x += __shfl_xor(s.x, o);
+        s.y += __shfl_xor(s.y, o);
+        s.z += __shfl_xor(s.z, o);
+        s.w += __shfl_xor(s.w, o);
+    }
+    if (sub == 0) {
+        *reinterpret_cast<f32x4*>(Y + (int64_t)r * ldy + cl * 4) = s;
+        if (acc) {
+            f32x4* a = reinterpret_cast<f32x4*>(acc + (int64_t)r * ldacc + cl * 4);
+            *a = *a + s;
+        }
+    }
+}
+
+// generic fallback: any d, one neighbour at a time, lane strides over columns
+__global__ __launch_bounds__(256) void spmm_generic_kernel(const int64_t* __restrict__ rowptr,
+                                                           const int32_t* __restrict__ col,
+                                                           const float* __restrict__ val, int n_rows,
+                                                           const float* __restrict__ X, int64_t ldx, int d,
+                                                           float* __restrict__ Y, int64_t ldy,
+                                                           float* __restrict__ acc, int64_t ldacc) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rows) return;
+    const int64_t beg = rowptr[r], end = rowptr[r + 1];
+    for (int c0 = lane; c0 < d; c0 += 64) {
+        float s = 0.f;
+        for (int64_t j = beg; j < end; ++j) s += val[j] * X[(int64_t)col[j] * ldx + c0];
+        Y[(int64_t)r * ldy + c0] = s;
+        if (acc) acc[(int64_t)r * ldacc + c0] += s;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int gdmcf_topk_masked_f32(const float* pred, int64_t ldp, int B, int I, const int64_t* mask_indptr,
+                          const int32_t* mask_indices, int k, int64_t* idx_out, float* val_out, void* stream) {
+    GD_CHECK_SHAPE(B > 0 && I > 0 && ldp >= I, "topk: bad shape");
+    GD_CHECK_SHAPE(k >= 1 && k <= I, "topk: k out of range (selected index k out of range)");
+    GD_CHECK_ARG(k <= 2048, "topk: k > 2048 unsupported");
+    GD_CHECK_ARG((mask_indptr == nullptr) == (mask_indices == nullptr), "topk: mask indptr/indices mismatch");
+    int KP = 2;
+    while (KP < k) KP <<= 1;
+    const size_t lds = (size_t)KP * 8 + (256 + 8) * 4 + (size_t)((I + 31) / 32) * 4;
+    if (lds > 160 * 1024) {
+        gdmcf_set_error("topk: row width %d needs %zu B of LDS (> 160 KiB)", I, lds);
+        return GDMCF_E_UNSUPPORTED;
+    }
+    static size_t attr_lds = 0;
+    if (lds > 48 * 1024 && lds > attr_lds) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(topk_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) {
+            gdmcf_set_error("topk: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return GDMCF_E_HIP;
+        }
+        attr_lds = 160 * 1024;
+    }
+    GdProfScope prof(9, 4.0 * B * (double)I, (hipStream_t)stream);
+    hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, pred, ldp, I, mask_indptr,
+                       mask_indices, k, KP, idx_out, val_out);
+    return gd_launch_status("topk");
+}
+
+int gdmcf_spmm_csr_f32(const int64_t* rowptr, const int32_t* col, const float* val, int n_rows, const float* X,
+                       int64_t ldx, int d, float* Y, int64_t ldy, float* acc, int64_t ldacc, void* stream) {
+    GD_CHECK_SHAPE(n_rows > 0 && d > 0 && ldx >= d && ldy >= d, "spmm: bad shape");
+    GD_CHECK_SHAPE(acc == nullptr || ldacc >= d, "spmm: ldacc < d");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(gd_cdiv(n_rows, 4)), block(256);
+    const bool vec = (d % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && gd_aligned16(X) && gd_aligned16(Y) &&
+                     (acc == nullptr || ((ldacc % 4 == 0) && gd_aligned16(acc)));
+    const int lpr = d / 4;
+    // work is filled in by the caller-side nnz (not known here without a sync): report rows*d*8 + pointer bytes;
+    // bench.py adds the nnz*(4+4) term itself.
+    GdProfScope prof(8, (double)n_rows * d * 8.0 + (double)(n_rows + 1) * 8.0, s);
+    if (vec && lpr == 16)
+        hipLaunchKernelGGL(spmm_vec_kernel<16>, grid, block, 0, s, rowptr, col, val, n_rows, X, ldx, Y, ldy, acc, ldacc);
+    else if (vec && lpr == 8)
+        hipLaunchKernelGGL(spmm_vec_kernel<8>, grid, block, 0, s, rowptr, col, val, n_rows, X, ldx, Y, ldy, acc, ldacc);
+    else if (vec && lpr == 32)
+        hipLaunchKernelGGL(spmm_vec_kernel<32>, grid, block, 0, s, rowptr, col, val, n_rows, X, ldx, Y, ldy, acc, ldacc);
+    else if (vec && lpr == 64)
+        hipLaunchKernelGGL(spmm_vec_kernel<64>, grid, block, 0, s, rowptr, col, val, n_rows, X, ldx, Y, ldy, acc, ldacc);
+    else if (vec && lpr == 4)
+        hipLaunchKernelGGL(spmm_vec_kernel<4>, grid, block, 0, s, rowptr, col, val, n_rows, X, ldx, Y, ldy, acc, ldacc);
+    else if (vec && lpr == 2)
+        hipLaunchKernelGGL(spmm_vec_kernel<2>, grid, block, 0, s, rowptr, col, val, n_rows, X, ldx, Y, ldy, acc, ldacc);
+    else
+        hipLaunchKernelGGL(spmm_generic_kernel, grid, block, 0, s, rowptr, col, val, n_rows, X, ldx, d, Y, ldy, acc,
+                           ldacc);
+    return gd_launch_status("spmm_csr");
+}
+
+}  // extern "C"

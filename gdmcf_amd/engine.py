@@ -1,0 +1,326 @@
+"""Drives the C ABI (include/gdmcf_hip.h) for one DNN denoiser: owns the HBM workspaces and the
+order of kernel launches for
+  * the fused training forward  (q_sample -> dropout -> layers -> row loss -> f64 tail)
+  * its backward                (weight / bias / embedding gradients)
+  * the plain forward/backward  (model(x, t))
+  * the reverse-diffusion loop  (p_sample).
+PyTorch is used for device memory and streams only; every arithmetic step is a HIP kernel.
+
+HBM layout (all float32 row-major, leading dims padded to 64 elements = 256 B):
+  xin   [B, ldk]  first-layer input  [ drop(x_t) | emb(t) | 0-pad ],  ldk = ceil64(I + E)
+  act_l [B, ld_l] tanh outputs of every layer but the last
+  diff  [B, ldi]  alpha*out - target (the last layer's output is never stored in training)
+  slabs           split-K partial sums (forward of layer 0, input-gradient of the last layer)
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def _ceil64(n):
+    return (n + 63) // 64 * 64
+
+
+class _Bufs:
+    pass
+
+
+class DenoiserEngine:
+    def __init__(self, model):
+        self.model = model
+        self.lib = _lib.load()
+        self.E = int(model.time_emb_dim)
+        self.I = int(model.in_dims[0])
+        self.version = 0
+        self.seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+        self.offset = 0
+        self._bufs = {}
+        self._saved = None
+
+    def manual_seed(self, seed):
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.offset = 0
+
+    # ------------------------------------------------------------------------------------------
+    def _layers(self):
+        layers = self.model.layer_list()
+        for w, b, _ in layers:
+            _lib.require_gpu(w, "DNN parameters")
+            if not (w.is_contiguous() and b.is_contiguous() and w.dtype == torch.float32):
+                raise RuntimeError("gdmcf_amd: DNN parameters must be contiguous float32")
+        return layers
+
+    def buffers(self, B, device):
+        key = (B, str(device))
+        b = self._bufs.get(key)
+        if b is not None:
+            return b
+        lib, I, E = self.lib, self.I, self.E
+        layers = self.model.layer_list()
+        f32 = dict(dtype=torch.float32, device=device)
+        b = _Bufs()
+        b.ldk = _ceil64(I + E)
+        b.xin = torch.zeros(B, b.ldk, **f32)
+        b.xin2 = None
+        b.temb = torch.zeros(B, max(E, 1), **f32)
+        b.rownorm = torch.zeros(B, **f32)
+        b.acts = [torch.zeros(B, _ceil64(w.shape[0]), **f32) for (w, _, _) in layers[:-1]]
+        b.dzs = [torch.zeros(B, _ceil64(w.shape[0]), **f32) for (w, _, _) in layers[:-1]]
+        b.hs = torch.zeros(B, _ceil64(layers[-1][0].shape[1]), **f32)
+        b.ldi = _ceil64(I)
+        b.diff = torch.zeros(B, b.ldi, **f32)
+        b.xt = None
+        b.rowpart = torch.zeros(B, lib.gdmcf_loss_tiles(layers[-1][0].shape[0]), **f32)
+        b.rowsum = torch.zeros(B, **f32)
+        b.gradcoef = torch.zeros(B, **f32)
+        b.rowdiv_mse = torch.full((B,), float(I), **f32)
+        b.lu = torch.zeros(B, dtype=torch.float64, device=device)
+        b.demb = torch.zeros(B, max(E, 1), **f32)
+        ws = 0
+        for (w, _, _) in layers:
+            ws = max(ws, lib.gdmcf_linear_ws_bytes(B, w.shape[0], w.shape[1]))
+        b.ws_bytes = int(ws)
+        b.ws = torch.empty(max(ws, 256), dtype=torch.uint8, device=device)
+        self._bufs[key] = b
+        return b
+
+    # ------------------------------------------------------------------------------------------
+    def _prep(self, bufs, x, ts, ca, cb, noise, drop_mask, training, xt_out=None, xin=None):
+        m, lib = self.model, self.lib
+        B = x.shape[0]
+        if x.dtype != torch.float32 or x.stride(-1) != 1:
+            x = x.float().contiguous()
+        xin = bufs.xin if xin is None else xin
+        noise_mode = 0
+        if ca is not None:
+            noise_mode = 1 if noise is not None else 2
+            if noise is not None and (noise.dtype != torch.float32 or noise.stride(-1) != 1):
+                noise = noise.float().contiguous()
+        p = float(m.drop.p)
+        drop_mode = 0
+        keep = None
+        if drop_mask is not None:
+            drop_mode = 1
+            keep = drop_mask if drop_mask.dtype == torch.uint8 else (drop_mask != 0).to(torch.uint8)
+            keep = keep.contiguous()
+        elif training and p > 0.0:
+            drop_mode = 2
+        self.offset += 1
+        rc = lib.gdmcf_dnn_prep_input_f32(
+            x.data_ptr(), x.stride(0), _lib.ptr(ts), _lib.ptr(ca), _lib.ptr(cb), noise_mode, _lib.ptr(noise),
+            noise.stride(0) if noise is not None else 0, drop_mode, _lib.ptr(keep),
+            keep.stride(0) if keep is not None else 0, p, self.seed, self.offset, int(bool(m.norm)),
+            m.emb_layer.weight.data_ptr(), m.emb_layer.bias.data_ptr(), self.E, B, self.I, xin.data_ptr(),
+            xin.stride(0), _lib.ptr(xt_out), xt_out.stride(0) if xt_out is not None else 0, bufs.temb.data_ptr(),
+            bufs.rownorm.data_ptr(), _lib.stream_ptr())
+        _lib.check(rc)
+        return x, noise, keep  # keep the (possibly converted) inputs alive until the stream has consumed them
+
+    def _hidden_forward(self, bufs, layers, B, xin=None):
+        """All layers but the last; returns (A, lda, K) feeding the last layer."""
+        lib, st = self.lib, _lib.stream_ptr()
+        A, lda = (bufs.xin if xin is None else xin), bufs.ldk
+        for li, (w, bias, act) in enumerate(layers[:-1]):
+            N, K = w.shape
+            out = bufs.acts[li]
+            _lib.check(lib.gdmcf_linear_fwd_f32(A.data_ptr(), lda, w.data_ptr(), w.stride(0), bias.data_ptr(), act, B,
+                                                N, K, out.data_ptr(), out.stride(0), bufs.ws.data_ptr(),
+                                                bufs.ws_bytes, st))
+            A, lda = out, out.stride(0)
+        return A, lda
+
+    # ------------------------------------------------------------------------------------------
+    # fused training forward / backward
+    # ------------------------------------------------------------------------------------------
+    def train_forward(self, spec):
+        x0, ts = spec["x_start"], spec["ts"]
+        B, dev = x0.shape[0], x0.device
+        layers = self._layers()
+        bufs = self.buffers(B, dev)
+        lib, st = self.lib, _lib.stream_ptr()
+        self.version += 1
+        eps_mode = spec["eps_mode"]
+        xt_out = None
+        if eps_mode:
+            if bufs.xt is None:
+                bufs.xt = torch.zeros(B, bufs.ldi, dtype=torch.float32, device=dev)
+            xt_out = bufs.xt
+        keepalive = self._prep(bufs, x0, ts, spec["ca"], spec["cb"], spec["noise"], spec["drop_mask"],
+                               self.model.training, xt_out=xt_out)
+        x0c = keepalive[0]
+        alpha = None
+        if eps_mode:
+            # target = eps, except rows with t == 0 whose term is the x0-likelihood
+            # mean((x0 - (r1*x_t - r2*eps_hat))^2 / 2)  (reference gaussian_diffusion.py:344-348)
+            is0 = (ts == 0)
+            noise = keepalive[1]
+            target = torch.where(is0[:, None], spec["r1_0"] * bufs.xt[:, : self.I] - x0c, noise)
+            alpha = torch.where(is0, spec["r2_0"], torch.ones((), dtype=torch.float32, device=dev)).float().contiguous()
+            rowdiv = torch.where(is0, 2.0 * self.I, 1.0 * self.I).float().contiguous()
+        else:
+            target = x0c
+            rowdiv = bufs.rowdiv_mse
+        A, lda = self._hidden_forward(bufs, layers, B)
+        w, bias, _ = layers[-1]
+        N, K = w.shape
+        _lib.check(lib.gdmcf_linear_loss_fwd_f32(A.data_ptr(), lda, w.data_ptr(), w.stride(0), bias.data_ptr(),
+                                                 target.data_ptr(), target.stride(0), _lib.ptr(alpha), B, N, K, None,
+                                                 0, bufs.diff.data_ptr(), bufs.ldi, bufs.rowpart.data_ptr(),
+                                                 bufs.rowsum.data_ptr(), st))
+        loss = torch.empty(B, dtype=torch.float64, device=dev)
+        pt = spec["pt"]
+        _lib.check(lib.gdmcf_row_loss_finish_f64(bufs.rowsum.data_ptr(), rowdiv.data_ptr(), _lib.ptr(alpha),
+                                                 ts.data_ptr(), spec["weight_t"].data_ptr(), pt.data_ptr(), B,
+                                                 spec["T"], spec["H"], spec["Lt_history"].data_ptr(),
+                                                 spec["Lt_count"].data_ptr(), int(spec["update_history"]),
+                                                 bufs.lu.data_ptr(), loss.data_ptr(), bufs.gradcoef.data_ptr(), st))
+        self._saved = dict(kind="train", B=B, bufs=bufs, layers=layers, keepalive=(keepalive, target, alpha, rowdiv, pt))
+        return loss
+
+    def train_backward(self, gloss):
+        sv = self._saved
+        bufs = sv["bufs"]
+        rowscale = (gloss.to(torch.float32) * bufs.gradcoef).contiguous()
+        return self._backward(sv, bufs.diff, bufs.ldi, rowscale)
+
+    # ------------------------------------------------------------------------------------------
+    # plain forward / backward (model(x, t))
+    # ------------------------------------------------------------------------------------------
+    def forward_plain(self, x, timesteps, training, drop_mask=None):
+        B, dev = x.shape[0], x.device
+        layers = self._layers()
+        bufs = self.buffers(B, dev)
+        lib, st = self.lib, _lib.stream_ptr()
+        self.version += 1
+        ts = timesteps.to(device=dev, dtype=torch.int64).contiguous()
+        keepalive = self._prep(bufs, x, ts, None, None, None, drop_mask, training)
+        A, lda = self._hidden_forward(bufs, layers, B)
+        w, bias, act = layers[-1]
+        N, K = w.shape
+        out = torch.empty(B, N, dtype=torch.float32, device=dev)
+        _lib.check(lib.gdmcf_linear_fwd_f32(A.data_ptr(), lda, w.data_ptr(), w.stride(0), bias.data_ptr(), act, B, N,
+                                            K, out.data_ptr(), out.stride(0), bufs.ws.data_ptr(), bufs.ws_bytes, st))
+        self._saved = dict(kind="plain", B=B, bufs=bufs, layers=layers, keepalive=(keepalive, ts))
+        return out
+
+    def backward_plain(self, gout):
+        sv = self._saved
+        g = gout.to(torch.float32)
+        if g.stride(-1) != 1:
+            g = g.contiguous()
+        return self._backward(sv, g, g.stride(0), None)
+
+    # ------------------------------------------------------------------------------------------
+    def _backward(self, sv, dz_last, ld_last, rowscale):
+        """Gradients in model.parameters() order: emb_layer (w, b), in_layers..., out_layers...
+        dz_last is d(loss)/d(last layer output) up to the per-row factor `rowscale`."""
+        lib, st = self.lib, _lib.stream_ptr()
+        bufs, layers, B = sv["bufs"], sv["layers"], sv["B"]
+        dev = dz_last.device
+        L = len(layers)
+        grads_w = [None] * L
+        grads_b = [None] * L
+        dz, lddz, rs = dz_last, ld_last, rowscale
+        for li in range(L - 1, -1, -1):
+            w, bias, _ = layers[li]
+            N, K = w.shape
+            if li > 0:
+                A_prev, lda_prev = bufs.acts[li - 1], bufs.acts[li - 1].stride(0)
+            else:
+                A_prev, lda_prev = bufs.xin, bufs.ldk
+            dW = torch.empty_like(w)
+            db = torch.empty_like(bias)
+            A_use, lda_use = A_prev, lda_prev
+            if rs is not None:
+                # (rs . dZ)^T A == dZ^T (rs . A): scale the small activation instead of the big dZ
+                _lib.check(lib.gdmcf_rowscale_f32(A_prev.data_ptr(), lda_prev, rs.data_ptr(), B, K, bufs.hs.data_ptr(),
+                                                  bufs.hs.stride(0), st))
+                A_use, lda_use = bufs.hs, bufs.hs.stride(0)
+            _lib.check(lib.gdmcf_linear_bwd_weight_f32(dz.data_ptr(), lddz, A_use.data_ptr(), lda_use, _lib.ptr(rs), B,
+                                                       N, K, dW.data_ptr(), dW.stride(0), db.data_ptr(), 0, st))
+            grads_w[li], grads_b[li] = dW, db
+            if li > 0:
+                dprev = bufs.dzs[li - 1]
+                act_prev = layers[li - 1][2]
+                _lib.check(lib.gdmcf_linear_bwd_input_f32(dz.data_ptr(), lddz, w.data_ptr(), w.stride(0), _lib.ptr(rs),
+                                                          A_prev.data_ptr(), lda_prev, act_prev, B, N, K,
+                                                          dprev.data_ptr(), dprev.stride(0), bufs.ws.data_ptr(),
+                                                          bufs.ws_bytes, st))
+                dz, lddz, rs = dprev, dprev.stride(0), None
+        m = self.model
+        dWe = torch.empty_like(m.emb_layer.weight)
+        dbe = torch.empty_like(m.emb_layer.bias)
+        w0 = layers[0][0]
+        _lib.check(lib.gdmcf_emb_bwd_f32(dz.data_ptr(), lddz, w0.data_ptr(), w0.stride(0), self.I, self.E,
+                                         bufs.temb.data_ptr(), B, w0.shape[0], bufs.demb.data_ptr(), dWe.data_ptr(),
+                                         dbe.data_ptr(), st))
+        out = [dWe, dbe]
+        for li in range(L):
+            out += [grads_w[li], grads_b[li]]
+        return out
+
+    # ------------------------------------------------------------------------------------------
+    # reverse diffusion loop (reference gaussian_diffusion.py:161-220)
+    # ------------------------------------------------------------------------------------------
+    def p_sample_loop(self, x_start, steps, T, tabs32, eps_mode, sampling_noise, noise0=None, step_noise=None,
+                      capture=None):
+        """tabs32: dict of float32 device tables [T] (sqrt_ab, sqrt_1mab, c1, c2, r1, r2, sigma)."""
+        m, lib = self.model, self.lib
+        B, dev, I = x_start.shape[0], x_start.device, self.I
+        layers = self._layers()
+        bufs = self.buffers(B, dev)
+        st = _lib.stream_ptr()
+        self.version += 1
+        if bufs.xin2 is None:
+            bufs.xin2 = torch.zeros_like(bufs.xin)
+        if bufs.xt is None:
+            bufs.xt = torch.zeros(B, bufs.ldi, dtype=torch.float32, device=dev)
+        cur, nxt = bufs.xin, bufs.xin2
+        norm = bool(m.norm)
+        keep = []
+        t_vec = torch.full((B,), max(steps - 1, 0), dtype=torch.int64, device=dev)
+        t0 = torch.full((B,), T - 1, dtype=torch.int64, device=dev)
+        # x_T: either x_start itself or q_sample(x_start, steps-1); lands in xt (always) and, when the
+        # model does not normalise, directly in the first-layer input with the embedding of t = T-1.
+        ca = cb = None
+        if steps > 0:
+            ca, cb = tabs32["sqrt_ab"], tabs32["sqrt_1mab"]
+        xt = bufs.xt
+        # pass 1: x_t only (ts = steps-1 for the noising coefficients)
+        keep.append(self._prep(bufs, x_start, t_vec, ca, cb, noise0, None, False, xt_out=xt, xin=nxt))
+        out = None
+        for n, i in enumerate(range(T - 1, -1, -1)):
+            ts = t0 if i == T - 1 else torch.full((B,), i, dtype=torch.int64, device=dev)
+            # build the layer input for timestep i from the current x_t (no dropout in sampling)
+            keep.append(self._prep(bufs, xt[:, :I], ts, None, None, None, None, False, xin=cur))
+            A, lda = self._hidden_forward(bufs, layers, B, xin=cur)
+            w, bias, _ = layers[-1]
+            N, K = w.shape
+            c1, c2 = tabs32["c1"][i].expand(B).contiguous(), tabs32["c2"][i].expand(B).contiguous()
+            r1 = r2 = sg = z = None
+            if eps_mode:
+                r1, r2 = tabs32["r1"][i].expand(B).contiguous(), tabs32["r2"][i].expand(B).contiguous()
+            if sampling_noise and i != 0:
+                sg = tabs32["sigma"][i].expand(B).contiguous()
+                z = step_noise[n] if step_noise is not None else torch.randn(B, I, dtype=torch.float32, device=dev)
+                z = z.contiguous()
+            pred = None
+            if capture is not None:
+                pred = torch.empty(B, I, dtype=torch.float32, device=dev)
+            out = torch.empty(B, I, dtype=torch.float32, device=dev) if i == 0 else None
+            xn = out if out is not None else (bufs.diff if xt is bufs.xt else bufs.xt)
+            _lib.check(lib.gdmcf_linear_posterior_fwd_f32(
+                A.data_ptr(), lda, w.data_ptr(), w.stride(0), bias.data_ptr(), xt.data_ptr(), xt.stride(0),
+                c1.data_ptr(), c2.data_ptr(), _lib.ptr(r1), _lib.ptr(r2), _lib.ptr(sg), _lib.ptr(z),
+                z.stride(0) if z is not None else 0, B, N, K, xn.data_ptr(), xn.stride(0), _lib.ptr(pred),
+                pred.stride(0) if pred is not None else 0, st))
+            keep.append((c1, c2, r1, r2, sg, z))
+            if capture is not None:
+                capture.setdefault("pred_xstart", []).append(pred)
+                capture.setdefault("mean", []).append(xn[:, :I].clone())
+            xt = xn
+        self._saved = None
+        del keep
+        return out

@@ -1,0 +1,249 @@
+"""Gaussian diffusion over dense user-interaction rows with the reference's interface
+(reference models/gaussian_diffusion.py:54-547): same constructor, `training_losses`, `p_sample`,
+`q_sample`, `sample_timesteps`, `SNR`, the schedule tables as float64 attributes, the
+`Lt_history` / `Lt_count` importance-sampling state.
+
+Everything per-element runs in HIP kernels through the C ABI (include/gdmcf_hip.h); this file is
+the host-side mirror of the reference class.  Extra keyword-only arguments (`ts`, `pt`, `noise`,
+`drop_mask`, ...) inject the randomness explicitly -- that is how the parity tests compare with
+the CPU oracle on identical inputs.  Without them noise and dropout come from an in-kernel
+Philox stream and are never materialised in HBM.
+"""
+import enum
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .DNN import DNN
+
+_SCHEDULE_KIND = {"linear": 0, "linear-var": 1, "cosine": 2, "binomial": 3}
+
+
+class ModelMeanType(enum.Enum):
+    START_X = enum.auto()  # the model predicts x_0
+    EPSILON = enum.auto()  # the model predicts epsilon
+
+
+class _TrainLoss(torch.autograd.Function):
+    """loss[B] (float64) of the fused q_sample -> denoiser -> weighted row-MSE path."""
+
+    @staticmethod
+    def forward(ctx, eng, spec, *params):
+        loss = eng.train_forward(spec)
+        ctx.eng, ctx.version = eng, eng.version
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        eng = ctx.eng
+        if ctx.version != eng.version:
+            raise RuntimeError("gdmcf_amd: activations were overwritten by a later forward; "
+                               "call backward before the next training_losses/forward")
+        return (None, None, *eng.train_backward(gloss))
+
+
+class GaussianDiffusion(nn.Module):
+    def __init__(self, mean_type, noise_schedule, noise_scale, noise_min, noise_max, steps, device,
+                 history_num_per_term=10, beta_fixed=True, discrete=0.99, CatOneHot=False, epps=None, args=None):
+        super().__init__()
+        if CatOneHot:
+            raise NotImplementedError("CatOneHot (discrete one-hot branch) is outside the hot path (SURVEY 8f)")
+        self.mean_type = mean_type
+        self.noise_schedule = noise_schedule
+        self.noise_scale = noise_scale
+        self.noise_min = noise_min
+        self.noise_max = noise_max
+        self.steps = steps
+        self.device = torch.device(device)
+        self.discrete = discrete
+        self.CatOneHot = CatOneHot
+        self.gcn = 0
+        self.indexIn = None
+        self.history_num_per_term = history_num_per_term
+        self.Lt_history = torch.zeros(steps, history_num_per_term, dtype=torch.float64, device=self.device)
+        self.Lt_count = torch.zeros(steps, dtype=torch.int64, device=self.device)
+        self._hist_full = False
+        self.update_history = True  # data-parallel wrappers switch this off and replay the gathered batch
+        self.rng = "philox"  # "philox": in-kernel noise/dropout;  "torch": torch.randn / torch.bernoulli
+        if noise_scale != 0.0:
+            if noise_schedule not in _SCHEDULE_KIND:
+                raise NotImplementedError(f"unknown beta schedule: {noise_schedule}!")
+            tabs = _lib.schedule_tables(_SCHEDULE_KIND[noise_schedule], noise_scale, noise_min, noise_max, steps,
+                                        beta_fixed)
+            for name, row in zip(_lib.TABLE_NAMES, tabs):
+                setattr(self, name, torch.from_numpy(row.copy()).to(self.device))
+            self._derive_tables()
+
+    # -- tables -----------------------------------------------------------------------------
+    def get_betas(self):
+        kind = _SCHEDULE_KIND.get(self.noise_schedule)
+        if kind is None:
+            raise NotImplementedError(f"unknown beta schedule: {self.noise_schedule}!")
+        return _lib.schedule_tables(kind, self.noise_scale, self.noise_min, self.noise_max, self.steps, False)[0]
+
+    def _derive_tables(self):
+        """float32 copies (the reference casts to f32 in _extract_into_tensor, :544) and the
+        float64 per-timestep loss weights (:339-350)."""
+        f = lambda t: t.to(torch.float32).contiguous()
+        t = torch.arange(self.steps, device=self.device)
+        self._t32 = dict(
+            sqrt_ab=f(self.sqrt_alphas_cumprod), sqrt_1mab=f(self.sqrt_one_minus_alphas_cumprod),
+            c1=f(self.posterior_mean_coef1), c2=f(self.posterior_mean_coef2),
+            r1=f(self.sqrt_recip_alphas_cumprod), r2=f(self.sqrt_recipm1_alphas_cumprod),
+            sigma=torch.exp(0.5 * f(self.posterior_log_variance_clipped)).contiguous())
+        w_x0 = torch.where(t == 0, 1.0, self.SNR(t - 1) - self.SNR(t))
+        w_eps = (1 - self.alphas_cumprod) / ((1 - self.alphas_cumprod_prev) ** 2 * (1 - self.betas))
+        w_eps = torch.where(t == 0, 1.0, w_eps)
+        self._weights = {"x0": w_x0.contiguous(), "eps": w_eps.contiguous(),
+                         "one": torch.ones(self.steps, dtype=torch.float64, device=self.device)}
+
+    def SNR(self, t):
+        return self.alphas_cumprod[t] / (1 - self.alphas_cumprod[t])
+
+    def _extract_into_tensor(self, arr, timesteps, broadcast_shape):
+        res = arr.to(timesteps.device)[timesteps].float()
+        while len(res.shape) < len(broadcast_shape):
+            res = res[..., None]
+        return res.expand(broadcast_shape)
+
+    # -- timesteps ---------------------------------------------------------------------------
+    def importance_probs(self, uniform_prob=0.001):
+        Lt_sqrt = torch.sqrt(torch.mean(self.Lt_history ** 2, axis=-1))
+        pt_all = Lt_sqrt / torch.sum(Lt_sqrt)
+        pt_all = pt_all * (1 - uniform_prob)
+        pt_all = pt_all + uniform_prob / len(pt_all)
+        return pt_all
+
+    def sample_timesteps(self, batch_size, device, method="uniform", uniform_prob=0.001):
+        if method == "importance":
+            if not self._hist_full:
+                # counts only grow, so once full the (device-syncing) check is never needed again
+                self._hist_full = bool((self.Lt_count == self.history_num_per_term).all())
+            if not self._hist_full:
+                return self.sample_timesteps(batch_size, device, method="uniform")
+            pt_all = self.importance_probs(uniform_prob)
+            t = torch.multinomial(pt_all, num_samples=batch_size, replacement=True)
+            pt = pt_all.gather(dim=0, index=t) * len(pt_all)
+            return t, pt
+        elif method == "uniform":
+            t = torch.randint(0, self.steps, (batch_size,), device=device).long()
+            pt = torch.ones_like(t).float()
+            return t, pt
+        raise ValueError
+
+    # -- q_sample ----------------------------------------------------------------------------
+    def q_sample(self, x_start, t, noise=None):
+        """x_t = sqrt(abar_t) x_0 + sqrt(1-abar_t) eps  (reference :399-407), HIP kernel."""
+        _lib.require_gpu(x_start, "x_start")
+        if noise is not None:
+            assert noise.shape == x_start.shape
+        lib = _lib.load()
+        B, I = x_start.shape
+        x = x_start.float().contiguous()
+        ldo = (I + 3) // 4 * 4
+        out = torch.empty(B, ldo, dtype=torch.float32, device=x.device)
+        t = t.to(device=x.device, dtype=torch.int64).contiguous()
+        nz = None if noise is None else noise.float().contiguous()
+        self._q_calls = getattr(self, "_q_calls", 0) + 1
+        rc = lib.gdmcf_dnn_prep_input_f32(
+            x.data_ptr(), x.stride(0), t.data_ptr(), self._t32["sqrt_ab"].data_ptr(),
+            self._t32["sqrt_1mab"].data_ptr(), 1 if nz is not None else 2, _lib.ptr(nz),
+            nz.stride(0) if nz is not None else 0, 0, None, 0, 0.0, int(torch.initial_seed()) & (2 ** 63 - 1),
+            (1 << 40) + self._q_calls, 0, None, None, 0, B, I, out.data_ptr(), ldo, None, 0, None, None,
+            _lib.stream_ptr())
+        _lib.check(rc)
+        return out[:, :I]
+
+    # -- training ------------------------------------------------------------------------------
+    def training_losses(self, model, x_start, reweight=False, index=None, *, ts=None, pt=None, noise=None,
+                        drop_mask=None):
+        _lib.require_gpu(x_start, "x_start")
+        if not isinstance(model, DNN):
+            raise TypeError("gdmcf_amd.GaussianDiffusion.training_losses needs a gdmcf_amd.DNN denoiser")
+        batch_size, device = x_start.size(0), x_start.device
+        assert x_start.dim() == 2 and x_start.size(1) == model.in_dims[0], "x_start must be [B, n_items]"
+        if ts is None:
+            ts, pt = self.sample_timesteps(batch_size, device, "importance")
+        ts = ts.to(device=device, dtype=torch.int64).contiguous()
+        pt = pt.to(device=device, dtype=torch.float64).contiguous()
+        eps_mode = self.mean_type == ModelMeanType.EPSILON
+        if self.mean_type not in (ModelMeanType.START_X, ModelMeanType.EPSILON):
+            raise NotImplementedError(self.mean_type)
+        ca = cb = None
+        if self.noise_scale != 0.0:
+            ca, cb = self._t32["sqrt_ab"], self._t32["sqrt_1mab"]
+            if noise is None and (eps_mode or self.rng == "torch"):
+                noise = torch.randn_like(x_start, dtype=torch.float32)  # eps is the target: must exist in HBM
+        elif eps_mode:
+            raise NotImplementedError("noise_scale == 0 with mean_type EPSILON")
+        if drop_mask is None and self.rng == "torch" and model.training and model.drop.p > 0:
+            drop_mask = torch.bernoulli(torch.full_like(x_start, 1.0 - model.drop.p, dtype=torch.float32)).to(torch.uint8)
+        if reweight == True:  # noqa: E712  (the reference's own test)
+            weight_t = self._weights["eps" if eps_mode else "x0"]
+        else:
+            if eps_mode:
+                raise NotImplementedError("reweight=False with mean_type EPSILON")
+            # the reference leaves `loss` undefined here (NameError); DiffRec semantics: unit weights on the mse
+            weight_t = self._weights["one"]
+        spec = dict(x_start=x_start, ts=ts, pt=pt, ca=ca, cb=cb, noise=noise, drop_mask=drop_mask, eps_mode=eps_mode,
+                    weight_t=weight_t, T=self.steps, H=self.history_num_per_term, Lt_history=self.Lt_history,
+                    Lt_count=self.Lt_count, update_history=self.update_history)
+        if eps_mode:
+            spec["r1_0"] = self._t32["r1"][0]
+            spec["r2_0"] = self._t32["r2"][0]
+        eng = model.engine
+        loss = _TrainLoss.apply(eng, spec, *model.param_list())
+        self.last_ts, self.last_loss_unscaled = ts, eng.buffers(batch_size, device).lu
+        return {"loss": loss}
+
+    # -- sampling --------------------------------------------------------------------------------
+    def p_sample(self, model, x_start, steps, sampling_noise=False, index=None, *, noise0=None, step_noise=None,
+                 capture=None):
+        assert steps <= self.steps, "Too much steps in inference."
+        _lib.require_gpu(x_start, "x_start")
+        if not isinstance(model, DNN):
+            raise TypeError("gdmcf_amd.GaussianDiffusion.p_sample needs a gdmcf_amd.DNN denoiser")
+        if self.noise_scale == 0.0:
+            x_t = x_start
+            with torch.no_grad():
+                for i in list(range(self.steps))[::-1]:
+                    t = torch.full((x_t.shape[0],), i, dtype=torch.int64, device=x_t.device)
+                    x_t = model(x_t, t)
+            return x_t
+        with torch.no_grad():
+            return model.engine.p_sample_loop(x_start, steps, self.steps, self._t32,
+                                              self.mean_type == ModelMeanType.EPSILON, bool(sampling_noise),
+                                              noise0=noise0, step_noise=step_noise, capture=capture)
+
+
+# ---- module-level helpers of the reference file (kept for API parity) -------------------------------
+def betas_from_linear_variance(steps, variance, max_beta=0.999):
+    alpha_bar = 1 - variance
+    betas = [1 - alpha_bar[0]]
+    for i in range(1, steps):
+        betas.append(min(1 - alpha_bar[i] / alpha_bar[i - 1], max_beta))
+    return np.array(betas)
+
+
+def betas_for_alpha_bar(num_diffusion_timesteps, alpha_bar, max_beta=0.999):
+    betas = []
+    for i in range(num_diffusion_timesteps):
+        t1 = i / num_diffusion_timesteps
+        t2 = (i + 1) / num_diffusion_timesteps
+        betas.append(min(1 - alpha_bar(t2) / alpha_bar(t1), max_beta))
+    return np.array(betas)
+
+
+def normal_kl(mean1, logvar1, mean2, logvar2):
+    """KL between two diagonal gaussians (reference :1165-1192; dead code there)."""
+    tensor = next((o for o in (mean1, logvar1, mean2, logvar2) if isinstance(o, torch.Tensor)), None)
+    assert tensor is not None, "at least one argument must be a Tensor"
+    logvar1, logvar2 = [x if isinstance(x, torch.Tensor) else torch.tensor(x).to(tensor) for x in (logvar1, logvar2)]
+    return 0.5 * (-1.0 + logvar2 - logvar1 + torch.exp(logvar1 - logvar2) + ((mean1 - mean2) ** 2) * torch.exp(-logvar2))
+
+
+def mean_flat(tensor):
+    return tensor.mean(dim=list(range(1, len(tensor.shape))))

@@ -1,0 +1,74 @@
+"""Fused multi-tensor AdamW (drop-in for torch.optim.AdamW as constructed at reference main.py:258).
+
+One HIP launch (gdmcf_adamw_f32) updates every parameter: 28 B of HBM traffic per element
+(read p, g, m, v; write p, m, v).  Same update rule and the same state_dict layout
+(`step`, `exp_avg`, `exp_avg_sq`) as torch.optim.AdamW (amsgrad / maximize are not supported).
+"""
+import torch
+
+from . import _lib
+
+_BLOCK = 4096  # elements per workgroup; must match ADAM_BLOCK_ELEMS in kernels_misc.hip
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=False):
+        if amsgrad:
+            raise NotImplementedError("FusedAdamW: amsgrad is not supported")
+        if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
+            raise ValueError("FusedAdamW: invalid hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._tables = {}
+        self.grad_scale = 1.0
+
+    def _table(self, gi, plist):
+        """Device table [n][6] = (p, g, m, v, numel, first_block); re-uploaded only when a pointer moved."""
+        rows, blk = [], 0
+        for p in plist:
+            st = self.state[p]
+            rows.append((p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
+                         p.numel(), blk))
+            blk += (p.numel() + _BLOCK - 1) // _BLOCK
+        key = tuple(rows)
+        cached = self._tables.get(gi)
+        if cached is None or cached[0] != key:
+            host = torch.tensor(rows, dtype=torch.int64)
+            cached = (key, host.to(plist[0].device), blk)
+            self._tables[gi] = cached
+        return cached[1], cached[2]
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = _lib.load()
+        for gi, group in enumerate(self.param_groups):
+            plist = [p for p in group["params"] if p.grad is not None]
+            if not plist:
+                continue
+            for p in plist:
+                _lib.require_gpu(p, "FusedAdamW parameter")
+                if p.dtype != torch.float32 or not p.is_contiguous():
+                    raise RuntimeError("FusedAdamW: parameters must be contiguous float32")
+                if p.grad.is_sparse:
+                    raise RuntimeError("FusedAdamW does not support sparse gradients")
+                if not p.grad.is_contiguous() or p.grad.dtype != torch.float32:
+                    p.grad = p.grad.float().contiguous()
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            steps = {int(self.state[p]["step"]) for p in plist}
+            if len(steps) != 1:
+                raise RuntimeError("FusedAdamW: parameters of one group must share the step count")
+            step = steps.pop() + 1
+            table, nblk = self._table(gi, plist)
+            b1, b2 = group["betas"]
+            _lib.check(lib.gdmcf_adamw_f32(table.data_ptr(), len(plist), nblk, group["lr"], b1, b2, group["eps"],
+                                           group["weight_decay"], step, float(self.grad_scale), _lib.stream_ptr()))
+            for p in plist:
+                self.state[p]["step"] = step
+        return loss

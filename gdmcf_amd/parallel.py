@@ -1,0 +1,87 @@
+"""Data parallelism for the training step: one process per GPU, torch.distributed (backend "nccl"
+is RCCL on ROCm, over xGMI); "gloo" on CPU for tests.
+
+User rows are independent through q_sample, the denoiser forward and the per-row loss, so a batch
+shards over ranks with exactly one exchange per step:
+  * all-reduce(SUM) of the parameter gradients, scaled by 1/world in the fused AdamW
+    (rank r holds rows [r*B, (r+1)*B) of the global batch; grad of the global mean = mean of
+    the local-mean grads);
+  * an all-gather of (ts, unscaled loss) -- 16 B per row -- so every rank replays the identical
+    order-dependent Lt-history FIFO update (reference gaussian_diffusion.py:355-368) over the
+    global batch in rank order.
+The reference has no distributed path; this is new, MI355X-first design.
+"""
+import torch
+import torch.distributed as dist
+
+
+def allreduce_grads(params, group=None, bucket_bytes=256 << 20):
+    """In-place SUM all-reduce of .grad over ranks.  Large tensors go alone (no copy); small ones are
+    coalesced into one flat bucket.  xGMI is point-to-point, so few, large messages are preferred."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    small, handles = [], []
+    for p in params:
+        if p.grad is None:
+            continue
+        g = p.grad
+        if g.numel() * g.element_size() >= (1 << 20):
+            handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group, async_op=True))
+        else:
+            small.append(g)
+    if small:
+        flat = torch.cat([g.reshape(-1) for g in small])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        off = 0
+        for g in small:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+    for h in handles:
+        h.wait()
+
+
+def gather_history_inputs(ts, loss_unscaled, group=None):
+    """All-gather (ts, unscaled per-row loss) in rank order -> tensors of the GLOBAL batch."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return ts, loss_unscaled
+    world = dist.get_world_size(group)
+    ts_all = [torch.empty_like(ts) for _ in range(world)]
+    lu_all = [torch.empty_like(loss_unscaled) for _ in range(world)]
+    dist.all_gather(ts_all, ts.contiguous(), group=group)
+    dist.all_gather(lu_all, loss_unscaled.contiguous(), group=group)
+    return torch.cat(ts_all), torch.cat(lu_all)
+
+
+def broadcast_parameters(model, group=None, src=0):
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        for p in model.parameters():
+            dist.broadcast(p.data, src=src, group=group)
+
+
+class DataParallelStep:
+    """zero_grad -> training_losses -> mean -> backward -> all-reduce -> AdamW, per rank (the body of
+    reference main.py:345-351 plus the single exchange)."""
+
+    def __init__(self, diffusion, model, optimizer, group=None):
+        self.diffusion, self.model, self.optimizer, self.group = diffusion, model, optimizer, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if self.world > 1:
+            diffusion.update_history = False  # replayed below on the gathered global batch
+            optimizer.grad_scale = 1.0 / self.world
+            broadcast_parameters(model, group)
+
+    def __call__(self, batch, reweight=True, **rand):
+        from . import _lib
+        self.optimizer.zero_grad()
+        losses = self.diffusion.training_losses(self.model, batch, reweight, **rand)
+        loss = losses["loss"].mean()
+        loss.backward()
+        if self.world > 1:
+            allreduce_grads(self.model.parameters(), self.group)
+            d = self.diffusion
+            ts_all, lu_all = gather_history_inputs(d.last_ts, d.last_loss_unscaled, self.group)
+            _lib.check(_lib.load().gdmcf_lt_history_update(ts_all.data_ptr(), lu_all.data_ptr(), ts_all.numel(),
+                                                           d.steps, d.history_num_per_term, d.Lt_history.data_ptr(),
+                                                           d.Lt_count.data_ptr(), _lib.stream_ptr()))
+        self.optimizer.step()
+        return loss

@@ -1,0 +1,190 @@
+/* gdmcf_hip.h -- C ABI of libgdmcf_hip.so, the MI355X (gfx950) hot path of GDMCF.
+ *
+ * The reference (GDMCF/GDMCF, pure Python on PyTorch) has NO FFI / plugin interface
+ * (SURVEY.md F1): its boundary is the Python object protocol between main.py and the classes
+ * GaussianDiffusion / DNN / LightGCN.  This header is the C boundary a maintainer would bind
+ * underneath those classes; every entry point names the reference code it replaces
+ * (file:line relative to the reference root).  gdmcf_amd/ (Python, ctypes) is that binding.
+ *
+ * Conventions
+ *   - plain pointers + sizes; all `const float*`/`float*`/`int64_t*` arguments are DEVICE
+ *     pointers unless the name ends in `_host`; no torch types.
+ *   - matrices are row-major; `ld*` is the row stride in ELEMENTS (may exceed the width).
+ *   - every device function enqueues work on `stream` (a hipStream_t passed as void*) and
+ *     returns immediately: 0 = ok, negative = error (GDMCF_E_*); the Python layer maps
+ *     GDMCF_E_SHAPE to AssertionError, GDMCF_E_ARG to ValueError, GDMCF_E_UNSUPPORTED to
+ *     NotImplementedError (the reference's own error conventions) and
+ *     GDMCF_E_HIP to RuntimeError.
+ *   - no function allocates device memory; scratch is passed in as `ws`/`ws_bytes`
+ *     (query the size with the matching *_ws_bytes function) so everything is
+ *     hipGraph-capturable.
+ */
+#ifndef GDMCF_HIP_H
+#define GDMCF_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GDMCF_OK 0
+#define GDMCF_E_SHAPE (-1)       /* shape/assert violation  -> AssertionError      */
+#define GDMCF_E_ARG (-2)         /* bad enum / value        -> ValueError          */
+#define GDMCF_E_UNSUPPORTED (-3) /* unknown schedule etc.   -> NotImplementedError */
+#define GDMCF_E_HIP (-4)         /* HIP runtime error       -> RuntimeError        */
+#define GDMCF_E_WORKSPACE (-5)   /* workspace too small     -> RuntimeError        */
+
+/* library / device ------------------------------------------------------------------ */
+int gdmcf_version(void);                 /* ABI version, currently 1 */
+const char* gdmcf_last_error(void);      /* thread-local message of the last failing call */
+int gdmcf_device_info(int* n_cu, int* wave_size, char* arch_host, int arch_len);
+
+/* Optional in-library timing with HIP events on the launch stream (bench.py's live roofline
+ * measurement).  While enabled, every tagged kernel launch is bracketed by two hipEventRecord
+ * calls; gdmcf_prof_collect synchronises them and returns (tag, milliseconds, work) triples,
+ * where work = algorithmic FLOPs (GEMM tags) or bytes (HBM-bound tags) of that launch.
+ * Tags: 1 linear_fwd gemm, 2 loss_fwd gemm, 3 posterior gemm, 4 bwd_input gemm, 5 bwd_weight gemm,
+ * 6 adamw, 7 prep_input, 8 spmm, 9 topk.                                                     */
+int gdmcf_prof_enable(int on);
+int gdmcf_prof_collect(int cap, int* tags_host, float* ms_host, double* work_host);
+
+/* ---- schedules: host, float64 --------------------------------------------------------
+ * replaces GaussianDiffusion.get_betas + calculate_for_diffusion
+ * (models/gaussian_diffusion.py:109-159, betas_from_linear_variance :1138-1144,
+ * betas_for_alpha_bar :1146-1163, betas[0]=1e-5 :79).
+ * kind: 0 linear, 1 linear-var, 2 cosine, 3 binomial.
+ * out_tables_host: [13][T] doubles in this order: betas, alphas_cumprod, alphas_cumprod_prev,
+ * alphas_cumprod_next, sqrt_alphas_cumprod, sqrt_one_minus_alphas_cumprod,
+ * log_one_minus_alphas_cumprod, sqrt_recip_alphas_cumprod, sqrt_recipm1_alphas_cumprod,
+ * posterior_variance, posterior_log_variance_clipped, posterior_mean_coef1, posterior_mean_coef2.
+ * Returns GDMCF_E_SHAPE when the reference's asserts (:81-83) would fire. */
+#define GDMCF_N_TABLES 13
+int gdmcf_schedule_build(int kind, double noise_scale, double noise_min, double noise_max, int T,
+                         int beta_fixed, double* out_tables_host);
+
+/* ---- denoiser input: q_sample + F.normalize + dropout + timestep embedding + cat ------
+ * replaces GaussianDiffusion.q_sample (:399-407) with _extract_into_tensor (:532-547),
+ * and DNN.forward's prologue (models/DNN.py:73-78): timestep_embedding (:1806-1825),
+ * emb_layer, F.normalize, nn.Dropout, torch.cat.
+ *   xin[b, 0:I]   = drop( norm( ca[ts[b]]*x[b,:] + cb[ts[b]]*noise[b,:] ) )
+ *   xin[b, I:I+E] = emb_w @ temb(ts[b]) + emb_b ;  xin[b, I+E:ldxin] = 0
+ * ca/cb: float32 tables [T] (the reference casts the f64 tables to f32 before use); pass
+ * NULL for both to skip the q_sample (xin <- x).
+ * noise_mode 0: none (requires ca==NULL or cb treated as 0); 1: explicit `noise` [B,ldn];
+ *            2: Philox4x32-10 + Box-Muller N(0,1): element (b,i) is component i&3 of the block with
+ *               counter (i>>2, b, stream, offset) and key seed (stream 0 = noise, 1 = dropout),
+ *               so any kernel can regenerate it.
+ * drop_mode  0: none; 1: explicit keep-mask `keep` (uint8 [B,ldkeep]); 2: Philox Bernoulli(1-p).
+ * normalize != 0 applies F.normalize (L2, eps 1e-12) to the (noised) row before dropout and
+ * needs rownorm_ws (float32 [B] scratch).
+ * xt_out (optional, [B,ldxt]) receives the pre-normalize/pre-dropout x_t.
+ * temb_out (optional, [B,E]) receives the sinusoidal embedding (needed by the backward).   */
+int gdmcf_dnn_prep_input_f32(const float* x, int64_t ldx, const int64_t* ts, const float* ca,
+                             const float* cb, int noise_mode, const float* noise, int64_t ldn,
+                             int drop_mode, const uint8_t* keep, int64_t ldkeep, float drop_p,
+                             uint64_t seed, uint64_t offset, int normalize, const float* emb_w,
+                             const float* emb_b, int E, int B, int I, float* xin, int64_t ldxin,
+                             float* xt_out, int64_t ldxt, float* temb_out, float* rownorm_ws,
+                             void* stream);
+
+/* Rewrites only the embedding + padding columns [I, ldxin) of xin for new timesteps (reverse
+ * loop: x_t already sits in xin[:, 0:I], written by gdmcf_linear_posterior_fwd_f32).          */
+int gdmcf_dnn_emb_cols_f32(const int64_t* ts, const float* emb_w, const float* emb_b, int E, int B,
+                           int I, float* xin, int64_t ldxin, float* temb_out, void* stream);
+
+/* ---- dense layers on the f32 MFMA (v_mfma_f32_16x16x4_f32) -------------------------------
+ * replaces nn.Linear (+tanh) in DNN.forward (models/DNN.py:79-86) and their autograd backward
+ * (main.py:350).  W is nn.Linear layout [N,K].  act: 0 none, 1 tanh.                        */
+size_t gdmcf_linear_ws_bytes(int M, int N, int K);
+/* C[M,N] = act(A[M,K] @ W[N,K]^T + bias) */
+int gdmcf_linear_fwd_f32(const float* A, int64_t lda, const float* W, int64_t ldw,
+                         const float* bias, int act, int M, int N, int K, float* C, int64_t ldc,
+                         void* ws, size_t ws_bytes, void* stream);
+/* Last layer fused with the per-row diffusion loss (gaussian_diffusion.py:335 mean_flat):
+ *   out = A @ W^T + bias ;  diff[m,n] = alpha[m]*out[m,n] - target[m,n]   (alpha NULL -> 1)
+ *   rowsum[m] = sum_n diff[m,n]^2  (deterministic two-stage reduction)
+ * `out` may be NULL (training never needs it).  rowpart: scratch [M, gdmcf_loss_tiles(N)]. */
+int gdmcf_loss_tiles(int N);
+int gdmcf_linear_loss_fwd_f32(const float* A, int64_t lda, const float* W, int64_t ldw,
+                              const float* bias, const float* target, int64_t ldt,
+                              const float* alpha, int M, int N, int K, float* out, int64_t ldo,
+                              float* diff, int64_t ldd, float* rowpart, float* rowsum,
+                              void* stream);
+/* Last layer fused with the reverse-diffusion posterior mean (gaussian_diffusion.py:473-515,
+ * :451-471, :518-523, :210-217):  out = A @ W^T + bias
+ *   pred = eps_mode ? r1[t]*x_t - r2[t]*out : out ;  mean = c1[t]*pred + c2[t]*x_t
+ *   x_next = mean + (t!=0 ? sigma[t]*z : 0)            (z NULL -> deterministic)
+ * per-row coefficient vectors c1,c2,r1,r2,sigma are float32 [M] (already gathered by t).    */
+int gdmcf_linear_posterior_fwd_f32(const float* A, int64_t lda, const float* W, int64_t ldw,
+                                   const float* bias, const float* x_t, int64_t ldxt,
+                                   const float* c1, const float* c2, const float* r1,
+                                   const float* r2, const float* sigma, const float* z,
+                                   int64_t ldz, int M, int N, int K, float* x_next,
+                                   int64_t ldxn, float* pred_out, int64_t ldp, void* stream);
+/* dA[M,K] = rowscale[m] * (dZ[M,N] @ W[N,K]) * (act==1 ? 1 - Aact[m,k]^2 : 1)
+ * (grad wrt the layer input, fused with the previous layer's tanh').  rowscale may be NULL. */
+int gdmcf_linear_bwd_input_f32(const float* dZ, int64_t lddz, const float* W, int64_t ldw,
+                               const float* rowscale, const float* Aact, int64_t ldact, int act,
+                               int M, int N, int K, float* dA, int64_t ldda, void* ws,
+                               size_t ws_bytes, void* stream);
+/* dW[N,K] = dZ[M,N]^T @ A[M,K]  (weight grad; accumulate != 0 adds into dW)
+ * db[N]   = sum_m rowscale[m]*dZ[m,n]   (db NULL -> skipped).  When rowscale != NULL the
+ * caller passes A already multiplied by rowscale (see gdmcf_rowscale_f32).                 */
+int gdmcf_linear_bwd_weight_f32(const float* dZ, int64_t lddz, const float* A, int64_t lda,
+                                const float* rowscale, int M, int N, int K, float* dW,
+                                int64_t lddw, float* db, int accumulate, void* stream);
+int gdmcf_rowscale_f32(const float* A, int64_t lda, const float* rowscale, int M, int K, float* out,
+                       int64_t ldo, void* stream);
+/* Gradients of the timestep-embedding branch (models/DNN.py:73-74,78):
+ *   demb[m,e] = sum_n dZ1[m,n]*W1[n, I+e] ;  dWe = demb^T @ temb ;  dbe = sum_m demb       */
+int gdmcf_emb_bwd_f32(const float* dZ1, int64_t lddz, const float* W1, int64_t ldw, int I, int E,
+                      const float* temb, int M, int N, float* demb_ws, float* dWe, float* dbe,
+                      void* stream);
+
+/* ---- per-row loss tail, float64 (gaussian_diffusion.py:339-370) --------------------------
+ *   loss[b] = weight_t[ts[b]] * (float64)(rowsum[b]/rowdiv[b]) ; Lt-history FIFO update in
+ *   batch order (:355-368) ; loss[b] /= pt[b].   rowdiv = I (mse) or 2I (likelihood), f32.
+ * weight_t: float64 [T].  pt: float64 [B].  Lt_history: float64 [T,H]; Lt_count: int64 [T].
+ * gradcoef[b] (optional) = d loss[b] / d out[b,n] / diff[b,n] = 2*alpha[b]*weight/(pt*rowdiv),
+ * the per-row factor the backward multiplies `diff` by (alpha NULL -> 1).
+ * update_history == 0 leaves the ring buffer untouched (data-parallel ranks call
+ * gdmcf_lt_history_update on the gathered batch instead).                                  */
+int gdmcf_row_loss_finish_f64(const float* rowsum, const float* rowdiv, const float* alpha,
+                              const int64_t* ts, const double* weight_t, const double* pt, int B,
+                              int T, int H, double* Lt_history, int64_t* Lt_count,
+                              int update_history, double* loss_unscaled, double* loss,
+                              float* gradcoef, void* stream);
+int gdmcf_lt_history_update(const int64_t* ts, const double* loss_unscaled, int B, int T, int H,
+                            double* Lt_history, int64_t* Lt_count, void* stream);
+
+/* ---- fused multi-tensor AdamW (torch.optim.AdamW as used at main.py:258,351) -------------
+ * table: device int64 [n_tensors][6] = {param*, grad*, exp_avg*, exp_avg_sq*, numel, first_block}
+ * (first_block = prefix sum of ceil(numel/4096)); total_blocks = grid size.
+ * grad_scale multiplies every gradient first (1/world_size for data parallel).             */
+int gdmcf_adamw_f32(const int64_t* table, int n_tensors, int total_blocks, float lr, float beta1,
+                    float beta2, float eps, float weight_decay, int step, float grad_scale,
+                    void* stream);
+
+/* ---- evaluation: history mask + top-k (main.py:296-301) ----------------------------------
+ * For every row: entries listed in the CSR history mask become -inf, then the k largest
+ * scores are returned in descending order; ties broken by LOWEST index (torch.topk leaves
+ * tie order unspecified).  mask_indptr int64 [B+1] / mask_indices int32 (NULL = no mask).  */
+int gdmcf_topk_masked_f32(const float* pred, int64_t ldp, int B, int I, const int64_t* mask_indptr,
+                          const int32_t* mask_indices, int k, int64_t* idx_out, float* val_out,
+                          void* stream);
+
+/* ---- LightGCN propagation: CSR SpMM (lightGCN.py:184-189) --------------------------------
+ * Y[r,:] = sum_j val[j]*X[col[j],:]   for j in [rowptr[r], rowptr[r+1])
+ * acc (optional): acc[r,:] += Y[r,:]  -- running layer sum for the layer mean (:188-189).
+ * rowptr int64 [n_rows+1], col int32, val float32; X,Y [*,d] with row strides ldx/ldy.      */
+int gdmcf_spmm_csr_f32(const int64_t* rowptr, const int32_t* col, const float* val, int n_rows,
+                       const float* X, int64_t ldx, int d, float* Y, int64_t ldy, float* acc,
+                       int64_t ldacc, void* stream);
+/* out = acc * scale  (layer mean = running sum / (L+1)) */
+int gdmcf_scale_f32(const float* acc, int64_t n, float scale, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GDMCF_HIP_H */
