@@ -89,8 +89,14 @@ __device__ __forceinline__ void xt4(const PrepArgs& a, int b, int col, float ca,
             box_muller(r.z, r.w, nz[2], nz[3]);
         }
 #pragma unroll
-        // two rounded products + one rounded sum, exactly as the reference's mul, mul, add (:403-407)
-        for (int j = 0; j < 4; ++j) v[j] = __fadd_rn(__fmul_rn(ca, v[j]), __fmul_rn(cb, nz[j]));
+        // two rounded products + one rounded sum, exactly as the reference's mul, mul, add (:403-407):
+        // no FMA contraction here (HIP's __fmul_rn/__fadd_rn are plain operators and would still fuse)
+        for (int j = 0; j < 4; ++j) {
+#pragma clang fp contract(off)
+            const float p0 = ca * v[j];
+            const float p1 = cb * nz[j];
+            v[j] = p0 + p1;
+        }
     }
 }
 

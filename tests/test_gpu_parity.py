@@ -291,6 +291,13 @@ def test_full_size_step_matches_oracle_yelp_shape():
     oopt = O.make_optimizer(om, 1e-5)
     gopt = gdmcf_amd.FusedAdamW(model.parameters(), lr=1e-5, weight_decay=0.0)
     om.train(), model.train()
+    # size-independent property at full size: the loss is linear in the per-row weights 1/pt
+    gdif.update_history = False
+    with torch.no_grad():
+        l1 = gdif.training_losses(model, cu(x), True, ts=cu(ts), pt=cu(pt), noise=cu(noise), drop_mask=cu(keep))["loss"]
+        l2 = gdif.training_losses(model, cu(x), True, ts=cu(ts), pt=cu(pt * 2), noise=cu(noise), drop_mask=cu(keep))["loss"]
+    np.testing.assert_array_equal((l2 * 2).cpu().numpy(), l1.cpu().numpy())  # deterministic kernels: exact
+    gdif.update_history = True
     oloss, ovec = O.train_step(od, om, oopt, x, True, ts=ts, pt=pt, noise=noise, drop_mask=keep)
     gopt.zero_grad()
     terms = gdif.training_losses(model, cu(x), True, ts=cu(ts), pt=cu(pt), noise=cu(noise), drop_mask=cu(keep))
@@ -302,9 +309,10 @@ def test_full_size_step_matches_oracle_yelp_shape():
     np.testing.assert_allclose(terms["loss"].detach().cpu().numpy(), ovec.numpy(), rtol=1e-4)
     for (k, p), (_, q) in zip(model.named_parameters(), om.named_parameters()):
         assert H.relerr(grads[k].cpu().numpy(), q.grad.numpy()) < 2e-4, k
-        assert np.abs(p.detach().cpu().numpy() - q.detach().numpy()).max() < 0.02 * 1e-5, k
+        # first AdamW step = -lr * g/(|g|+eps): ill-conditioned where |g| ~ eps (fp32 noise decides), so
+        # bound the worst element by a fraction of lr and require the well-conditioned ones to agree tightly
+        dp = np.abs(p.detach().cpu().numpy() - q.detach().numpy())
+        big = np.abs(q.grad.numpy()) > 1e-5
+        assert dp.max() < 0.25 * 1e-5, k
+        assert (not big.any()) or dp[big].max() < 0.01 * 1e-5, k
     np.testing.assert_allclose(gdif.Lt_history.cpu().numpy(), od.Lt_history.numpy(), rtol=1e-4)
-    # size-independent property at full size: the loss is linear in the per-row weights 1/pt
-    model.zero_grad()
-    t2 = gdif.training_losses(model, cu(x), True, ts=cu(ts), pt=cu(pt * 2), noise=cu(noise), drop_mask=cu(keep))
-    np.testing.assert_allclose(t2["loss"].detach().cpu().numpy() * 2, ovec.numpy(), rtol=1e-3)
