@@ -44,9 +44,11 @@ _SIGNATURES = {
     "gdmcf_emb_bwd_f32": (c_int, [P, c_int64, P, c_int64, c_int, c_int, P, c_int, c_int, P, P, P, P]),
     "gdmcf_row_loss_finish_f64": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, P, P, c_int, P, P, P, P]),
     "gdmcf_lt_history_update": (c_int, [P, P, c_int, c_int, c_int, P, P, P]),
+    "gdmcf_sample_timesteps": (c_int, [P, P, c_int, c_int, c_int, c_double, c_uint64, c_uint64, P, P, P, P]),
     "gdmcf_adamw_f32": (c_int, [P, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_int, c_float, P]),
     "gdmcf_topk_masked_f32": (c_int, [P, c_int64, c_int, c_int, P, P, c_int, P, P, P]),
-    "gdmcf_spmm_csr_f32": (c_int, [P, P, P, c_int, P, c_int64, c_int, P, c_int64, P, c_int64, P]),
+    "gdmcf_spmm_csr_f32": (c_int, [P, P, P, c_int, P, P, c_int, P, P, c_int, P, c_int64, c_int, P, c_int64, P, P, c_int,
+                                   c_int64, c_float, c_double, P]),
     "gdmcf_scale_f32": (c_int, [P, c_int64, c_float, P, P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -67,7 +67,6 @@ struct GdGemm {
     int splits;
     int tiles_m, tiles_n;
     int m_fastest;  // tile order inside one split
-    int veca, vecb;  // 16-byte vector loads legal for A / B
     float* C;
     int64_t ldc;
     int64_t slab_stride;

@@ -27,98 +27,92 @@ struct TileGeom {
 };
 
 // ---- global -> register staging -----------------------------------------------------------
+// 16-byte vectors that are only 4-byte aligned: gfx950 runs with unaligned access enabled and
+// hipcc emits global_load_dwordx4 for them, so odd row strides (nn.Linear in_features = 34405)
+// still stream with the widest load.
+typedef f32x4 f32x4_u __attribute__((aligned(4)));
+
 template <int LAY, int R, int BK>
 struct TileStage {
     using G = TileGeom<LAY, R, BK>;
     f32x4 reg[G::NL];
 
-    __device__ __forceinline__ void load(const float* __restrict__ P, int64_t ld, int row0, int nrows, int k0,
-                                         int kend, int vec, int tid) {
+    // Interior K tile (k0 + BK <= kend).  Branch-free so that all loads issue back to back and the
+    // only wait is at the LDS write after the MFMAs.  Rows past `nrows` are clamped onto valid rows:
+    // their products land in accumulator rows/columns that the epilogue never stores.
+    // MC layout needs nrows >= 4 (checked by the caller).
+    __device__ __forceinline__ void load_fast(const float* __restrict__ P, int64_t ld, int row0, int nrows, int k0,
+                                              bool rows_full, int tid) {
 #pragma unroll
         for (int i = 0; i < G::NL; ++i) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (vec) {
-                const int idx = tid + i * NTHREADS;
-                if (G::NL * NTHREADS == G::F4 || idx < G::F4) {
-                    if (LAY == GD_LAY_KC) {
-                        const int r = idx / (BK / 4), kk = (idx % (BK / 4)) * 4;
-                        const int gr = row0 + r, gk = k0 + kk;
-                        if (gr < nrows && gk < kend) {
-                            const float* p = P + (int64_t)gr * ld + gk;
-                            if (gk + 3 < kend) {
-                                v = *reinterpret_cast<const f32x4*>(p);
-                            } else {
-                                v.x = p[0];
-                                if (gk + 1 < kend) v.y = p[1];
-                                if (gk + 2 < kend) v.z = p[2];
-                            }
-                        }
-                    } else {
-                        const int kk = idx / (R / 4), r = (idx % (R / 4)) * 4;
-                        const int gk = k0 + kk, gr = row0 + r;
-                        if (gk < kend && gr < nrows) {
-                            const float* p = P + (int64_t)gk * ld + gr;
-                            if (gr + 3 < nrows) {
-                                v = *reinterpret_cast<const f32x4*>(p);
-                            } else {
-                                v.x = p[0];
-                                if (gr + 1 < nrows) v.y = p[1];
-                                if (gr + 2 < nrows) v.z = p[2];
-                            }
-                        }
-                    }
-                }
+            int idx = tid + i * NTHREADS;
+            if (G::NL * NTHREADS != G::F4) idx = min(idx, G::F4 - 1);
+            if (LAY == GD_LAY_KC) {
+                const int r = idx / (BK / 4), kk = (idx % (BK / 4)) * 4;
+                const int gr = min(row0 + r, nrows - 1);
+                reg[i] = *reinterpret_cast<const f32x4_u*>(P + (int64_t)gr * ld + (k0 + kk));
             } else {
-                // rows not 16-byte aligned (e.g. nn.Linear weight with an odd in_features):
-                // consecutive lanes read consecutive floats, 4 independent dword loads per slot.
+                const int kk = idx / (R / 4), r = (idx % (R / 4)) * 4;
+                const int gr = row0 + r;
+                const int gc = min(gr, nrows - 4);
+                f32x4 v = *reinterpret_cast<const f32x4_u*>(P + (int64_t)(k0 + kk) * ld + gc);
+                if (!rows_full) {  // wave-uniform; a vector straddling the last column is shifted in registers
+                    const int sh = gr - gc;
+                    v.x = sh == 0 ? v.x : (sh == 1 ? v.y : (sh == 2 ? v.z : v.w));
+                    v.y = sh == 0 ? v.y : (sh == 1 ? v.z : v.w);
+                    v.z = sh == 0 ? v.z : v.w;
+                }
+                reg[i] = v;
+            }
+        }
+    }
+
+    // Partial K tile (or tiny matrices): element-wise predicated, zero filled.
+    __device__ __forceinline__ void load_slow(const float* __restrict__ P, int64_t ld, int row0, int nrows, int k0,
+                                              int kend, int tid) {
+#pragma unroll
+        for (int i = 0; i < G::NL; ++i) {
+            const int idx = tid + i * NTHREADS;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (G::NL * NTHREADS == G::F4 || idx < G::F4) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int idx = tid + (i * 4 + j) * NTHREADS;
-                    float x = 0.f;
-                    if (G::NL * NTHREADS == G::F4 || idx < G::F4 * 4) {
-                        int r, kk;
-                        if (LAY == GD_LAY_KC) {
-                            r = idx / BK;
-                            kk = idx % BK;
-                        } else {
-                            kk = idx / R;
-                            r = idx % R;
-                        }
-                        const int gr = row0 + r, gk = k0 + kk;
-                        if (gr < nrows && gk < kend)
-                            x = (LAY == GD_LAY_KC) ? P[(int64_t)gr * ld + gk] : P[(int64_t)gk * ld + gr];
+                    int gr, gk;
+                    if (LAY == GD_LAY_KC) {
+                        gr = row0 + idx / (BK / 4);
+                        gk = k0 + (idx % (BK / 4)) * 4 + j;
+                    } else {
+                        gk = k0 + idx / (R / 4);
+                        gr = row0 + (idx % (R / 4)) * 4 + j;
                     }
-                    v[j] = x;
+                    if (gr < nrows && gk < kend)
+                        v[j] = (LAY == GD_LAY_KC) ? P[(int64_t)gr * ld + gk] : P[(int64_t)gk * ld + gr];
                 }
             }
             reg[i] = v;
         }
     }
 
-    __device__ __forceinline__ void store(float* __restrict__ lds, int vec, int tid) const {
+    __device__ __forceinline__ void load(const float* __restrict__ P, int64_t ld, int row0, int nrows, int k0,
+                                         int kend, bool rows_full, int tid) {
+        const bool fast = (k0 + BK <= kend) && (LAY == GD_LAY_KC || nrows >= 4);
+        if (fast)
+            load_fast(P, ld, row0, nrows, k0, rows_full, tid);
+        else
+            load_slow(P, ld, row0, nrows, k0, kend, tid);
+    }
+
+    __device__ __forceinline__ void store(float* __restrict__ lds, int tid) const {
 #pragma unroll
         for (int i = 0; i < G::NL; ++i) {
-            if (vec) {
-                const int idx = tid + i * NTHREADS;
-                if (G::NL * NTHREADS == G::F4 || idx < G::F4) {
-                    if (LAY == GD_LAY_KC) {
-                        const int r = idx / (BK / 4), kk = (idx % (BK / 4)) * 4;
-                        *reinterpret_cast<f32x4*>(&lds[r * G::LD + kk]) = reg[i];
-                    } else {
-                        const int kk = idx / (R / 4), r = (idx % (R / 4)) * 4;
-                        *reinterpret_cast<f32x4*>(&lds[kk * G::LD + r]) = reg[i];
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int idx = tid + (i * 4 + j) * NTHREADS;
-                    if (G::NL * NTHREADS == G::F4 || idx < G::F4 * 4) {
-                        if (LAY == GD_LAY_KC)
-                            lds[(idx / BK) * G::LD + (idx % BK)] = reg[i][j];
-                        else
-                            lds[(idx / R) * G::LD + (idx % R)] = reg[i][j];
-                    }
+            const int idx = tid + i * NTHREADS;
+            if (G::NL * NTHREADS == G::F4 || idx < G::F4) {
+                if (LAY == GD_LAY_KC) {
+                    const int r = idx / (BK / 4), kk = (idx % (BK / 4)) * 4;
+                    *reinterpret_cast<f32x4*>(&lds[r * G::LD + kk]) = reg[i];
+                } else {
+                    const int kk = idx / (R / 4), r = (idx % (R / 4)) * 4;
+                    *reinterpret_cast<f32x4*>(&lds[kk * G::LD + r]) = reg[i];
                 }
             }
         }
@@ -192,11 +186,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GdGemm g) {
     TileStage<LAYA, BM, BK> sa;
     TileStage<LAYB, BN, BK> sb;
 
+    const bool a_full = (m0 + BM <= g.M), b_full = (n0 + BN <= g.N);
     if (nt > 0) {
-        sa.load(g.A, g.lda, m0, g.M, kbeg, kend, g.veca, tid);
-        sb.load(g.B, g.ldb, n0, g.N, kbeg, kend, g.vecb, tid);
-        sa.store(smem, g.veca, tid);
-        sb.store(smem + GA::FLOATS, g.vecb, tid);
+        sa.load(g.A, g.lda, m0, g.M, kbeg, kend, a_full, tid);
+        sb.load(g.B, g.ldb, n0, g.N, kbeg, kend, b_full, tid);
+        sa.store(smem, tid);
+        sb.store(smem + GA::FLOATS, tid);
     }
     __syncthreads();
 
@@ -206,8 +201,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GdGemm g) {
         const bool more = (it + 1 < nt);
         if (more) {
             const int k0 = kbeg + (it + 1) * BK;
-            sa.load(g.A, g.lda, m0, g.M, k0, kend, g.veca, tid);
-            sb.load(g.B, g.ldb, n0, g.N, k0, kend, g.vecb, tid);
+            sa.load(g.A, g.lda, m0, g.M, k0, kend, a_full, tid);
+            sb.load(g.B, g.ldb, n0, g.N, k0, kend, b_full, tid);
         }
 #pragma unroll
         for (int c = 0; c < BK / 16; ++c) {
@@ -224,8 +219,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GdGemm g) {
         }
         if (more) {
             float* An = smem + ((it + 1) & 1) * STAGE_FLOATS;
-            sa.store(An, g.veca, tid);
-            sb.store(An + GA::FLOATS, g.vecb, tid);
+            sa.store(An, tid);
+            sb.store(An + GA::FLOATS, tid);
         }
         __syncthreads();
     }

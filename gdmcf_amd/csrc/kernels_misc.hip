@@ -263,49 +263,77 @@ __global__ __launch_bounds__(256) void emb_bwd_demb_kernel(const float* __restri
     }
 }
 
-// dWe[e,f] = sum_m demb[m,e]*temb[m,f];  dbe[e] = sum_m demb[m,e]
-__global__ void emb_bwd_w_kernel(const float* __restrict__ demb, const float* __restrict__ temb, int M, int E,
-                                 float* __restrict__ dWe, float* __restrict__ dbe) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+// dWe[e,f] = sum_m demb[m,e]*temb[m,f];  dbe[e] = sum_m demb[m,e]   (one wave per output element)
+__global__ __launch_bounds__(64) void emb_bwd_w_kernel(const float* __restrict__ demb, const float* __restrict__ temb,
+                                                       int M, int E, float* __restrict__ dWe,
+                                                       float* __restrict__ dbe) {
+    const int idx = blockIdx.x, lane = threadIdx.x;
+    float s = 0.f;
     if (idx < E * E) {
         const int e = idx / E, f = idx % E;
-        float s = 0.f;
-        for (int m = 0; m < M; ++m) s += demb[(int64_t)m * E + e] * temb[(int64_t)m * E + f];
-        dWe[idx] = s;
-    } else if (idx < E * E + E) {
+        for (int m = lane; m < M; m += 64) s += demb[(int64_t)m * E + e] * temb[(int64_t)m * E + f];
+    } else {
         const int e = idx - E * E;
-        float s = 0.f;
-        for (int m = 0; m < M; ++m) s += demb[(int64_t)m * E + e];
-        dbe[e] = s;
+        for (int m = lane; m < M; m += 64) s += demb[(int64_t)m * E + e];
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) {
+        if (idx < E * E) dWe[idx] = s;
+        else dbe[idx - E * E] = s;
     }
 }
 
-// rowsum[m] = sum_j rowpart[m, j] in fixed order
+// rowsum[m] = sum_j rowpart[m, j]: one wave per row, lane-strided partials + xor tree (fixed order)
 __global__ __launch_bounds__(256) void rowpart_reduce_kernel(const float* __restrict__ rowpart, int ld, int M, int nt,
                                                              float* __restrict__ rowsum) {
-    const int m = blockIdx.x * 256 + threadIdx.x;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (m >= M) return;
     float s = 0.f;
-    for (int j = 0; j < nt; ++j) s += rowpart[(int64_t)m * ld + j];
-    rowsum[m] = s;
+    for (int j = lane; j < nt; j += 64) s += rowpart[(int64_t)m * ld + j];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) rowsum[m] = s;
 }
 
 // ---------------------------------------------------------------------------------------------
 // float64 loss tail + Lt-history FIFO (reference gaussian_diffusion.py:339-370)
 // ---------------------------------------------------------------------------------------------
-__device__ void lt_history_serial(const int64_t* ts, const double* lu, int B, int H, double* hist, int64_t* cnt) {
-    // strictly in batch order: the FIFO is order dependent (reference :355-368)
-    for (int b = 0; b < B; ++b) {
-        const int64_t t = ts[b];
-        double* row = hist + t * H;
-        if (cnt[t] == H) {
-            for (int j = 0; j + 1 < H; ++j) row[j] = row[j + 1];
-            row[H - 1] = lu[b];
-        } else {
-            row[cnt[t]] = lu[b];
-            cnt[t] += 1;
-        }
+// The reference appends row by row (FIFO of H per timestep, :355-368).  The end state only depends,
+// per timestep t, on the order of the rows with ts == t: it is the last min(H, cnt+n_t) entries of
+// [old entries..., new entries in batch order].  So every row computes its rank among the earlier
+// rows with the same t (independent, pipelined LDS reads -- no serial dependency chain) and writes
+// straight to its final slot.  Needs T*H doubles + B ints of LDS.
+__device__ void lt_history_parallel(const int64_t* __restrict__ ts, const double* __restrict__ lu, int B, int T, int H,
+                                    double* hist, int64_t* cnt, unsigned char* lds_raw) {
+    double* old = reinterpret_cast<double*>(lds_raw);           // [T*H]
+    int* n_t = reinterpret_cast<int*>(old + (size_t)T * H);     // [T]
+    int* c0 = n_t + T;                                          // [T]
+    int* tsl = c0 + T;                                          // [B]
+    const int tid = threadIdx.x, nth = blockDim.x;
+    for (int i = tid; i < T * H; i += nth) old[i] = hist[i];
+    for (int t = tid; t < T; t += nth) {
+        n_t[t] = 0;
+        c0[t] = (int)cnt[t];
     }
+    for (int b = tid; b < B; b += nth) tsl[b] = (int)ts[b];
+    __syncthreads();
+    for (int b = tid; b < B; b += nth) atomicAdd(&n_t[tsl[b]], 1);
+    __syncthreads();
+    // old entries slide left by `drop`
+    for (int i = tid; i < T * H; i += nth) {
+        const int t = i / H, j = i % H;
+        const int drop = max(0, c0[t] + n_t[t] - H);
+        if (j < c0[t] && j - drop >= 0) hist[(int64_t)t * H + (j - drop)] = old[i];
+    }
+    // new entries
+    for (int b = tid; b < B; b += nth) {
+        const int t = tsl[b];
+        int rank = 0;
+        for (int p = 0; p < b; ++p) rank += (tsl[p] == t);
+        const int drop = max(0, c0[t] + n_t[t] - H);
+        const int pos = c0[t] + rank - drop;
+        if (pos >= 0) hist[(int64_t)t * H + pos] = lu[b];
+    }
+    for (int t = tid; t < T; t += nth) cnt[t] = (int64_t)min(H, c0[t] + n_t[t]);
 }
 
 __global__ __launch_bounds__(256) void row_loss_finish_kernel(const float* __restrict__ rowsum,
@@ -314,24 +342,104 @@ __global__ __launch_bounds__(256) void row_loss_finish_kernel(const float* __res
                                                               float* __restrict__ gradcoef,
                                                               const int64_t* __restrict__ ts,
                                                               const double* __restrict__ weight_t,
-                                                              const double* __restrict__ pt, int B, int H,
+                                                              const double* __restrict__ pt, int B, int T, int H,
                                                               double* hist, int64_t* cnt, int update,
                                                               double* __restrict__ lu, double* __restrict__ loss) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fin_lds[];
     for (int b = threadIdx.x; b < B; b += 256) {
         const float mse = rowsum[b] / rowdiv[b];  // f32 mean, as mean_flat on f32 (:335)
-        lu[b] = weight_t[ts[b]] * (double)mse;    // f64 weight * f32 mse -> f64 (:352)
+        const double l = weight_t[ts[b]] * (double)mse;  // f64 weight * f32 mse -> f64 (:352)
+        lu[b] = l;
+        loss[b] = l / pt[b];  // (:370)
         if (gradcoef)
             gradcoef[b] = (float)(2.0 * (alpha ? (double)alpha[b] : 1.0) * weight_t[ts[b]] /
                                   (pt[b] * (double)rowdiv[b]));
     }
     __syncthreads();
-    if (update && threadIdx.x == 0) lt_history_serial(ts, lu, B, H, hist, cnt);
-    for (int b = threadIdx.x; b < B; b += 256) loss[b] = lu[b] / pt[b];  // (:370)
+    if (update) lt_history_parallel(ts, lu, B, T, H, hist, cnt, fin_lds);
 }
 
-__global__ void lt_history_update_kernel(const int64_t* ts, const double* lu, int B, int H, double* hist,
-                                         int64_t* cnt) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) lt_history_serial(ts, lu, B, H, hist, cnt);
+__global__ __launch_bounds__(256) void lt_history_update_kernel(const int64_t* ts, const double* lu, int B, int T,
+                                                                int H, double* hist, int64_t* cnt) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fin_lds[];
+    lt_history_parallel(ts, lu, B, T, H, hist, cnt, fin_lds);
+}
+
+// ---------------------------------------------------------------------------------------------
+// importance-sampled timesteps (reference gaussian_diffusion.py:373-397) in ONE launch, no host sync:
+// uniform until every Lt_count == H, then p_t ~ sqrt(mean(Lt_history^2)) mixed with uniform_prob,
+// inverse-CDF sampling with a Philox stream; pt = p[t]*T (float64), or 1 in the uniform phase.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sample_timesteps_kernel(const double* __restrict__ hist,
+                                                               const int64_t* __restrict__ cnt, int T, int H, int B,
+                                                               double uniform_prob, uint64_t seed, uint64_t offset,
+                                                               int64_t* __restrict__ ts, double* __restrict__ pt,
+                                                               double* __restrict__ p_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char st_lds[];
+    double* p = reinterpret_cast<double*>(st_lds);  // [T] probabilities, then inclusive CDF in cdf[]
+    double* cdf = p + T;
+    __shared__ int full;
+    __shared__ double total;
+    const int tid = threadIdx.x;
+    if (tid == 0) full = 1;
+    __syncthreads();
+    for (int t = tid; t < T; t += 256)
+        if (cnt[t] != H) full = 0;
+    __syncthreads();
+    const bool imp = (full != 0);
+    if (imp) {
+        for (int t = tid; t < T; t += 256) {
+            double s = 0.0;
+            for (int j = 0; j < H; ++j) {
+                const double v = hist[(int64_t)t * H + j];
+                s += v * v;
+            }
+            p[t] = sqrt(s / (double)H);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double s = 0.0;
+            for (int t = 0; t < T; ++t) s += p[t];
+            total = s;
+        }
+        __syncthreads();
+        for (int t = tid; t < T; t += 256) {
+            double v = p[t] / total;
+            v *= 1.0 - uniform_prob;
+            v += uniform_prob / (double)T;
+            p[t] = v;
+            if (p_out) p_out[t] = v;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double s = 0.0;
+            for (int t = 0; t < T; ++t) {
+                s += p[t];
+                cdf[t] = s;
+            }
+        }
+        __syncthreads();
+    }
+    for (int b = tid; b < B; b += 256) {
+        const uint4 r = philox4x32_10(make_uint4((uint32_t)b, 0u, 2u, (uint32_t)offset),
+                                      make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+        const double u = ((double)r.x * 4294967296.0 + (double)r.y) * (1.0 / 18446744073709551616.0);  // [0,1)
+        int t;
+        if (imp) {
+            const double x = u * cdf[T - 1];
+            int lo = 0, hi = T - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (cdf[mid] > x) hi = mid; else lo = mid + 1;
+            }
+            t = lo;
+            pt[b] = p[t] * (double)T;
+        } else {
+            t = min((int)(u * (double)T), T - 1);
+            pt[b] = 1.0;
+        }
+        ts[b] = t;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -474,7 +582,7 @@ int gdmcf_emb_bwd_f32(const float* dZ1, int64_t lddz, const float* W1, int64_t l
     GD_CHECK_SHAPE(M > 0 && N > 0 && E > 0 && ldw >= I + E && lddz >= N, "emb_bwd: bad shape");
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(emb_bwd_demb_kernel, dim3(M), dim3(256), 0, s, dZ1, lddz, W1, ldw, I, E, N, demb_ws);
-    hipLaunchKernelGGL(emb_bwd_w_kernel, dim3(gd_cdiv(E * E + E, 128)), dim3(128), 0, s, demb_ws, temb, M, E, dWe, dbe);
+    hipLaunchKernelGGL(emb_bwd_w_kernel, dim3(E * E + E), dim3(64), 0, s, demb_ws, temb, M, E, dWe, dbe);
     return gd_launch_status("emb_bwd");
 }
 
@@ -483,17 +591,31 @@ int gdmcf_row_loss_finish_f64(const float* rowsum, const float* rowdiv, const fl
                               int64_t* Lt_count, int update_history, double* loss_unscaled, double* loss,
                               float* gradcoef, void* stream) {
     GD_CHECK_SHAPE(B > 0 && T > 0 && H > 0, "row_loss_finish: bad shape");
-    hipLaunchKernelGGL(row_loss_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, rowsum, rowdiv, alpha,
-                       gradcoef, ts, weight_t, pt, B, H, Lt_history, Lt_count, update_history, loss_unscaled, loss);
+    const size_t lds = (size_t)T * H * 8 + (size_t)T * 8 + (size_t)B * 4 + 16;
+    GD_CHECK_ARG(lds <= 64 * 1024, "row_loss_finish: T*H and B too large for the LDS-resident FIFO update");
+    hipLaunchKernelGGL(row_loss_finish_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, rowsum, rowdiv, alpha,
+                       gradcoef, ts, weight_t, pt, B, T, H, Lt_history, Lt_count, update_history, loss_unscaled, loss);
     return gd_launch_status("row_loss_finish");
 }
 
 int gdmcf_lt_history_update(const int64_t* ts, const double* loss_unscaled, int B, int T, int H, double* Lt_history,
                             int64_t* Lt_count, void* stream) {
     GD_CHECK_SHAPE(B > 0 && T > 0 && H > 0, "lt_history_update: bad shape");
-    hipLaunchKernelGGL(lt_history_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ts, loss_unscaled, B, H,
-                       Lt_history, Lt_count);
+    const size_t lds = (size_t)T * H * 8 + (size_t)T * 8 + (size_t)B * 4 + 16;
+    GD_CHECK_ARG(lds <= 64 * 1024, "lt_history_update: T*H and B too large for the LDS-resident FIFO update");
+    hipLaunchKernelGGL(lt_history_update_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, ts, loss_unscaled, B, T,
+                       H, Lt_history, Lt_count);
     return gd_launch_status("lt_history_update");
+}
+
+int gdmcf_sample_timesteps(const double* Lt_history, const int64_t* Lt_count, int T, int H, int B,
+                           double uniform_prob, uint64_t seed, uint64_t offset, int64_t* ts, double* pt, double* p_out,
+                           void* stream) {
+    GD_CHECK_SHAPE(B > 0 && T > 0 && H > 0, "sample_timesteps: bad shape");
+    GD_CHECK_ARG(T <= 4096, "sample_timesteps: T > 4096 unsupported");
+    hipLaunchKernelGGL(sample_timesteps_kernel, dim3(1), dim3(256), (size_t)T * 16, (hipStream_t)stream, Lt_history,
+                       Lt_count, T, H, B, uniform_prob, seed, offset, ts, pt, p_out);
+    return gd_launch_status("sample_timesteps");
 }
 
 int gdmcf_adamw_f32(const int64_t* table, int n_tensors, int total_blocks, float lr, float beta1, float beta2,
@@ -543,6 +665,6 @@ int gd_colsum(const float* dZ, int64_t ld, const float* rs, int M, int N, float*
 }
 
 int gd_rowpart_reduce(const float* rowpart, int ld, int M, int nt, float* rowsum, hipStream_t s) {
-    hipLaunchKernelGGL(rowpart_reduce_kernel, dim3(gd_cdiv(M, 256)), dim3(256), 0, s, rowpart, ld, M, nt, rowsum);
+    hipLaunchKernelGGL(rowpart_reduce_kernel, dim3(gd_cdiv(M, 4)), dim3(256), 0, s, rowpart, ld, M, nt, rowsum);
     return gd_launch_status("rowpart_reduce");
 }

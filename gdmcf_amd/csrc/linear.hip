@@ -25,8 +25,6 @@ int pick_splits(int M, int N, int K, int cls, int bk) {
 
 inline int64_t round4(int64_t x) { return (x + 3) & ~(int64_t)3; }
 
-inline int vec_ok(const float* p, int64_t ld) { return gd_aligned16(p) && (ld % 4) == 0; }
-
 }  // namespace
 
 extern "C" {
@@ -51,7 +49,6 @@ int gdmcf_linear_fwd_f32(const float* A, int64_t lda, const float* W, int64_t ld
     const int splits = pick_splits(M, N, K, cls, 32);
     GdGemm g = {};
     g.A = A; g.lda = lda; g.B = W; g.ldb = ldw; g.M = M; g.N = N; g.K = K;
-    g.veca = vec_ok(A, lda); g.vecb = vec_ok(W, ldw);
     g.m_fastest = gd_cdiv(M, gd_gemm_tile_m(cls)) <= gd_cdiv(N, gd_gemm_tile_n(cls));
     g.bias = bias; g.act = act; g.prof_tag = 1;
     if (splits == 1) {
@@ -81,7 +78,6 @@ int gdmcf_linear_loss_fwd_f32(const float* A, int64_t lda, const float* W, int64
     const int cls = gd_pick_shape_class(M, N);
     GdGemm g = {};
     g.A = A; g.lda = lda; g.B = W; g.ldb = ldw; g.M = M; g.N = N; g.K = K; g.splits = 1;
-    g.veca = vec_ok(A, lda); g.vecb = vec_ok(W, ldw);
     g.m_fastest = gd_cdiv(M, gd_gemm_tile_m(cls)) <= gd_cdiv(N, gd_gemm_tile_n(cls));
     g.bias = bias; g.aux = target; g.ldaux = ldt; g.r0 = alpha; g.out2 = out; g.ldout2 = ldo;
     g.prof_tag = 2;
@@ -103,7 +99,6 @@ int gdmcf_linear_posterior_fwd_f32(const float* A, int64_t lda, const float* W, 
     const int cls = gd_pick_shape_class(M, N);
     GdGemm g = {};
     g.A = A; g.lda = lda; g.B = W; g.ldb = ldw; g.M = M; g.N = N; g.K = K; g.splits = 1;
-    g.veca = vec_ok(A, lda); g.vecb = vec_ok(W, ldw);
     g.m_fastest = gd_cdiv(M, gd_gemm_tile_m(cls)) <= gd_cdiv(N, gd_gemm_tile_n(cls));
     g.bias = bias; g.aux = x_t; g.ldaux = ldxt; g.aux2 = z; g.ldaux2 = ldz;
     g.r0 = c1; g.r1 = c2; g.r2 = r1; g.r3 = r2; g.r4 = sigma;
@@ -128,7 +123,6 @@ int gdmcf_linear_bwd_input_f32(const float* dZ, int64_t lddz, const float* W, in
     }
     GdGemm g = {};
     g.A = dZ; g.lda = lddz; g.B = W; g.ldb = ldw; g.M = M; g.N = K; g.K = N;
-    g.veca = vec_ok(dZ, lddz); g.vecb = vec_ok(W, ldw);
     g.m_fastest = gd_cdiv(M, gd_gemm_tile_m(cls)) <= gd_cdiv(K, gd_gemm_tile_n(cls));
     g.splits = splits; g.C = (float*)ws; g.ldc = lds_; g.slab_stride = (int64_t)M * lds_; g.prof_tag = 4;
     int rc = gd_gemm_launch(GD_LAY_KC, GD_LAY_MC, GD_EPI_SLAB, cls, g, s);
@@ -147,7 +141,6 @@ int gdmcf_linear_bwd_weight_f32(const float* dZ, int64_t lddz, const float* A, i
     const int cls = gd_pick_shape_class(N, K);
     GdGemm g = {};
     g.A = dZ; g.lda = lddz; g.B = A; g.ldb = lda; g.M = N; g.N = K; g.K = M; g.splits = 1;
-    g.veca = vec_ok(dZ, lddz); g.vecb = vec_ok(A, lda);
     g.m_fastest = gd_cdiv(N, gd_gemm_tile_m(cls)) <= gd_cdiv(K, gd_gemm_tile_n(cls));
     g.C = dW; g.ldc = lddw; g.accumulate = accumulate; g.prof_tag = 5;
     int rc = gd_gemm_launch(GD_LAY_MC, GD_LAY_MC, GD_EPI_STORE, cls, g, s);

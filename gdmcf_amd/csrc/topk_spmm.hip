@@ -150,39 +150,56 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ pre
 }
 
 // ---------------------------------------------------------------------------------------------
-// CSR SpMM, one wave per row.  LPR lanes cover one embedding row with 16-byte loads, so a wave
-// gathers 64/LPR neighbours per instruction (d = 64 -> 4 x 256 B rows = 1 KiB per wave-instruction).
-// The running layer sum (LightGCN layer mean) is fused as `acc += Y`.
+// CSR SpMM  Y = (A X + sum_k addend_k) * scale,  one wave per VIRTUAL row.
+// Degree skew is the problem (a hub item has 1e4+ neighbours, the median row ~20): the host splits
+// every row into virtual rows of <= chunk nonzeros (plan arrays below), so hub rows spread over many
+// waves; a row that was split writes float partials that a second tiny kernel adds in slot order
+// (deterministic, no atomics).  LPR lanes cover one embedding row with 16-byte loads, so a wave
+// gathers 64/LPR neighbour rows per instruction (d = 64: 4 x 256 B) and keeps 4 such instructions
+// in flight.  The LightGCN layer mean is fused through `addends`/`scale` in the last layer.
 // ---------------------------------------------------------------------------------------------
+constexpr int SPMM_MAX_ADD = 8;
+struct SpmmAdd {
+    const float* p[SPMM_MAX_ADD];
+    int n;
+    int64_t ld;
+    float scale;
+};
+
 template <int LPR>
-__global__ __launch_bounds__(256) void spmm_vec_kernel(const int64_t* __restrict__ rowptr,
+__global__ __launch_bounds__(256) void spmm_vec_kernel(const int64_t* __restrict__ vptr,
+                                                       const int32_t* __restrict__ vrow,
+                                                       const int32_t* __restrict__ vslot, int n_virtual,
                                                        const int32_t* __restrict__ col,
-                                                       const float* __restrict__ val, int n_rows,
-                                                       const float* __restrict__ X, int64_t ldx,
-                                                       float* __restrict__ Y, int64_t ldy, float* __restrict__ acc,
-                                                       int64_t ldacc) {
+                                                       const float* __restrict__ val, const float* __restrict__ X,
+                                                       int64_t ldx, float* __restrict__ Y, int64_t ldy,
+                                                       float* __restrict__ partial, int d, const SpmmAdd add) {
     constexpr int NPAR = 64 / LPR;
     const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= n_rows) return;
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= n_virtual) return;
     const int sub = lane / LPR, cl = lane % LPR;
-    const int64_t beg = rowptr[r], end = rowptr[r + 1];
-    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+    const int64_t beg = vptr[v], end = vptr[v + 1];
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
     int64_t j = beg + sub;
-    for (; j + NPAR < end; j += 2 * NPAR) {
-        const int c0 = col[j], c1 = col[j + NPAR];
-        const float w0 = val[j], w1 = val[j + NPAR];
+    for (; j + 3 * NPAR < end; j += 4 * NPAR) {
+        const int c0 = col[j], c1 = col[j + NPAR], c2 = col[j + 2 * NPAR], c3 = col[j + 3 * NPAR];
+        const float w0 = val[j], w1 = val[j + NPAR], w2 = val[j + 2 * NPAR], w3 = val[j + 3 * NPAR];
         const f32x4 x0 = *reinterpret_cast<const f32x4*>(X + (int64_t)c0 * ldx + cl * 4);
         const f32x4 x1 = *reinterpret_cast<const f32x4*>(X + (int64_t)c1 * ldx + cl * 4);
+        const f32x4 x2 = *reinterpret_cast<const f32x4*>(X + (int64_t)c2 * ldx + cl * 4);
+        const f32x4 x3 = *reinterpret_cast<const f32x4*>(X + (int64_t)c3 * ldx + cl * 4);
         s0 += w0 * x0;
         s1 += w1 * x1;
+        s2 += w2 * x2;
+        s3 += w3 * x3;
     }
-    if (j < end) {
+    for (; j < end; j += NPAR) {
         const int c0 = col[j];
         const float w0 = val[j];
         s0 += w0 * *reinterpret_cast<const f32x4*>(X + (int64_t)c0 * ldx + cl * 4);
     }
-    f32x4 s = s0 + s1;
+    f32x4 s = (s0 + s1) + (s2 + s3);
 #pragma unroll
     for (int o = LPR; o < 64; o <<= 1) {
         s.x += __shfl_xor(s.x, o);
@@ -191,30 +208,56 @@ __global__ __launch_bounds__(256) void spmm_vec_kernel(const int64_t* __restrict
         s.w += __shfl_xor(s.w, o);
     }
     if (sub == 0) {
-        *reinterpret_cast<f32x4*>(Y + (int64_t)r * ldy + cl * 4) = s;
-        if (acc) {
-            f32x4* a = reinterpret_cast<f32x4*>(acc + (int64_t)r * ldacc + cl * 4);
-            *a = *a + s;
+        const int slot = vslot[v];
+        if (slot >= 0) {
+            *reinterpret_cast<f32x4*>(partial + (int64_t)slot * d + cl * 4) = s;
+        } else {
+            const int r = vrow[v];
+            for (int k = 0; k < add.n; ++k) s += *reinterpret_cast<const f32x4*>(add.p[k] + (int64_t)r * add.ld + cl * 4);
+            *reinterpret_cast<f32x4*>(Y + (int64_t)r * ldy + cl * 4) = s * add.scale;
         }
     }
 }
 
-// generic fallback: any d, one neighbour at a time, lane strides over columns
-__global__ __launch_bounds__(256) void spmm_generic_kernel(const int64_t* __restrict__ rowptr,
+// generic fallback (any d): one neighbour at a time, lanes stride over columns
+__global__ __launch_bounds__(256) void spmm_generic_kernel(const int64_t* __restrict__ vptr,
+                                                           const int32_t* __restrict__ vrow,
+                                                           const int32_t* __restrict__ vslot, int n_virtual,
                                                            const int32_t* __restrict__ col,
-                                                           const float* __restrict__ val, int n_rows,
-                                                           const float* __restrict__ X, int64_t ldx, int d,
-                                                           float* __restrict__ Y, int64_t ldy,
-                                                           float* __restrict__ acc, int64_t ldacc) {
+                                                           const float* __restrict__ val, const float* __restrict__ X,
+                                                           int64_t ldx, float* __restrict__ Y, int64_t ldy,
+                                                           float* __restrict__ partial, int d, const SpmmAdd add) {
     const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= n_rows) return;
-    const int64_t beg = rowptr[r], end = rowptr[r + 1];
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= n_virtual) return;
+    const int64_t beg = vptr[v], end = vptr[v + 1];
+    const int slot = vslot[v], r = vrow[v];
     for (int c0 = lane; c0 < d; c0 += 64) {
         float s = 0.f;
         for (int64_t j = beg; j < end; ++j) s += val[j] * X[(int64_t)col[j] * ldx + c0];
-        Y[(int64_t)r * ldy + c0] = s;
-        if (acc) acc[(int64_t)r * ldacc + c0] += s;
+        if (slot >= 0) {
+            partial[(int64_t)slot * d + c0] = s;
+        } else {
+            for (int k = 0; k < add.n; ++k) s += add.p[k][(int64_t)r * add.ld + c0];
+            Y[(int64_t)r * ldy + c0] = s * add.scale;
+        }
+    }
+}
+
+// rows that were split: Y[r] = (sum of their partial slots, in order, + addends) * scale
+__global__ __launch_bounds__(256) void spmm_combine_kernel(const int32_t* __restrict__ lrow,
+                                                           const int32_t* __restrict__ lptr, int n_long,
+                                                           const float* __restrict__ partial, int d,
+                                                           float* __restrict__ Y, int64_t ldy, const SpmmAdd add) {
+    const int lane = threadIdx.x & 63;
+    const int l = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (l >= n_long) return;
+    const int r = lrow[l];
+    for (int c0 = lane; c0 < d; c0 += 64) {
+        float s = 0.f;
+        for (int k = lptr[l]; k < lptr[l + 1]; ++k) s += partial[(int64_t)k * d + c0];
+        for (int k = 0; k < add.n; ++k) s += add.p[k][(int64_t)r * add.ld + c0];
+        Y[(int64_t)r * ldy + c0] = s * add.scale;
     }
 }
 
@@ -251,33 +294,41 @@ int gdmcf_topk_masked_f32(const float* pred, int64_t ldp, int B, int I, const in
     return gd_launch_status("topk");
 }
 
-int gdmcf_spmm_csr_f32(const int64_t* rowptr, const int32_t* col, const float* val, int n_rows, const float* X,
-                       int64_t ldx, int d, float* Y, int64_t ldy, float* acc, int64_t ldacc, void* stream) {
-    GD_CHECK_SHAPE(n_rows > 0 && d > 0 && ldx >= d && ldy >= d, "spmm: bad shape");
-    GD_CHECK_SHAPE(acc == nullptr || ldacc >= d, "spmm: ldacc < d");
+int gdmcf_spmm_csr_f32(const int64_t* vptr, const int32_t* vrow, const int32_t* vslot, int n_virtual,
+                       const int32_t* lrow, const int32_t* lptr, int n_long, const int32_t* col, const float* val,
+                       int n_rows, const float* X, int64_t ldx, int d, float* Y, int64_t ldy, float* partial_ws,
+                       const float* const* addends_host, int n_add, int64_t ld_add, float scale, double alg_bytes,
+                       void* stream) {
+    GD_CHECK_SHAPE(n_rows > 0 && n_virtual >= n_rows - 0 * n_rows && d > 0 && ldx >= d && ldy >= d, "spmm: bad shape");
+    GD_CHECK_ARG(n_add >= 0 && n_add <= SPMM_MAX_ADD && (n_add == 0 || (addends_host && ld_add >= d)), "spmm: bad addends");
+    GD_CHECK_ARG(n_long == 0 || (lrow && lptr && partial_ws), "spmm: split rows need lrow/lptr/partial_ws");
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid(gd_cdiv(n_rows, 4)), block(256);
+    SpmmAdd add = {};
+    add.n = n_add; add.ld = ld_add; add.scale = scale;
+    bool add_al = true;
+    for (int k = 0; k < n_add; ++k) {
+        add.p[k] = addends_host[k];
+        add_al = add_al && gd_aligned16(add.p[k]);
+    }
+    const dim3 grid(gd_cdiv(n_virtual, 4)), block(256);
     const bool vec = (d % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && gd_aligned16(X) && gd_aligned16(Y) &&
-                     (acc == nullptr || ((ldacc % 4 == 0) && gd_aligned16(acc)));
+                     (n_add == 0 || ((ld_add % 4 == 0) && add_al)) && (partial_ws == nullptr || gd_aligned16(partial_ws));
     const int lpr = d / 4;
-    // work is filled in by the caller-side nnz (not known here without a sync): report rows*d*8 + pointer bytes;
-    // bench.py adds the nnz*(4+4) term itself.
-    GdProfScope prof(8, (double)n_rows * d * 8.0 + (double)(n_rows + 1) * 8.0, s);
-    if (vec && lpr == 16)
-        hipLaunchKernelGGL(spmm_vec_kernel<16>, grid, block, 0, s, rowptr, col, val, n_rows, X, ldx, Y, ldy, acc, ldacc);
-    else if (vec && lpr == 8)
-        hipLaunchKernelGGL(spmm_vec_kernel<8>, grid, block, 0, s, rowptr, col, val, n_rows, X, ldx, Y, ldy, acc, ldacc);
-    else if (vec && lpr == 32)
-        hipLaunchKernelGGL(spmm_vec_kernel<32>, grid, block, 0, s, rowptr, col, val, n_rows, X, ldx, Y, ldy, acc, ldacc);
-    else if (vec && lpr == 64)
-        hipLaunchKernelGGL(spmm_vec_kernel<64>, grid, block, 0, s, rowptr, col, val, n_rows, X, ldx, Y, ldy, acc, ldacc);
-    else if (vec && lpr == 4)
-        hipLaunchKernelGGL(spmm_vec_kernel<4>, grid, block, 0, s, rowptr, col, val, n_rows, X, ldx, Y, ldy, acc, ldacc);
-    else if (vec && lpr == 2)
-        hipLaunchKernelGGL(spmm_vec_kernel<2>, grid, block, 0, s, rowptr, col, val, n_rows, X, ldx, Y, ldy, acc, ldacc);
-    else
-        hipLaunchKernelGGL(spmm_generic_kernel, grid, block, 0, s, rowptr, col, val, n_rows, X, ldx, d, Y, ldy, acc,
-                           ldacc);
+    {
+        GdProfScope prof(8, alg_bytes, s);
+#define GD_SPMM_LAUNCH(K) hipLaunchKernelGGL(K, grid, block, 0, s, vptr, vrow, vslot, n_virtual, col, val, X, ldx, Y, ldy, partial_ws, d, add)
+        if (vec && lpr == 16) GD_SPMM_LAUNCH(spmm_vec_kernel<16>);
+        else if (vec && lpr == 8) GD_SPMM_LAUNCH(spmm_vec_kernel<8>);
+        else if (vec && lpr == 32) GD_SPMM_LAUNCH(spmm_vec_kernel<32>);
+        else if (vec && lpr == 64) GD_SPMM_LAUNCH(spmm_vec_kernel<64>);
+        else if (vec && lpr == 4) GD_SPMM_LAUNCH(spmm_vec_kernel<4>);
+        else if (vec && lpr == 2) GD_SPMM_LAUNCH(spmm_vec_kernel<2>);
+        else GD_SPMM_LAUNCH(spmm_generic_kernel);
+#undef GD_SPMM_LAUNCH
+        if (n_long > 0)
+            hipLaunchKernelGGL(spmm_combine_kernel, dim3(gd_cdiv(n_long, 4)), block, 0, s, lrow, lptr, n_long, partial_ws,
+                               d, Y, ldy, add);
+    }
     return gd_launch_status("spmm_csr");
 }
 

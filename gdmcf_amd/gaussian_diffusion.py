@@ -65,7 +65,6 @@ class GaussianDiffusion(nn.Module):
         self.history_num_per_term = history_num_per_term
         self.Lt_history = torch.zeros(steps, history_num_per_term, dtype=torch.float64, device=self.device)
         self.Lt_count = torch.zeros(steps, dtype=torch.int64, device=self.device)
-        self._hist_full = False
         self.update_history = True  # data-parallel wrappers switch this off and replay the gathered batch
         self.rng = "philox"  # "philox": in-kernel noise/dropout;  "torch": torch.randn / torch.bernoulli
         if noise_scale != 0.0:
@@ -118,15 +117,19 @@ class GaussianDiffusion(nn.Module):
         return pt_all
 
     def sample_timesteps(self, batch_size, device, method="uniform", uniform_prob=0.001):
+        """(t, pt) as the reference (:373-397).  'importance' runs as ONE HIP kernel that also takes the
+        "history not full yet -> uniform" branch on the device (no host sync, no torch micro-kernels)."""
         if method == "importance":
-            if not self._hist_full:
-                # counts only grow, so once full the (device-syncing) check is never needed again
-                self._hist_full = bool((self.Lt_count == self.history_num_per_term).all())
-            if not self._hist_full:
-                return self.sample_timesteps(batch_size, device, method="uniform")
-            pt_all = self.importance_probs(uniform_prob)
-            t = torch.multinomial(pt_all, num_samples=batch_size, replacement=True)
-            pt = pt_all.gather(dim=0, index=t) * len(pt_all)
+            device = torch.device(device)
+            if device.type != "cuda":
+                raise RuntimeError("gdmcf_amd: sample_timesteps must run on the MI355X; the HIP path has no CPU fallback")
+            t = torch.empty(batch_size, dtype=torch.int64, device=device)
+            pt = torch.empty(batch_size, dtype=torch.float64, device=device)
+            self._ts_calls = getattr(self, "_ts_calls", 0) + 1
+            _lib.check(_lib.load().gdmcf_sample_timesteps(
+                self.Lt_history.data_ptr(), self.Lt_count.data_ptr(), self.steps, self.history_num_per_term,
+                batch_size, float(uniform_prob), int(torch.initial_seed()) & (2 ** 63 - 1), self._ts_calls,
+                t.data_ptr(), pt.data_ptr(), None, _lib.stream_ptr()))
             return t, pt
         elif method == "uniform":
             t = torch.randint(0, self.steps, (batch_size,), device=device).long()

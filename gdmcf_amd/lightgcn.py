@@ -1,17 +1,22 @@
 """LightGCN embedding propagation with the reference's interface (reference lightGCN.py:129-203).
 
 `get_A_tilda` builds the symmetric-normalised bipartite adjacency D^-1/2 A D^-1/2 once on the host
-(float32, as the reference) and keeps it on the GPU as CSR; `propagate_through_layers` runs the
-n_layers SpMMs in the HIP kernel gdmcf_spmm_csr_f32 with the layer mean fused as a running sum.
+(float32, as the reference), keeps it on the GPU as CSR and builds the execution plan that splits hub
+rows into virtual rows; `propagate_through_layers` runs the n_layers SpMMs in the HIP kernel
+gdmcf_spmm_csr_f32 with the layer mean fused into the last layer's epilogue.
 Only the forward propagation is on the hot path; BPR training is a
 "next" row (8f3), so E0 gradients are not produced here.
 """
+import ctypes
+
 import numpy as np
 import scipy.sparse as sp
 import torch
 import torch.nn as nn
 
 from . import _lib
+
+SPMM_CHUNK = 256  # max nonzeros per virtual row
 
 
 def normalized_bipartite_csr(users, items, n_users, n_items):
@@ -30,6 +35,26 @@ def normalized_bipartite_csr(users, items, n_users, n_items):
     rows = np.repeat(np.arange(N), np.diff(A.indptr))
     data = ((d[rows] * A.data).astype(np.float32) * d[A.indices]).astype(np.float32)
     return A.indptr.astype(np.int64), A.indices.astype(np.int32), data
+
+
+def spmm_plan(indptr, chunk=SPMM_CHUNK):
+    """Virtual-row plan for gdmcf_spmm_csr_f32 (see include/gdmcf_hip.h): every row is cut into pieces
+    of <= chunk nonzeros; rows cut into more than one piece get partial slots + an entry in lrow/lptr."""
+    indptr = np.asarray(indptr, dtype=np.int64)
+    deg = np.diff(indptr)
+    pieces = np.maximum(1, -(-deg // chunk)).astype(np.int64)
+    n_virtual = int(pieces.sum())
+    vrow = np.repeat(np.arange(len(deg), dtype=np.int32), pieces)
+    first = np.concatenate([[0], np.cumsum(pieces)[:-1]])
+    k = np.arange(n_virtual, dtype=np.int64) - first[vrow]  # piece index inside its row
+    beg = indptr[vrow] + k * chunk
+    vptr = np.concatenate([beg, indptr[-1:]]).astype(np.int64)
+    is_long = pieces[vrow] > 1
+    vslot = np.full(n_virtual, -1, dtype=np.int32)
+    vslot[is_long] = np.arange(int(is_long.sum()), dtype=np.int32)
+    lrow = np.nonzero(pieces > 1)[0].astype(np.int32)
+    lptr = np.concatenate([[0], np.cumsum(pieces[lrow])]).astype(np.int32)
+    return dict(vptr=vptr, vrow=vrow, vslot=vslot, lrow=lrow, lptr=lptr, n_slots=int(is_long.sum()))
 
 
 class LightGCN(nn.Module):
@@ -53,34 +78,49 @@ class LightGCN(nn.Module):
                                                          np.asarray(self.data["item_id_idx"]), self.n_users,
                                                          self.n_items)
         dev = self._device
+        plan = spmm_plan(indptr)
+        self._plan = {k: (torch.from_numpy(v).to(dev) if isinstance(v, np.ndarray) else v) for k, v in plan.items()}
+        self._partial = torch.empty(max(plan["n_slots"], 1), self.latent_dim, dtype=torch.float32, device=dev)
+        self.nnz = int(indices.size)
         return (torch.from_numpy(indptr).to(dev), torch.from_numpy(indices).to(dev), torch.from_numpy(vals).to(dev))
+
+    def algorithmic_bytes(self):
+        """Compulsory HBM bytes of one layer: CSR once, X once, Y once."""
+        N, d = self.n_users + self.n_items, self.latent_dim
+        return self.nnz * 8.0 + (N + 1) * 8.0 + 2.0 * N * d * 4.0
 
     @torch.no_grad()
     def propagate_through_layers(self, return_layers=False):
         lib = _lib.load()
         E0 = self.E0.weight.detach()
         _lib.require_gpu(E0, "LightGCN.E0")
-        indptr, indices, vals = self.norm_adj_csr
+        _, indices, vals = self.norm_adj_csr
+        pl = self._plan
         N, d = E0.shape
         st = _lib.stream_ptr()
-        acc = E0.clone()
         cur = E0.contiguous()
-        layers = []
-        bufs = [torch.empty_like(acc), torch.empty_like(acc)]
+        layers = [cur]
+        nv, nl = pl["vrow"].numel(), pl["lrow"].numel()
         for layer in range(self.n_layers):
-            nxt = bufs[layer & 1]
-            _lib.check(lib.gdmcf_spmm_csr_f32(indptr.data_ptr(), indices.data_ptr(), vals.data_ptr(), N, cur.data_ptr(),
-                                              cur.stride(0), d, nxt.data_ptr(), nxt.stride(0), acc.data_ptr(),
-                                              acc.stride(0), st))
-            if return_layers:
-                layers.append(nxt.clone())
-            cur = nxt
-        mean = torch.empty_like(acc)
-        _lib.check(lib.gdmcf_scale_f32(acc.data_ptr(), acc.numel(), 1.0 / (self.n_layers + 1), mean.data_ptr(), st))
+            last = (layer == self.n_layers - 1) and not return_layers
+            out = torch.empty_like(cur)
+            adds = layers if last else []
+            arr = (ctypes.c_void_p * max(len(adds), 1))(*[a.data_ptr() for a in adds])
+            _lib.check(lib.gdmcf_spmm_csr_f32(
+                pl["vptr"].data_ptr(), pl["vrow"].data_ptr(), pl["vslot"].data_ptr(), nv, _lib.ptr(pl["lrow"]) if nl else None,
+                _lib.ptr(pl["lptr"]) if nl else None, nl, indices.data_ptr(), vals.data_ptr(), N, cur.data_ptr(),
+                cur.stride(0), d, out.data_ptr(), out.stride(0), self._partial.data_ptr(), arr, len(adds),
+                cur.stride(0), 1.0 / (self.n_layers + 1) if last else 1.0, self.algorithmic_bytes(), st))
+            layers.append(out)
+            cur = out
+        if return_layers:
+            mean = torch.stack(layers).sum(0) / (self.n_layers + 1)  # test/debug path only
+        else:
+            mean = cur if self.n_layers > 0 else E0
         final_user, final_item = torch.split(mean, [self.n_users, self.n_items])
         init_user, init_item = torch.split(E0, [self.n_users, self.n_items])
         if return_layers:
-            return final_user, final_item, init_user, init_item, layers
+            return final_user, final_item, init_user, init_item, layers[1:]
         return final_user, final_item, init_user, init_item
 
     def forward(self, users, pos_items, neg_items):

@@ -158,6 +158,16 @@ int gdmcf_row_loss_finish_f64(const float* rowsum, const float* rowdiv, const fl
 int gdmcf_lt_history_update(const int64_t* ts, const double* loss_unscaled, int B, int T, int H,
                             double* Lt_history, int64_t* Lt_count, void* stream);
 
+/* ---- importance-sampled timesteps (gaussian_diffusion.py:373-397), one launch, no host sync ----
+ * Until every Lt_count == H: t ~ uniform{0..T-1}, pt = 1.  Afterwards p = sqrt(mean(Lt_history^2))
+ * normalised, mixed as p*(1-uniform_prob) + uniform_prob/T; t by inverse CDF, pt = p[t]*T.
+ * Random numbers: Philox4x32-10 (counter (b,0,2,offset), key seed) -- the reference's torch.randint /
+ * torch.multinomial streams cannot be reproduced on the device, parity tests inject ts instead.
+ * p_out (optional, float64 [T]) receives the probability vector when the importance branch is live. */
+int gdmcf_sample_timesteps(const double* Lt_history, const int64_t* Lt_count, int T, int H, int B,
+                           double uniform_prob, uint64_t seed, uint64_t offset, int64_t* ts,
+                           double* pt, double* p_out, void* stream);
+
 /* ---- fused multi-tensor AdamW (torch.optim.AdamW as used at main.py:258,351) -------------
  * table: device int64 [n_tensors][6] = {param*, grad*, exp_avg*, exp_avg_sq*, numel, first_block}
  * (first_block = prefix sum of ceil(numel/4096)); total_blocks = grid size.
@@ -175,13 +185,24 @@ int gdmcf_topk_masked_f32(const float* pred, int64_t ldp, int B, int I, const in
                           void* stream);
 
 /* ---- LightGCN propagation: CSR SpMM (lightGCN.py:184-189) --------------------------------
- * Y[r,:] = sum_j val[j]*X[col[j],:]   for j in [rowptr[r], rowptr[r+1])
- * acc (optional): acc[r,:] += Y[r,:]  -- running layer sum for the layer mean (:188-189).
- * rowptr int64 [n_rows+1], col int32, val float32; X,Y [*,d] with row strides ldx/ldy.      */
-int gdmcf_spmm_csr_f32(const int64_t* rowptr, const int32_t* col, const float* val, int n_rows,
-                       const float* X, int64_t ldx, int d, float* Y, int64_t ldy, float* acc,
-                       int64_t ldacc, void* stream);
-/* out = acc * scale  (layer mean = running sum / (L+1)) */
+ * Y[r,:] = ( sum_j val[j]*X[col[j],:]  +  sum_k addend_k[r,:] ) * scale
+ * The adjacency is plain CSR (col int32, val float32) plus a host-built execution plan that splits
+ * every row into "virtual rows" of at most `chunk` nonzeros so that hub nodes spread over many waves:
+ *   vptr  int64 [n_virtual+1]  nonzero range of each virtual row (consecutive, covering the CSR)
+ *   vrow  int32 [n_virtual]    the real row it belongs to
+ *   vslot int32 [n_virtual]    -1: the row is whole, write Y directly; >= 0: slot in partial_ws
+ *   lrow  int32 [n_long], lptr int32 [n_long+1]: the split rows and their slot ranges
+ *   partial_ws float32 [n_slots, d]
+ * With chunk = infinity the plan degenerates to vptr = rowptr (n_virtual = n_rows, n_long = 0).
+ * addends_host: HOST array of n_add (<= 8) device pointers [n_rows, ld_add] -- the last LightGCN
+ * layer passes E_0..E_{L-1} and scale = 1/(L+1) so the layer mean (:188-189) costs no extra pass.
+ * alg_bytes: algorithmic bytes of this launch, forwarded to the profiling hook only.          */
+int gdmcf_spmm_csr_f32(const int64_t* vptr, const int32_t* vrow, const int32_t* vslot, int n_virtual,
+                       const int32_t* lrow, const int32_t* lptr, int n_long, const int32_t* col,
+                       const float* val, int n_rows, const float* X, int64_t ldx, int d, float* Y,
+                       int64_t ldy, float* partial_ws, const float* const* addends_host, int n_add,
+                       int64_t ld_add, float scale, double alg_bytes, void* stream);
+/* out = acc * scale */
 int gdmcf_scale_f32(const float* acc, int64_t n, float scale, float* out, void* stream);
 
 #ifdef __cplusplus

@@ -207,6 +207,81 @@ def test_lightgcn_propagation_matches_reference(case):
     np.testing.assert_allclose(fu.cpu().numpy(), fx["final_user"], rtol=0, atol=3e-7)
     np.testing.assert_allclose(fi.cpu().numpy(), fx["final_item"], rtol=0, atol=3e-7)
     np.testing.assert_array_equal(iu.cpu().numpy(), fx["E0"][:U])
+    fu2, fi2, _, _ = m.propagate_through_layers()  # production path: layer mean fused into the last SpMM
+    np.testing.assert_allclose(fu2.cpu().numpy(), fx["final_user"], rtol=0, atol=3e-7)
+    np.testing.assert_allclose(fi2.cpu().numpy(), fx["final_item"], rtol=0, atol=3e-7)
+
+
+def test_spmm_hub_rows_are_split_and_exact():
+    """A hub item with thousands of neighbours goes through the virtual-row split + combine path."""
+    rng = np.random.default_rng(0)
+    U, It, d = 3000, 50, 64
+    users = np.concatenate([np.arange(U), rng.integers(0, U, 500)])
+    items = np.concatenate([np.zeros(U, dtype=np.int64), rng.integers(1, It, 500)])  # item 0 has 3000 neighbours
+    A = O.lightgcn_norm_adj(users, items, U, It)
+    E0 = rng.standard_normal((U + It, d)).astype(np.float32)
+    ref = O.lightgcn_propagate(A, E0, 3, U)
+    m = gdmcf_amd.LightGCN({"user_id_idx": users, "item_id_idx": items}, U, It, 3, d, device=DEV)
+    assert m._plan["lrow"].numel() >= 1 and m._plan["n_slots"] >= 12
+    with torch.no_grad():
+        m.E0.weight.copy_(torch.from_numpy(E0))
+    m = m.to(DEV)
+    fu, fi, _, _ = m.propagate_through_layers()
+    np.testing.assert_allclose(fu.cpu().numpy(), ref[0], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(fi.cpu().numpy(), ref[1], rtol=0, atol=5e-6)
+    fu2, fi2, _, _ = m.propagate_through_layers()
+    assert torch.equal(fi, fi2) and torch.equal(fu, fu2)  # deterministic (no atomics)
+
+
+def test_lt_history_kernel_matches_serial_fifo():
+    """The parallel rank-based FIFO update == the reference's row-by-row loop (gaussian_diffusion.py:355-368)."""
+    from gdmcf_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(0)
+    for T, H, B in [(3, 4, 50), (5, 10, 400), (40, 10, 16), (7, 3, 1), (2, 10, 257)]:
+        od = O.GaussianDiffusion(O.ModelMeanType.START_X, "linear", 0.1, 0.001, 0.01, T, history_num_per_term=H)
+        hist = torch.zeros(T, H, dtype=torch.float64, device=DEV)
+        cnt = torch.zeros(T, dtype=torch.int64, device=DEV)
+        for rounds in range(4):
+            ts = torch.randint(0, T, (B,), generator=g)
+            if rounds == 1:
+                ts[:] = ts[0]  # every row on one timestep: deep overflow
+            lu = torch.rand(B, generator=g, dtype=torch.float64)
+            od.update_history(ts, lu)
+            tsd, lud = ts.to(DEV), lu.to(DEV)
+            _lib.check(lib.gdmcf_lt_history_update(tsd.data_ptr(), lud.data_ptr(), B, T, H, hist.data_ptr(),
+                                                   cnt.data_ptr(), _lib.stream_ptr()))
+            np.testing.assert_array_equal(cnt.cpu().numpy(), od.Lt_count.numpy())
+            live = (torch.arange(H)[None, :] < od.Lt_count[:, None]).numpy()
+            np.testing.assert_array_equal(hist.cpu().numpy()[live], od.Lt_history.numpy()[live])
+
+
+def test_sample_timesteps_kernel():
+    fx = H.load("train_imp_T40")
+    meta = H.train_meta(fx)
+    d = gpu_diffusion(meta)
+    B = 4096
+    t, pt = d.sample_timesteps(B, DEV, "importance")  # history empty -> uniform branch, pt == 1
+    assert t.dtype == torch.int64 and int(t.min()) >= 0 and int(t.max()) < meta["T"]
+    assert torch.equal(pt, torch.ones(B, dtype=torch.float64, device=DEV))
+    cnts = torch.bincount(t, minlength=meta["T"]).float() / B
+    assert float((cnts - 1.0 / meta["T"]).abs().max()) < 0.02
+    d.Lt_history.copy_(torch.from_numpy(fx["Lt_history0"]))
+    d.Lt_count.copy_(torch.from_numpy(fx["Lt_count0"]))
+    from gdmcf_amd import _lib
+    p_out = torch.zeros(meta["T"], dtype=torch.float64, device=DEV)
+    ts = torch.empty(B, dtype=torch.int64, device=DEV)
+    ptv = torch.empty(B, dtype=torch.float64, device=DEV)
+    _lib.check(_lib.load().gdmcf_sample_timesteps(d.Lt_history.data_ptr(), d.Lt_count.data_ptr(), meta["T"], 10, B, 0.001,
+                                                  7, 1, ts.data_ptr(), ptv.data_ptr(), p_out.data_ptr(),
+                                                  _lib.stream_ptr()))
+    np.testing.assert_allclose(p_out.cpu().numpy(), fx["s0.p_all"], rtol=1e-12)  # the reference's p vector
+    np.testing.assert_allclose(ptv.cpu().numpy(), (p_out[ts] * meta["T"]).cpu().numpy(), rtol=0, atol=0)
+    emp = torch.bincount(ts, minlength=meta["T"]).double().cpu().numpy() / B
+    assert np.abs(emp - fx["s0.p_all"]).max() < 0.02
+    t2, _ = d.sample_timesteps(B, DEV, "importance")
+    t3, _ = d.sample_timesteps(B, DEV, "importance")
+    assert not torch.equal(t2, t3)
 
 
 @pytest.mark.parametrize("d", [8, 16, 32, 64, 128, 256, 20, 7])
