@@ -32,17 +32,26 @@ struct TileGeom {
 // still stream with the widest load.
 typedef f32x4 f32x4_u __attribute__((aligned(4)));
 
+// Tile loads are issued as inline asm so that hipcc neither counts nor waits for them: the kernel keeps
+// two tiles in flight and places the counted s_waitcnt vmcnt(N) itself (stage_wait below).  Left to the
+// compiler, the waits degenerate to vmcnt(0..4) at joins/back-edges and drain the second stage.
+__device__ __forceinline__ f32x4 gload16(const float* p) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
 template <int LAY, int R, int BK>
 struct TileStage {
     using G = TileGeom<LAY, R, BK>;
     f32x4 reg[G::NL];
 
-    // Interior K tile (k0 + BK <= kend).  Branch-free so that all loads issue back to back and the
-    // only wait is at the LDS write after the MFMAs.  Rows past `nrows` are clamped onto valid rows:
-    // their products land in accumulator rows/columns that the epilogue never stores.
-    // MC layout needs nrows >= 4 (checked by the caller).
-    __device__ __forceinline__ void load_fast(const float* __restrict__ P, int64_t ld, int row0, int nrows, int k0,
-                                              bool rows_full, int tid) {
+    // Interior tile: k0 + BK <= kend and (MC layout) row0 + R <= nrows.  Nothing but address arithmetic and
+    // loads, so all of them issue back to back and the only wait is at the LDS write after the MFMAs.
+    // KC rows past `nrows` are clamped onto valid rows (their products land in accumulator rows/columns
+    // that the epilogue never stores).
+    __device__ __forceinline__ void load_plain(const float* __restrict__ P, int64_t ld, int row0, int nrows, int k0,
+                                               int tid) {
 #pragma unroll
         for (int i = 0; i < G::NL; ++i) {
             int idx = tid + i * NTHREADS;
@@ -50,59 +59,97 @@ struct TileStage {
             if (LAY == GD_LAY_KC) {
                 const int r = idx / (BK / 4), kk = (idx % (BK / 4)) * 4;
                 const int gr = min(row0 + r, nrows - 1);
-                reg[i] = *reinterpret_cast<const f32x4_u*>(P + (int64_t)gr * ld + (k0 + kk));
+                reg[i] = gload16(P + (int64_t)gr * ld + (k0 + kk));
             } else {
                 const int kk = idx / (R / 4), r = (idx % (R / 4)) * 4;
-                const int gr = row0 + r;
-                const int gc = min(gr, nrows - 4);
-                f32x4 v = *reinterpret_cast<const f32x4_u*>(P + (int64_t)(k0 + kk) * ld + gc);
-                if (!rows_full) {  // wave-uniform; a vector straddling the last column is shifted in registers
-                    const int sh = gr - gc;
-                    v.x = sh == 0 ? v.x : (sh == 1 ? v.y : (sh == 2 ? v.z : v.w));
-                    v.y = sh == 0 ? v.y : (sh == 1 ? v.z : v.w);
-                    v.z = sh == 0 ? v.z : v.w;
-                }
-                reg[i] = v;
+                reg[i] = gload16(P + (int64_t)(k0 + kk) * ld + (row0 + r));
             }
         }
     }
 
-    // Partial K tile (or tiny matrices): element-wise predicated, zero filled.
-    __device__ __forceinline__ void load_slow(const float* __restrict__ P, int64_t ld, int row0, int nrows, int k0,
+    // Edge tile (K tail and/or last row block), still branch-free: addresses are clamped onto valid
+    // elements here; the in-register shift of a vector straddling the edge and the zero fill of k >= kend
+    // are deferred to store_edge(), i.e. after the MFMAs, so these loads stay in flight like plain ones.
+    // No load leaves [0,nrows) x [0,kend).  Needs kend >= 4 (KC) / nrows >= 4 (MC).
+    __device__ __forceinline__ void load_edge(const float* __restrict__ P, int64_t ld, int row0, int nrows, int k0,
                                               int kend, int tid) {
 #pragma unroll
         for (int i = 0; i < G::NL; ++i) {
-            const int idx = tid + i * NTHREADS;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (G::NL * NTHREADS == G::F4 || idx < G::F4) {
+            int idx = tid + i * NTHREADS;
+            if (G::NL * NTHREADS != G::F4) idx = min(idx, G::F4 - 1);
+            if (LAY == GD_LAY_KC) {
+                const int r = idx / (BK / 4), kk = (idx % (BK / 4)) * 4;
+                const int gr = min(row0 + r, nrows - 1);
+                const int gc = max(min(k0 + kk, kend - 4), 0);
+                reg[i] = gload16(P + (int64_t)gr * ld + gc);
+            } else {
+                const int kk = idx / (R / 4), r = (idx % (R / 4)) * 4;
+                const int gc = min(row0 + r, nrows - 4);
+                const int gk = min(k0 + kk, kend - 1);
+                reg[i] = gload16(P + (int64_t)gk * ld + gc);
+            }
+        }
+    }
+
+    __device__ __forceinline__ void fix_edge(int row0, int nrows, int k0, int kend, int tid) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    int gr, gk;
-                    if (LAY == GD_LAY_KC) {
-                        gr = row0 + idx / (BK / 4);
-                        gk = k0 + (idx % (BK / 4)) * 4 + j;
-                    } else {
-                        gk = k0 + idx / (R / 4);
-                        gr = row0 + (idx % (R / 4)) * 4 + j;
-                    }
-                    if (gr < nrows && gk < kend)
-                        v[j] = (LAY == GD_LAY_KC) ? P[(int64_t)gr * ld + gk] : P[(int64_t)gk * ld + gr];
-                }
+        for (int i = 0; i < G::NL; ++i) {
+            int idx = tid + i * NTHREADS;
+            if (G::NL * NTHREADS != G::F4) idx = min(idx, G::F4 - 1);
+            f32x4 v = reg[i];
+            if (LAY == GD_LAY_KC) {
+                const int gk = k0 + (idx % (BK / 4)) * 4;
+                const int sh = gk - max(min(gk, kend - 4), 0);  // 0 interior, 1..3 straddling kend, >= 4 beyond
+                v.x = sh == 0 ? v.x : (sh == 1 ? v.y : (sh == 2 ? v.z : v.w));
+                v.y = sh == 0 ? v.y : (sh == 1 ? v.z : v.w);
+                v.z = sh == 0 ? v.z : v.w;
+                v.x = (gk + 0 < kend) ? v.x : 0.f;
+                v.y = (gk + 1 < kend) ? v.y : 0.f;
+                v.z = (gk + 2 < kend) ? v.z : 0.f;
+                v.w = (gk + 3 < kend) ? v.w : 0.f;
+            } else {
+                const int kk = idx / (R / 4), gr = row0 + (idx % (R / 4)) * 4;
+                const int sh = gr - min(gr, nrows - 4);
+                v.x = sh == 0 ? v.x : (sh == 1 ? v.y : (sh == 2 ? v.z : v.w));
+                v.y = sh == 0 ? v.y : (sh == 1 ? v.z : v.w);
+                v.z = sh == 0 ? v.z : v.w;
+                const bool kz = (k0 + kk >= kend);
+                v.x = kz ? 0.f : v.x;
+                v.y = kz ? 0.f : v.y;
+                v.z = kz ? 0.f : v.z;
+                v.w = kz ? 0.f : v.w;
             }
             reg[i] = v;
         }
     }
 
-    __device__ __forceinline__ void load(const float* __restrict__ P, int64_t ld, int row0, int nrows, int k0,
-                                         int kend, bool rows_full, int tid) {
-        const bool fast = (k0 + BK <= kend) && (LAY == GD_LAY_KC || nrows >= 4);
-        if (fast)
-            load_fast(P, ld, row0, nrows, k0, rows_full, tid);
-        else
-            load_slow(P, ld, row0, nrows, k0, kend, tid);
+    int mode, m_row0, m_nrows, m_k0, m_kend;  // how this stage was loaded (wave-uniform), for store()
+
+    // Pins the stage registers behind a wait the caller has just executed (the asm is empty; the "+v"
+    // operands make every register of the stage opaque at this point, guide 5.7 form ii).
+    __device__ __forceinline__ void pin() {
+#pragma unroll
+        for (int i = 0; i < G::NL; ++i) asm volatile("" : "+v"(reg[i]));
     }
 
-    __device__ __forceinline__ void store(float* __restrict__ lds, int tid) const {
+    __device__ __forceinline__ void load(const float* __restrict__ P, int64_t ld, int row0, int nrows, int k0,
+                                         int kend, int kbeg, bool rows_full, int tid) {
+        // exactly two variants with the same number of loads in the same order, so the compiler's counted
+        // vmcnt waits stay exact across the join (a third, predicated path would force conservative waits
+        // that drain the second register stage).  Degenerate shapes are rejected on the host.
+        const bool k_full = (k0 + BK <= kend);
+        if (k_full && (LAY == GD_LAY_KC || rows_full)) {
+            mode = 0;
+            load_plain(P, ld, row0, nrows, k0, tid);
+        } else {
+            mode = 1;
+            m_row0 = row0; m_nrows = nrows; m_k0 = k0; m_kend = kend;
+            load_edge(P, ld, row0, nrows, k0, kend, tid);
+        }
+    }
+
+    __device__ __forceinline__ void store(float* __restrict__ lds, int tid) {
+        if (mode == 1) fix_edge(m_row0, m_nrows, m_k0, m_kend, tid);
 #pragma unroll
         for (int i = 0; i < G::NL; ++i) {
             const int idx = tid + i * NTHREADS;
@@ -183,27 +230,18 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GdGemm g) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    TileStage<LAYA, BM, BK> sa;
-    TileStage<LAYB, BN, BK> sb;
-
+    // Two register stages: the loads of tile t+2 are issued before the MFMAs of tile t, the registers of
+    // tile t+1 (issued one iteration earlier) are written to LDS after them.  Every load therefore has
+    // two full iterations to land -- with ~4 us loaded L2/HBM latency a CU needs ~100 KB in flight to keep
+    // its MFMA pipes busy, one tile ahead only gives half of that (measured: 40-60 % MFMA busy).
+    TileStage<LAYA, BM, BK> sa0, sa1;
+    TileStage<LAYB, BN, BK> sb0, sb1;
     const bool a_full = (m0 + BM <= g.M), b_full = (n0 + BN <= g.N);
-    if (nt > 0) {
-        sa.load(g.A, g.lda, m0, g.M, kbeg, kend, a_full, tid);
-        sb.load(g.B, g.ldb, n0, g.N, kbeg, kend, b_full, tid);
-        sa.store(smem, tid);
-        sb.store(smem + GA::FLOATS, tid);
-    }
-    __syncthreads();
+    float* const L0 = smem;
+    float* const L1 = smem + STAGE_FLOATS;
 
-    for (int it = 0; it < nt; ++it) {
-        const float* As = smem + (it & 1) * STAGE_FLOATS;
+    auto compute = [&](const float* As) {
         const float* Bs = As + GA::FLOATS;
-        const bool more = (it + 1 < nt);
-        if (more) {
-            const int k0 = kbeg + (it + 1) * BK;
-            sa.load(g.A, g.lda, m0, g.M, k0, kend, a_full, tid);
-            sb.load(g.B, g.ldb, n0, g.N, k0, kend, b_full, tid);
-        }
 #pragma unroll
         for (int c = 0; c < BK / 16; ++c) {
             float fa[TM][4], fb[TN][4];
@@ -217,13 +255,63 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GdGemm g) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
         }
-        if (more) {
-            float* An = smem + ((it + 1) & 1) * STAGE_FLOATS;
-            sa.store(An, tid);
-            sb.store(An + GA::FLOATS, tid);
+    };
+
+    constexpr int LOADS_PER_TILE = GA::NL + GB::NL;
+#define GD_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+    if (nt > 0) {
+        sa0.load(g.A, g.lda, m0, g.M, kbeg, kend, kbeg, a_full, tid);
+        sb0.load(g.B, g.ldb, n0, g.N, kbeg, kend, kbeg, b_full, tid);
+        if (nt > 1) {
+            sa1.load(g.A, g.lda, m0, g.M, kbeg + BK, kend, kbeg, a_full, tid);
+            sb1.load(g.B, g.ldb, n0, g.N, kbeg + BK, kend, kbeg, b_full, tid);
+            GD_WAIT_VM(LOADS_PER_TILE);  // tile 0 landed, tile 1 still in flight
+        } else {
+            GD_WAIT_VM(0);
+        }
+        sa0.pin();
+        sb0.pin();
+        sa0.store(L0, tid);
+        sb0.store(L0 + GA::FLOATS, tid);
+    }
+    __syncthreads();
+
+    for (int it = 0; it < nt; it += 2) {
+        // even tile `it`: LDS stage 0; stage-1 registers hold tile it+1 (in flight); stage-0 registers are free
+        const bool ld2 = (it + 2 < nt);
+        if (ld2) {
+            sa0.load(g.A, g.lda, m0, g.M, kbeg + (it + 2) * BK, kend, kbeg, a_full, tid);
+            sb0.load(g.B, g.ldb, n0, g.N, kbeg + (it + 2) * BK, kend, kbeg, b_full, tid);
+        }
+        compute(L0);
+        if (it + 1 < nt) {
+            if (ld2) GD_WAIT_VM(LOADS_PER_TILE); else GD_WAIT_VM(0);  // tile it+1 landed
+            sa1.pin();
+            sb1.pin();
+            sa1.store(L1, tid);
+            sb1.store(L1 + GA::FLOATS, tid);
         }
         __syncthreads();
+        if (it + 1 < nt) {
+            // odd tile `it+1`: LDS stage 1; stage-0 registers hold tile it+2 (in flight)
+            const bool ld3 = (it + 3 < nt);
+            if (ld3) {
+                sa1.load(g.A, g.lda, m0, g.M, kbeg + (it + 3) * BK, kend, kbeg, a_full, tid);
+                sb1.load(g.B, g.ldb, n0, g.N, kbeg + (it + 3) * BK, kend, kbeg, b_full, tid);
+            }
+            compute(L1);
+            if (ld2) {
+                if (ld3) GD_WAIT_VM(LOADS_PER_TILE); else GD_WAIT_VM(0);  // tile it+2 landed
+                sa0.pin();
+                sb0.pin();
+                sa0.store(L0, tid);
+                sb0.store(L0 + GA::FLOATS, tid);
+            }
+            __syncthreads();
+        }
     }
+    GD_WAIT_VM(0);
+#undef GD_WAIT_VM
 
     // ---- epilogue.  acc[i][j][e] = C[m0+wm0+16i+4q+e][n0+wn0+16j+r] ----
     float rowacc[TM][4];
@@ -366,6 +454,16 @@ int gd_pick_shape_class(int M, int N) {
 }
 
 int gd_gemm_launch(int layA, int layB, int epi, int cls, GdGemm& g, hipStream_t s) {
+    // the branch-free edge loader clamps 16-byte vectors onto valid elements: it needs >= 4 elements along
+    // the contiguous axis of every operand (K for K-contiguous operands, rows for row-contiguous ones)
+    if ((layA == GD_LAY_KC || layB == GD_LAY_KC) && g.K < 4) {
+        gdmcf_set_error("gemm: reduction length %d < 4 is not supported", g.K);
+        return GDMCF_E_UNSUPPORTED;
+    }
+    if ((layA == GD_LAY_MC && g.M < 4) || (layB == GD_LAY_MC && g.N < 4)) {
+        gdmcf_set_error("gemm: a row-contiguous operand with fewer than 4 rows (M=%d, N=%d) is not supported", g.M, g.N);
+        return GDMCF_E_UNSUPPORTED;
+    }
     if (layA == GD_LAY_KC && layB == GD_LAY_KC) {
         switch (epi) {
             case GD_EPI_SLAB: return launch_class<GD_LAY_KC, GD_LAY_KC, 32, GD_EPI_SLAB>(cls, g, s);

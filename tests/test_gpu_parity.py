@@ -227,8 +227,17 @@ def test_spmm_hub_rows_are_split_and_exact():
         m.E0.weight.copy_(torch.from_numpy(E0))
     m = m.to(DEV)
     fu, fi, _, _ = m.propagate_through_layers()
-    np.testing.assert_allclose(fu.cpu().numpy(), ref[0], rtol=0, atol=2e-6)
-    np.testing.assert_allclose(fi.cpu().numpy(), ref[1], rtol=0, atol=5e-6)
+    # a 3000-term fp32 sum is order sensitive: judge both against the float64 evaluation of the SAME
+    # float32 adjacency.  The oracle (sequential fp32) is within 3e-5 of it, the kernel (tree order) within 5e-6.
+    A64, E64 = A.astype(np.float64), E0.astype(np.float64)
+    acc, cur = E64.copy(), E64
+    for _ in range(3):
+        cur = A64 @ cur
+        acc = acc + cur
+    mean64 = acc / 4
+    np.testing.assert_allclose(ref[1], mean64[U:], rtol=0, atol=3e-5)
+    np.testing.assert_allclose(fu.cpu().numpy(), mean64[:U], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(fi.cpu().numpy(), mean64[U:], rtol=0, atol=5e-6)
     fu2, fi2, _, _ = m.propagate_through_layers()
     assert torch.equal(fi, fi2) and torch.equal(fu, fu2)  # deterministic (no atomics)
 
