@@ -12,6 +12,8 @@
 // identically for A and B so a b128 read feeds four consecutive MFMAs.
 // The exact f32 MFMA is a k-ordered fmaf chain, so results are deterministic for a given
 // (tile, split) configuration.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -314,64 +316,106 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GdGemm g) {
 #undef GD_WAIT_VM
 
     // ---- epilogue.  acc[i][j][e] = C[m0+wm0+16i+4q+e][n0+wn0+16j+r] ----
+    // Branch-free on the load side: every read (bias, target, x_t, z, per-row coefficients) uses indices
+    // clamped into the matrix and is issued before any of them is consumed, so the ~40 loads per lane are
+    // in flight together; only the stores are predicated.
     float rowacc[TM][4];
-    if (EPI == GD_EPI_LOSS) {
+    int ncl[TN];
+    bool nok[TN];
+    float biasv[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn0 + 16 * j + r;
+        nok[j] = n < g.N;
+        ncl[j] = min(n, g.N - 1);
+        biasv[j] = 0.f;
+        if ((EPI == GD_EPI_BIAS_ACT || EPI == GD_EPI_LOSS || EPI == GD_EPI_POST) && g.bias) biasv[j] = g.bias[ncl[j]];
+    }
+    if (EPI == GD_EPI_SLAB || EPI == GD_EPI_STORE || EPI == GD_EPI_BIAS_ACT) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) rowacc[i][e] = 0.f;
-    }
+            for (int e = 0; e < 4; ++e) {
+                const int m = m0 + wm0 + 16 * i + 4 * q + e;
+                if (m < g.M) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int m = m0 + wm0 + 16 * i + 4 * q + e;
-            if (m < g.M) {
-                float c1 = 0.f, c2 = 0.f, p1 = 0.f, p2 = 0.f, sg = 0.f, alpha = 1.f;
-                if (EPI == GD_EPI_POST) {
-                    c1 = g.r0[m];
-                    c2 = g.r1[m];
-                    if (g.r2) {
-                        p1 = g.r2[m];
-                        p2 = g.r3[m];
-                    }
-                    if (g.aux2) sg = g.r4[m];
-                }
-                if (EPI == GD_EPI_LOSS && g.r0) alpha = g.r0[m];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int n = n0 + wn0 + 16 * j + r;
-                    if (n < g.N) {
+                    for (int j = 0; j < TN; ++j) {
+                        if (!nok[j]) continue;
                         float v = acc[i][j][e];
                         if (EPI == GD_EPI_SLAB) {
-                            g.C[(int64_t)split * g.slab_stride + (int64_t)m * g.ldc + n] = v;
+                            g.C[(int64_t)split * g.slab_stride + (int64_t)m * g.ldc + ncl[j]] = v;
                         } else if (EPI == GD_EPI_STORE) {
-                            float* p = &g.C[(int64_t)m * g.ldc + n];
+                            float* p = &g.C[(int64_t)m * g.ldc + ncl[j]];
                             *p = g.accumulate ? (*p + v) : v;
-                        } else if (EPI == GD_EPI_BIAS_ACT) {
-                            if (g.bias) v += g.bias[n];
+                        } else {
+                            v += biasv[j];
                             if (g.act == 1) v = gd_tanh(v);
-                            g.C[(int64_t)m * g.ldc + n] = v;
-                        } else if (EPI == GD_EPI_LOSS) {
-                            if (g.bias) v += g.bias[n];
-                            if (g.out2) g.out2[(int64_t)m * g.ldout2 + n] = v;
-                            const float d = alpha * v - g.aux[(int64_t)m * g.ldaux + n];
-                            g.C[(int64_t)m * g.ldc + n] = d;
-                            rowacc[i][e] += d * d;
-                        } else if (EPI == GD_EPI_POST) {
-                            if (g.bias) v += g.bias[n];
-                            const float xt = g.aux[(int64_t)m * g.ldaux + n];
-                            float pred = v;
-                            if (g.r2) pred = p1 * xt - p2 * v;
-                            if (g.out2) g.out2[(int64_t)m * g.ldout2 + n] = pred;
-                            float mean = c1 * pred + c2 * xt;
-                            if (g.aux2) mean += sg * g.aux2[(int64_t)m * g.ldaux2 + n];
-                            g.C[(int64_t)m * g.ldc + n] = mean;
+                            g.C[(int64_t)m * g.ldc + ncl[j]] = v;
                         }
                     }
                 }
             }
-        }
+    } else {
+        // LOSS / POST: phase 1 -- all auxiliary loads; phase 2 -- arithmetic + predicated stores
+        float av[TM][4][TN];   // target (LOSS) or x_t (POST)
+        float zv[TM][4][TN];   // z noise (POST with sampling noise)
+        float c1v[TM][4], c2v[TM][4], p1v[TM][4], p2v[TM][4], sgv[TM][4];
+        const bool has_z = (EPI == GD_EPI_POST) && (g.aux2 != nullptr);
+        const bool has_r = (EPI == GD_EPI_POST) && (g.r2 != nullptr);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int mc = min(m0 + wm0 + 16 * i + 4 * q + e, g.M - 1);
+                c1v[i][e] = 1.f; c2v[i][e] = 0.f; p1v[i][e] = 0.f; p2v[i][e] = 0.f; sgv[i][e] = 0.f;
+                if (EPI == GD_EPI_LOSS) {
+                    if (g.r0) c1v[i][e] = g.r0[mc];  // alpha
+                } else {
+                    c1v[i][e] = g.r0[mc];
+                    c2v[i][e] = g.r1[mc];
+                    if (has_r) {
+                        p1v[i][e] = g.r2[mc];
+                        p2v[i][e] = g.r3[mc];
+                    }
+                    if (has_z) sgv[i][e] = g.r4[mc];
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    av[i][e][j] = g.aux[(int64_t)mc * g.ldaux + ncl[j]];
+                    zv[i][e][j] = has_z ? g.aux2[(int64_t)mc * g.ldaux2 + ncl[j]] : 0.f;
+                }
+            }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = m0 + wm0 + 16 * i + 4 * q + e;
+                const bool mok = m < g.M;
+                float racc = 0.f;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const bool ok = mok && nok[j];
+                    const float v = acc[i][j][e] + biasv[j];
+                    if (EPI == GD_EPI_LOSS) {
+                        const float d = c1v[i][e] * v - av[i][e][j];
+                        if (ok) {
+                            if (g.out2) g.out2[(int64_t)m * g.ldout2 + ncl[j]] = v;
+                            g.C[(int64_t)m * g.ldc + ncl[j]] = d;
+                            racc += d * d;
+                        }
+                    } else {
+                        const float xt = av[i][e][j];
+                        const float pred = has_r ? (p1v[i][e] * xt - p2v[i][e] * v) : v;
+                        float mean = c1v[i][e] * pred + c2v[i][e] * xt;
+                        if (has_z) mean += sgv[i][e] * zv[i][e][j];
+                        if (ok) {
+                            if (g.out2) g.out2[(int64_t)m * g.ldout2 + ncl[j]] = pred;
+                            g.C[(int64_t)m * g.ldc + ncl[j]] = mean;
+                        }
+                    }
+                }
+                rowacc[i][e] = racc;
+            }
     }
     if (EPI == GD_EPI_LOSS) {
         // per-row sum of squares: 16 lanes (r) of each q-group hold one row's columns
@@ -474,6 +518,8 @@ int gd_gemm_launch(int layA, int layB, int epi, int cls, GdGemm& g, hipStream_t 
     } else if (layA == GD_LAY_KC && layB == GD_LAY_MC) {
         if (epi == GD_EPI_SLAB) return launch_class<GD_LAY_KC, GD_LAY_MC, 32, GD_EPI_SLAB>(cls, g, s);
     } else if (layA == GD_LAY_MC && layB == GD_LAY_MC) {
+        static const int tn_bk = getenv("GDMCF_TN_BK") ? atoi(getenv("GDMCF_TN_BK")) : 16;  // tuning knob
+        if (epi == GD_EPI_STORE && tn_bk == 32) return launch_class<GD_LAY_MC, GD_LAY_MC, 32, GD_EPI_STORE>(cls, g, s);
         if (epi == GD_EPI_STORE) return launch_class<GD_LAY_MC, GD_LAY_MC, 16, GD_EPI_STORE>(cls, g, s);
     }
     gdmcf_set_error("unsupported gemm variant (layA=%d layB=%d epi=%d)", layA, layB, epi);

@@ -15,6 +15,21 @@ import torch
 import torch.distributed as dist
 
 
+def _host_staged(group):
+    """gloo has no device collectives on ROCm: stage through the host (rehearsal/tests only; the
+    production backend is "nccl" = RCCL, device to device over xGMI)."""
+    return dist.get_backend(group) == "gloo"
+
+
+def _all_reduce(t, group, async_op=False):
+    if t.is_cuda and _host_staged(group):
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+        return None
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+
 def allreduce_grads(params, group=None, bucket_bytes=256 << 20):
     """In-place SUM all-reduce of .grad over ranks.  Large tensors go alone (no copy); small ones are
     coalesced into one flat bucket.  xGMI is point-to-point, so few, large messages are preferred."""
@@ -26,18 +41,19 @@ def allreduce_grads(params, group=None, bucket_bytes=256 << 20):
             continue
         g = p.grad
         if g.numel() * g.element_size() >= (1 << 20):
-            handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group, async_op=True))
+            handles.append(_all_reduce(g, group, async_op=True))
         else:
             small.append(g)
     if small:
         flat = torch.cat([g.reshape(-1) for g in small])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        _all_reduce(flat, group)
         off = 0
         for g in small:
             g.copy_(flat[off:off + g.numel()].view_as(g))
             off += g.numel()
     for h in handles:
-        h.wait()
+        if h is not None:
+            h.wait()
 
 
 def gather_history_inputs(ts, loss_unscaled, group=None):
@@ -45,17 +61,25 @@ def gather_history_inputs(ts, loss_unscaled, group=None):
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return ts, loss_unscaled
     world = dist.get_world_size(group)
+    dev = ts.device
+    if ts.is_cuda and _host_staged(group):
+        ts, loss_unscaled = ts.cpu(), loss_unscaled.cpu()
     ts_all = [torch.empty_like(ts) for _ in range(world)]
     lu_all = [torch.empty_like(loss_unscaled) for _ in range(world)]
     dist.all_gather(ts_all, ts.contiguous(), group=group)
     dist.all_gather(lu_all, loss_unscaled.contiguous(), group=group)
-    return torch.cat(ts_all), torch.cat(lu_all)
+    return torch.cat(ts_all).to(dev), torch.cat(lu_all).to(dev)
 
 
 def broadcast_parameters(model, group=None, src=0):
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         for p in model.parameters():
-            dist.broadcast(p.data, src=src, group=group)
+            if p.is_cuda and _host_staged(group):
+                h = p.data.cpu()
+                dist.broadcast(h, src=src, group=group)
+                p.data.copy_(h)
+            else:
+                dist.broadcast(p.data, src=src, group=group)
 
 
 class DataParallelStep:
@@ -84,4 +108,4 @@ class DataParallelStep:
                                                            d.steps, d.history_num_per_term, d.Lt_history.data_ptr(),
                                                            d.Lt_count.data_ptr(), _lib.stream_ptr()))
         self.optimizer.step()
-        return loss
+        return loss.detach()
