@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Condenses rocprofv3 CSV output (gpurun_out/<run>/...) into the small summaries committed here.
+
+  python profiles/summarize.py stats  <kernel_stats.csv>                    -> per-kernel time table
+  python profiles/summarize.py traffic <fetch counter csv> <write counter csv> -> HBM bytes per launch
+
+HBM traffic follows MI355X_MICROARCH.md (HBM / rocprofv3): FETCH_SIZE and WRITE_SIZE come from separate
+--pmc passes and are in KiB; on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide coalesced
+streaming read, so it is doubled; WRITE_SIZE is exact for 16-B-per-lane stores (dword-per-lane stores,
+as in the GEMM epilogues, are uncalibrated -- marked)."""
+import collections
+import csv
+import json
+import sys
+
+
+def short(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    return name.split("(")[0][:70]
+
+
+def stats(path):
+    rows = list(csv.DictReader(open(path)))
+    out = []
+    for r in rows:
+        if float(r["Percentage"]) < 0.05:
+            continue
+        out.append(dict(kernel=short(r["Name"]), calls=int(r["Calls"]), avg_us=round(float(r["AverageNs"]) / 1e3, 2),
+                        total_ms=round(float(r["TotalDurationNs"]) / 1e6, 3), pct=float(r["Percentage"])))
+    return out
+
+
+def per_kernel(path, counter):
+    agg, n = collections.defaultdict(float), collections.defaultdict(set)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        k = short(r["Kernel_Name"])
+        agg[k] += float(r["Counter_Value"])
+        n[k].add(r["Dispatch_Id"])
+    return {k: agg[k] / len(n[k]) for k in agg}, {k: len(v) for k, v in n.items()}
+
+
+def traffic(fetch_csv, write_csv):
+    f, nf = per_kernel(fetch_csv, "FETCH_SIZE")
+    w, _ = per_kernel(write_csv, "WRITE_SIZE")
+    out = []
+    for k in sorted(f, key=lambda k: -(f[k] + w.get(k, 0))):
+        rd = 2.0 * f[k] * 1024  # gfx950 correction: FETCH_SIZE counts 128-B requests as 64 B
+        wr = w.get(k, 0.0) * 1024
+        if rd + wr < 1e6:
+            continue
+        out.append(dict(kernel=k, launches=nf[k], hbm_read_MB=round(rd / 1e6, 1), hbm_write_MB=round(wr / 1e6, 1),
+                        hbm_total_MB=round((rd + wr) / 1e6, 1)))
+    return out
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        print(json.dumps(stats(sys.argv[2]), indent=1))
+    else:
+        print(json.dumps(traffic(sys.argv[2], sys.argv[3]), indent=1))
