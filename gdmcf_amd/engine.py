@@ -38,6 +38,10 @@ class DenoiserEngine:
         self.offset = 0
         self._bufs = {}
         self._saved = None
+        # data parallel: called as grad_sink(param, grad) the moment a gradient's kernels are enqueued, so the
+        # all-reduce of the big weight gradients overlaps the rest of the backward (gdmcf_amd/parallel.py).
+        # When set, the engine assigns .grad itself and hands autograd None for that parameter.
+        self.grad_sink = None
 
     def manual_seed(self, seed):
         self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
@@ -241,6 +245,10 @@ class DenoiserEngine:
             _lib.check(lib.gdmcf_linear_bwd_weight_f32(dz.data_ptr(), lddz, A_use.data_ptr(), lda_use, _lib.ptr(rs), B,
                                                        N, K, dW.data_ptr(), dW.stride(0), db.data_ptr(), 0, st))
             grads_w[li], grads_b[li] = dW, db
+            if self.grad_sink is not None:
+                self.grad_sink(w, dW)
+                self.grad_sink(bias, db)
+                grads_w[li] = grads_b[li] = None
             if li > 0:
                 dprev = bufs.dzs[li - 1]
                 act_prev = layers[li - 1][2]
@@ -256,6 +264,10 @@ class DenoiserEngine:
         _lib.check(lib.gdmcf_emb_bwd_f32(dz.data_ptr(), lddz, w0.data_ptr(), w0.stride(0), self.I, self.E,
                                          bufs.temb.data_ptr(), B, w0.shape[0], bufs.demb.data_ptr(), dWe.data_ptr(),
                                          dbe.data_ptr(), st))
+        if self.grad_sink is not None:
+            self.grad_sink(m.emb_layer.weight, dWe)
+            self.grad_sink(m.emb_layer.bias, dbe)
+            dWe = dbe = None
         out = [dWe, dbe]
         for li in range(L):
             out += [grads_w[li], grads_b[li]]

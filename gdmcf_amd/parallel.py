@@ -84,15 +84,44 @@ def broadcast_parameters(model, group=None, src=0):
 
 class DataParallelStep:
     """zero_grad -> training_losses -> mean -> backward -> all-reduce -> AdamW, per rank (the body of
-    reference main.py:345-351 plus the single exchange)."""
+    reference main.py:345-351 plus the single exchange).
 
-    def __init__(self, diffusion, model, optimizer, group=None):
+    Overlap: the denoiser engine hands every gradient to `_sink` as soon as its kernels are enqueued.
+    Large tensors (the two 137.6 MB weight gradients at Yelp shape) start their all-reduce immediately on
+    RCCL's stream, so out_layers' gradient travels over xGMI while the dh / dW1 GEMMs still run; the few
+    small tensors are reduced in one flat bucket at the end.  Everything is waited for before AdamW."""
+
+    def __init__(self, diffusion, model, optimizer, group=None, overlap=True):
         self.diffusion, self.model, self.optimizer, self.group = diffusion, model, optimizer, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._handles, self._small = [], []
         if self.world > 1:
             diffusion.update_history = False  # replayed below on the gathered global batch
             optimizer.grad_scale = 1.0 / self.world
             broadcast_parameters(model, group)
+            if overlap:
+                model.engine.grad_sink = self._sink
+
+    def _sink(self, param, grad):
+        param.grad = grad if param.grad is None else param.grad.add_(grad)
+        g = param.grad
+        if g.numel() * g.element_size() >= (1 << 20):
+            self._handles.append(_all_reduce(g, self.group, async_op=True))
+        else:
+            self._small.append(g)
+
+    def _finish_exchange(self):
+        if self._small:
+            flat = torch.cat([g.reshape(-1) for g in self._small])
+            _all_reduce(flat, self.group)
+            off = 0
+            for g in self._small:
+                g.copy_(flat[off:off + g.numel()].view_as(g))
+                off += g.numel()
+        for h in self._handles:
+            if h is not None:
+                h.wait()
+        self._handles, self._small = [], []
 
     def __call__(self, batch, reweight=True, **rand):
         from . import _lib
@@ -101,7 +130,10 @@ class DataParallelStep:
         loss = losses["loss"].mean()
         loss.backward()
         if self.world > 1:
-            allreduce_grads(self.model.parameters(), self.group)
+            if self.model.engine.grad_sink is not None:
+                self._finish_exchange()
+            else:
+                allreduce_grads(self.model.parameters(), self.group)
             d = self.diffusion
             ts_all, lu_all = gather_history_inputs(d.last_ts, d.last_loss_unscaled, self.group)
             _lib.check(_lib.load().gdmcf_lt_history_update(ts_all.data_ptr(), lu_all.data_ptr(), ts_all.numel(),
