@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--spmm", action="store_true", help="also time the LightGCN SpMM (reported under 'spmm')")
+    ap.add_argument("--sampling", action="store_true", help="also time p_sample + masked top-k (reported under 'sampling')")
     return ap.parse_args()
 
 
@@ -168,6 +169,10 @@ def main():
     if args.spmm and rank == 0:
         spmm = bench_spmm(gdmcf_amd, lib, args.workload, dev)
 
+    sampling = None
+    if args.sampling and rank == 0:
+        sampling = bench_sampling(gdmcf_amd, lib, model, diffusion, x_dev[0], sub_ptr[:B + 1], sub_idx, dev)
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, I, x_host, args.cpu_seconds)
@@ -188,9 +193,41 @@ def main():
             out["speedup_vs_cpu"] = round(out["value"] / cpu["value"], 1)
         if spmm:
             out["spmm"] = spmm
+        if sampling:
+            out["sampling"] = sampling
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def bench_sampling(gdmcf_amd, lib, model, diffusion, x, indptr, indices, dev, iters=10, k=100):
+    """Evaluation path of reference main.py:288-301: p_sample (T denoiser forwards, steps=0) + history mask +
+    top-100, for one 400-user batch; users/s and the per-kernel split."""
+    model.eval()
+    ip = torch.from_numpy(np.asarray(indptr, dtype=np.int64)).to(dev)
+    ix = torch.from_numpy(np.asarray(indices[:int(indptr[-1])], dtype=np.int32)).to(dev)
+    for _ in range(2):
+        pred = diffusion.p_sample(model, x, 0, False)
+        idx = gdmcf_amd.masked_topk(pred, k, ip, ix)
+    torch.cuda.synchronize()
+    lib.gdmcf_prof_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        pred = diffusion.p_sample(model, x, 0, False)
+        idx = gdmcf_amd.masked_topk(pred, k, ip, ix)
+    torch.cuda.synchronize()
+    el = (time.perf_counter() - t0) / iters
+    prof = collect_prof(lib)
+    lib.gdmcf_prof_enable(0)
+    model.train()
+    out = dict(ms_per_batch=round(el * 1e3, 3), users_per_s=round(x.shape[0] / el, 1), topk=k, T=diffusion.steps)
+    for tag, name in ((1, "hidden_gemm"), (3, "posterior_gemm"), (7, "prep_input"), (9, "topk")):
+        if tag in prof:
+            d = prof[tag]
+            out[name + "_avg_ms"] = round(d["ms"] / d["n"], 4)
+            if tag == 9:
+                out["topk_GBps"] = round(d["work"] / (d["ms"] * 1e-3) / 1e9, 1)
+    return out
 
 
 def bench_spmm(gdmcf_amd, lib, workload, dev, layers=3, d=64, iters=20):

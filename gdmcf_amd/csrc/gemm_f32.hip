@@ -20,12 +20,23 @@ namespace {
 
 constexpr int NTHREADS = 256;
 
+// LDS images (bank rules: MI355X_MICROARCH.md, LDS):
+//  * K-contiguous operand: rows of BK floats with NO padding; the 16-byte slot s of row r is stored at slot
+//    s ^ ((r >> 1) & 7).  ds_read_b128 serves a wave in four 16-lane groups, each holding all 16 rows of an
+//    MFMA block at two neighbouring k-slots: with this swizzle the 16 addresses fall on 16 distinct
+//    16-byte slots of the 256-byte bank row (the former [row][BK+4] padding was 2-way conflicted).
+//  * row-contiguous operand: [k][rows + 4]; lane group q reads k-row 4q+s, so rows 4 apart must differ by
+//    16 banks: (rows+4) mod 8 == 4.
 template <int LAY, int R, int BK>
 struct TileGeom {
-    static constexpr int LD = (LAY == GD_LAY_KC) ? (BK + 4) : (R + ((48 - (R % 32)) % 32));
+    static_assert(LAY != GD_LAY_KC || BK == 32, "the XOR swizzle assumes 8 slots (32 floats) per row");
+    static_assert(R % 8 == 0, "tile rows must be a multiple of 8");
+    static constexpr int LD = (LAY == GD_LAY_KC) ? BK : (R + 4);
     static constexpr int FLOATS = (LAY == GD_LAY_KC) ? R * LD : BK * LD;
     static constexpr int F4 = R * BK / 4;
     static constexpr int NL = (F4 + NTHREADS - 1) / NTHREADS;
+    // float offset of 16-byte slot `slot` (0..7) of row r in a K-contiguous image
+    __device__ static __forceinline__ int kc_off(int r, int slot) { return r * BK + ((slot ^ ((r >> 1) & 7)) << 2); }
 };
 
 // ---- global -> register staging -----------------------------------------------------------
@@ -157,8 +168,8 @@ struct TileStage {
             const int idx = tid + i * NTHREADS;
             if (G::NL * NTHREADS == G::F4 || idx < G::F4) {
                 if (LAY == GD_LAY_KC) {
-                    const int r = idx / (BK / 4), kk = (idx % (BK / 4)) * 4;
-                    *reinterpret_cast<f32x4*>(&lds[r * G::LD + kk]) = reg[i];
+                    const int r = idx / (BK / 4), slot = idx % (BK / 4);
+                    *reinterpret_cast<f32x4*>(&lds[G::kc_off(r, slot)]) = reg[i];
                 } else {
                     const int kk = idx / (R / 4), r = (idx % (R / 4)) * 4;
                     *reinterpret_cast<f32x4*>(&lds[kk * G::LD + r]) = reg[i];
@@ -176,7 +187,7 @@ __device__ __forceinline__ void load_frag(const float* __restrict__ lds, int row
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         if (LAY == GD_LAY_KC) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(&lds[(row_base + t * 16 + r) * G::LD + 16 * c + 4 * q]);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&lds[G::kc_off(row_base + t * 16 + r, 4 * c + q)]);
             f[t][0] = v.x;
             f[t][1] = v.y;
             f[t][2] = v.z;
