@@ -87,6 +87,7 @@ struct GdGemm {
     int ld_rowpart;
     int accumulate;
     int prof_tag;
+    int stagger;  // startup delay (x512 clocks) for workgroups in odd wave slots; de-phases co-resident workgroups
 };
 
 // shape classes: 0 = "batch-M" (BM=80, BN=128), 1 = square 128x128, 2 = small 64x64

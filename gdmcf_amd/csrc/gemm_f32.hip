@@ -50,7 +50,12 @@ typedef f32x4 f32x4_u __attribute__((aligned(4)));
 // compiler, the waits degenerate to vmcnt(0..4) at joins/back-edges and drain the second stage.
 __device__ __forceinline__ f32x4 gload16(const float* p) {
     f32x4 v;
+#ifdef GD_PROBE_NO_GLOBAL  // tools/gemm_probe.hip ablation only
+    v = f32x4{1.f, 1.f, 1.f, 1.f};
+    asm volatile("" : "+v"(v) : "v"(p));
+#else
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+#endif
     return v;
 }
 
@@ -137,6 +142,28 @@ struct TileStage {
     }
 
     int mode, m_row0, m_nrows, m_k0, m_kend;  // how this stage was loaded (wave-uniform), for store()
+
+    // --- per-slot interface of the hand-interleaved steady-state loop (interior tiles only) ---
+    // source address of slot i for the K tile starting at k0 (rows of K-contiguous operands clamped)
+    static __device__ __forceinline__ const float* slot_ptr(const float* __restrict__ P, int64_t ld, int row0,
+                                                            int nrows, int k0, int i, int tid) {
+        int idx = tid + i * NTHREADS;
+        if (G::NL * NTHREADS != G::F4) idx = min(idx, G::F4 - 1);
+        if (LAY == GD_LAY_KC) {
+            const int r = idx / (BK / 4), kk = (idx % (BK / 4)) * 4;
+            return P + (int64_t)min(row0 + r, nrows - 1) * ld + (k0 + kk);
+        }
+        const int kk = idx / (R / 4), r = (idx % (R / 4)) * 4;
+        return P + (int64_t)(k0 + kk) * ld + (row0 + r);
+    }
+    static __device__ __forceinline__ int64_t tile_step(int64_t ld) { return (LAY == GD_LAY_KC) ? BK : (int64_t)BK * ld; }
+    // LDS float offset of slot i (-1: this thread has no element in the partial last slot)
+    static __device__ __forceinline__ int slot_lds(int i, int tid) {
+        const int idx = tid + i * NTHREADS;
+        if (G::NL * NTHREADS != G::F4 && idx >= G::F4) return -1;
+        if (LAY == GD_LAY_KC) return G::kc_off(idx / (BK / 4), idx % (BK / 4));
+        return (idx / (R / 4)) * G::LD + (idx % (R / 4)) * 4;
+    }
 
     // Pins the stage registers behind a wait the caller has just executed (the asm is empty; the "+v"
     // operands make every register of the stage opaque at this point, guide 5.7 form ii).
@@ -249,6 +276,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GdGemm g) {
     // its MFMA pipes busy, one tile ahead only gives half of that (measured: 40-60 % MFMA busy).
     TileStage<LAYA, BM, BK> sa0, sa1;
     TileStage<LAYB, BN, BK> sb0, sb1;
+    if (g.stagger > 0) {
+        // Two workgroups share a CU and run identical code from the same start: left alone they stay in
+        // lockstep (both in the MFMA phase, then both in the load/LDS phase, matrix pipe idle).  Delaying the
+        // workgroup that sits in the odd wave slots by part of an iteration makes the phases complementary.
+        const unsigned slot = __builtin_amdgcn_s_getreg((4) | (0 << 6) | ((4 - 1) << 11));  // HW_ID.wave_id
+        if (slot & 1u)
+            for (int i = 0; i < g.stagger; ++i) __builtin_amdgcn_s_sleep(8);
+    }
     const bool a_full = (m0 + BM <= g.M), b_full = (n0 + BN <= g.N);
     float* const L0 = smem;
     float* const L1 = smem + STAGE_FLOATS;
@@ -258,8 +293,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GdGemm g) {
 #pragma unroll
         for (int c = 0; c < BK / 16; ++c) {
             float fa[TM][4], fb[TN][4];
+#ifdef GD_PROBE_NO_LDSREAD
+            // ablation: operands stay whatever they were (uninitialised registers), no LDS traffic at all
+            for (int i = 0; i < TM; ++i) for (int s = 0; s < 4; ++s) asm volatile("" : "=v"(fa[i][s]));
+            for (int j = 0; j < TN; ++j) for (int s = 0; s < 4; ++s) asm volatile("" : "=v"(fb[j][s]));
+#else
             load_frag<LAYA, BM, BK, TM>(As, wm0, c, r, q, fa);
             load_frag<LAYB, BN, BK, TN>(Bs, wn0, c, r, q, fb);
+#endif
+#ifdef GD_PROBE_NO_MFMA
+            for (int s = 0; s < 4; ++s) for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) acc[i][j][s] += fa[i][s] + fb[j][s];
+#else
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -267,11 +311,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GdGemm g) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+#endif
         }
     };
 
     constexpr int LOADS_PER_TILE = GA::NL + GB::NL;
 #define GD_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+#ifdef GD_PROBE_NO_BARRIER
+#define __syncthreads() ((void)0)
+#endif
     if (nt > 0) {
         sa0.load(g.A, g.lda, m0, g.M, kbeg, kend, kbeg, a_full, tid);
         sb0.load(g.B, g.ldb, n0, g.N, kbeg, kend, kbeg, b_full, tid);
@@ -289,7 +337,83 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GdGemm g) {
     }
     __syncthreads();
 
-    for (int it = 0; it < nt; it += 2) {
+    int it = 0;
+    // ---- hand-interleaved steady state -----------------------------------------------------------------
+    // Measured (tools/gemm_probe): with the loads, the counted wait and the LDS writes sitting in one block
+    // after 80 back-to-back MFMAs, time = MFMA time + everything-else time; the second resident wave hides
+    // little of it.  Here the same work is threaded through the MFMA stream of the wave itself: the 7 loads of
+    // tile it+2 ride in the first half (k-chunk 0), the 7 LDS writes of tile it+1 in the second half, the
+    // fragments of chunk 1 are fetched during chunk 0.  sched_barrier(0) pins the order.  Interior tiles
+    // only; the generic loop below finishes the tail (and runs boundary workgroups entirely).
+    const int nt_full = (kend - kbeg) / BK;
+    if ((LAYA == GD_LAY_KC || a_full) && (LAYB == GD_LAY_KC || b_full) && nt_full >= 4) {
+        const float* pa[GA::NL];
+        const float* pb[GB::NL];
+        int wa[GA::NL], wb[GB::NL];
+#pragma unroll
+        for (int i = 0; i < GA::NL; ++i) {
+            pa[i] = TileStage<LAYA, BM, BK>::slot_ptr(g.A, g.lda, m0, g.M, kbeg + 2 * BK, i, tid);
+            wa[i] = TileStage<LAYA, BM, BK>::slot_lds(i, tid);
+        }
+#pragma unroll
+        for (int i = 0; i < GB::NL; ++i) {
+            pb[i] = TileStage<LAYB, BN, BK>::slot_ptr(g.B, g.ldb, n0, g.N, kbeg + 2 * BK, i, tid);
+            wb[i] = TileStage<LAYB, BN, BK>::slot_lds(i, tid);
+        }
+        const int64_t stepa = TileStage<LAYA, BM, BK>::tile_step(g.lda), stepb = TileStage<LAYB, BN, BK>::tile_step(g.ldb);
+        constexpr int NLT = GA::NL + GB::NL;  // loads (and LDS writes) per tile and thread
+        constexpr int NCH = BK / 16;          // k-chunks per tile, 4 MFMA groups each
+        constexpr int NG = 4 * NCH;           // MFMA groups per tile
+        constexpr int HG = NG / 2;            // loads ride in groups [0,HG), LDS writes in [HG,NG)
+        constexpr int PER = (NLT + HG - 1) / HG;
+
+        // one half-iteration: compute tile from Lc, load next-next tile into (la, lb), write (sa_, sb_) to Ln
+#define GD_HALF(Lc, Ln, la, lb, sa_, sb_)                                                                          \
+        {                                                                                                          \
+            float fra[2][TM][4], frb[2][TN][4];                                                                    \
+            load_frag<LAYA, BM, BK, TM>(Lc, wm0, 0, r, q, fra[0]);                                                 \
+            load_frag<LAYB, BN, BK, TN>(Lc + GA::FLOATS, wn0, 0, r, q, frb[0]);                                    \
+            _Pragma("unroll") for (int gi = 0; gi < NG; ++gi) {                                                    \
+                const int ch = gi >> 2, sgrp = gi & 3;                                                             \
+                if (gi == HG) {                                                                                    \
+                    GD_WAIT_VM(NLT); /* the tile loaded one half-iteration ago has landed; the new one flies */    \
+                    sa_.pin();                                                                                     \
+                    sb_.pin();                                                                                     \
+                }                                                                                                  \
+                _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                     \
+                    _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                 \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fra[ch & 1][i][sgrp], frb[ch & 1][j][sgrp], acc[i][j], 0, 0, 0); \
+                if (gi < HG) {                                                                                     \
+                    _Pragma("unroll") for (int u = gi * PER; u < (gi + 1) * PER && u < NLT; ++u) {                  \
+                        if (u < GA::NL) { la.reg[u] = gload16(pa[u]); pa[u] += stepa; }                             \
+                        else { lb.reg[u - GA::NL] = gload16(pb[u - GA::NL]); pb[u - GA::NL] += stepb; }             \
+                    }                                                                                              \
+                } else {                                                                                           \
+                    _Pragma("unroll") for (int u = (gi - HG) * PER; u < (gi - HG + 1) * PER && u < NLT; ++u) {      \
+                        if (u < GA::NL) { if (wa[u] >= 0) *reinterpret_cast<f32x4*>(&(Ln)[wa[u]]) = sa_.reg[u]; }   \
+                        else if (wb[u - GA::NL] >= 0)                                                               \
+                            *reinterpret_cast<f32x4*>(&(Ln)[GA::FLOATS + wb[u - GA::NL]]) = sb_.reg[u - GA::NL];    \
+                    }                                                                                              \
+                }                                                                                                  \
+                if (sgrp == 1 && ch + 1 < NCH) { /* fetch the next chunk's fragments under this chunk's MFMAs */  \
+                    load_frag<LAYA, BM, BK, TM>(Lc, wm0, ch + 1, r, q, fra[(ch + 1) & 1]);                         \
+                    load_frag<LAYB, BN, BK, TN>(Lc + GA::FLOATS, wn0, ch + 1, r, q, frb[(ch + 1) & 1]);            \
+                }                                                                                                  \
+                __builtin_amdgcn_sched_barrier(0);                                                                 \
+            }                                                                                                      \
+            __syncthreads();                                                                                       \
+        }
+        // invariant at the top (even `it`): L0 holds tile it, stage-1 registers hold tile it+1 (in flight),
+        // stage-0 registers are free; tiles it+2 and it+3 are interior.
+        for (; it + 3 < nt_full; it += 2) {
+            GD_HALF(L0, L1, sa0, sb0, sa1, sb1);  // tile it;   loads tile it+2 -> stage 0, writes tile it+1 -> L1
+            GD_HALF(L1, L0, sa1, sb1, sa0, sb0);  // tile it+1; loads tile it+3 -> stage 1, writes tile it+2 -> L0
+        }
+#undef GD_HALF
+        sa0.mode = sb0.mode = sa1.mode = sb1.mode = 0;
+    }
+
+    for (; it < nt; it += 2) {
         // even tile `it`: LDS stage 0; stage-1 registers hold tile it+1 (in flight); stage-0 registers are free
         const bool ld2 = (it + 2 < nt);
         if (ld2) {
@@ -325,6 +449,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GdGemm g) {
     }
     GD_WAIT_VM(0);
 #undef GD_WAIT_VM
+#ifdef GD_PROBE_NO_BARRIER
+#undef __syncthreads
+#endif
 
     // ---- epilogue.  acc[i][j][e] = C[m0+wm0+16i+4q+e][n0+wn0+16j+r] ----
     // Branch-free on the load side: every read (bias, target, x_t, z, per-row coefficients) uses indices
@@ -456,13 +583,13 @@ template <int LAYA, int LAYB, int BM, int BN, int BK, int WM, int WN, int EPI>
 int launch_one(GdGemm& g, hipStream_t s) {
     using GA = TileGeom<LAYA, BM, BK>;
     using GB = TileGeom<LAYB, BN, BK>;
-    constexpr size_t lds = (size_t)2 * (GA::FLOATS + GB::FLOATS) * sizeof(float);
-    static_assert(lds <= 160 * 1024, "LDS budget");
+    static const size_t lds_pad = getenv("GD_LDS_PAD") ? (size_t)atoi(getenv("GD_LDS_PAD")) : 0;  // occupancy experiments
+    const size_t lds = (size_t)2 * (GA::FLOATS + GB::FLOATS) * sizeof(float) + lds_pad;
     auto kern = gemm_f32_kernel<LAYA, LAYB, BM, BN, BK, WM, WN, EPI>;
     static bool attr_set = false;
     if (!attr_set && lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) {
             gdmcf_set_error("hipFuncSetAttribute(LDS=%zu): %s", lds, hipGetErrorString(e));
             return GDMCF_E_HIP;
@@ -504,8 +631,10 @@ int gd_gemm_bk(int layA, int layB) { return (layA == GD_LAY_MC && layB == GD_LAY
 
 int gd_pick_shape_class(int M, int N) {
     if (M <= 64 || N <= 64) return 2;
-    const int pad80 = gd_cdiv(M, 80) * 80, pad128 = gd_cdiv(M, 128) * 128;
-    return pad80 < pad128 ? 0 : 1;
+    // 128-row tiles reuse each B fragment over more rows (measured 101 vs 92 TF on the dW products); the
+    // 80-row tile exists for batch-sized M such as 400 = 5 x 80 where 128 would pad by 28 %.
+    const long pad80 = (long)gd_cdiv(M, 80) * 80, pad128 = (long)gd_cdiv(M, 128) * 128;
+    return (pad128 * 100 <= pad80 * 103) ? 1 : 0;
 }
 
 int gd_gemm_launch(int layA, int layB, int epi, int cls, GdGemm& g, hipStream_t s) {
