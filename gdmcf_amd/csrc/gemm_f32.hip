@@ -494,37 +494,36 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GdGemm g) {
                 }
             }
     } else {
-        // LOSS / POST: phase 1 -- all auxiliary loads; phase 2 -- arithmetic + predicated stores
-        float av[TM][4][TN];   // target (LOSS) or x_t (POST)
-        float zv[TM][4][TN];   // z noise (POST with sampling noise)
-        float c1v[TM][4], c2v[TM][4], p1v[TM][4], p2v[TM][4], sgv[TM][4];
+        // LOSS / POST, one 16-row block at a time: phase 1 -- all auxiliary loads of the block (4*TN per
+        // array, in flight together); phase 2 -- arithmetic + predicated stores.
         const bool has_z = (EPI == GD_EPI_POST) && (g.aux2 != nullptr);
         const bool has_r = (EPI == GD_EPI_POST) && (g.r2 != nullptr);
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i) {
+            float av[4][TN];  // target (LOSS) or x_t (POST)
+            float zv[4][TN];  // z noise (POST with sampling noise)
+            float c1v[4], c2v[4], p1v[4], p2v[4], sgv[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int mc = min(m0 + wm0 + 16 * i + 4 * q + e, g.M - 1);
-                c1v[i][e] = 1.f; c2v[i][e] = 0.f; p1v[i][e] = 0.f; p2v[i][e] = 0.f; sgv[i][e] = 0.f;
+                c1v[e] = 1.f; c2v[e] = 0.f; p1v[e] = 0.f; p2v[e] = 0.f; sgv[e] = 0.f;
                 if (EPI == GD_EPI_LOSS) {
-                    if (g.r0) c1v[i][e] = g.r0[mc];  // alpha
+                    if (g.r0) c1v[e] = g.r0[mc];  // alpha
                 } else {
-                    c1v[i][e] = g.r0[mc];
-                    c2v[i][e] = g.r1[mc];
+                    c1v[e] = g.r0[mc];
+                    c2v[e] = g.r1[mc];
                     if (has_r) {
-                        p1v[i][e] = g.r2[mc];
-                        p2v[i][e] = g.r3[mc];
+                        p1v[e] = g.r2[mc];
+                        p2v[e] = g.r3[mc];
                     }
-                    if (has_z) sgv[i][e] = g.r4[mc];
+                    if (has_z) sgv[e] = g.r4[mc];
                 }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    av[i][e][j] = g.aux[(int64_t)mc * g.ldaux + ncl[j]];
-                    zv[i][e][j] = has_z ? g.aux2[(int64_t)mc * g.ldaux2 + ncl[j]] : 0.f;
+                    av[e][j] = g.aux[(int64_t)mc * g.ldaux + ncl[j]];
+                    zv[e][j] = has_z ? g.aux2[(int64_t)mc * g.ldaux2 + ncl[j]] : 0.f;
                 }
             }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int m = m0 + wm0 + 16 * i + 4 * q + e;
@@ -535,17 +534,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GdGemm g) {
                     const bool ok = mok && nok[j];
                     const float v = acc[i][j][e] + biasv[j];
                     if (EPI == GD_EPI_LOSS) {
-                        const float d = c1v[i][e] * v - av[i][e][j];
+                        const float d = c1v[e] * v - av[e][j];
                         if (ok) {
                             if (g.out2) g.out2[(int64_t)m * g.ldout2 + ncl[j]] = v;
                             g.C[(int64_t)m * g.ldc + ncl[j]] = d;
                             racc += d * d;
                         }
                     } else {
-                        const float xt = av[i][e][j];
-                        const float pred = has_r ? (p1v[i][e] * xt - p2v[i][e] * v) : v;
-                        float mean = c1v[i][e] * pred + c2v[i][e] * xt;
-                        if (has_z) mean += sgv[i][e] * zv[i][e][j];
+                        const float xt = av[e][j];
+                        const float pred = has_r ? (p1v[e] * xt - p2v[e] * v) : v;
+                        float mean = c1v[e] * pred + c2v[e] * xt;
+                        if (has_z) mean += sgv[e] * zv[e][j];
                         if (ok) {
                             if (g.out2) g.out2[(int64_t)m * g.ldout2 + ncl[j]] = pred;
                             g.C[(int64_t)m * g.ldc + ncl[j]] = mean;
@@ -554,6 +553,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GdGemm g) {
                 }
                 rowacc[i][e] = racc;
             }
+        }
     }
     if (EPI == GD_EPI_LOSS) {
         // per-row sum of squares: 16 lanes (r) of each q-group hold one row's columns

@@ -230,34 +230,46 @@ __global__ __launch_bounds__(256) void rowscale_kernel(const float* __restrict__
     out[(int64_t)m * ldo + k] = A[(int64_t)m * lda + k] * rs[m];
 }
 
-// db[n] = sum_m rs[m]*dZ[m,n]; rows in fixed order, 8 independent loads in flight per thread
+// db[n] = sum_m rs[m]*dZ[m,n].  One workgroup per 64 columns; wave w sums rows w, w+4, ... (each row read
+// is one coalesced 256-B segment, 8 of them in flight), then the four partial sums are added in wave order.
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dZ, int64_t ld,
                                                      const float* __restrict__ rs, int M, int N,
                                                      float* __restrict__ db) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + lane;
+    const int nc = min(n, N - 1);
     float s = 0.f;
-    int m = 0;
-    for (; m + 8 <= M; m += 8) {
+    int m = wave;
+    for (; m + 28 < M; m += 32) {
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = dZ[(int64_t)(m + j) * ld + n] * (rs ? rs[m + j] : 1.f);
+        for (int j = 0; j < 8; ++j) v[j] = dZ[(int64_t)(m + 4 * j) * ld + nc] * (rs ? rs[m + 4 * j] : 1.f);
 #pragma unroll
         for (int j = 0; j < 8; ++j) s += v[j];
     }
-    for (; m < M; ++m) s += dZ[(int64_t)m * ld + n] * (rs ? rs[m] : 1.f);
-    db[n] = s;
+    for (; m < M; m += 4) s += dZ[(int64_t)m * ld + nc] * (rs ? rs[m] : 1.f);
+    part[wave][lane] = s;
+    __syncthreads();
+    if (wave == 0 && n < N) db[n] = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
 }
 
-// demb[m,e] = sum_n dZ1[m,n] * W1[n, I+e]   (one workgroup per row m, one wave slice per e)
+// W1e[n, e] = W1[n, I+e]: the E embedding columns of the first layer gathered into a compact [N, E] block
+__global__ __launch_bounds__(256) void emb_gather_w_kernel(const float* __restrict__ W1, int64_t ldw, int I, int E, int N,
+                                                           float* __restrict__ W1e) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < N * E) W1e[idx] = W1[(int64_t)(idx / E) * ldw + I + (idx % E)];
+}
+
+// demb[m,e] = sum_n dZ1[m,n] * W1e[n,e]   (one workgroup per row m, waves stride over e)
 __global__ __launch_bounds__(256) void emb_bwd_demb_kernel(const float* __restrict__ dZ1, int64_t lddz,
-                                                           const float* __restrict__ W1, int64_t ldw, int I, int E,
-                                                           int N, float* __restrict__ demb) {
+                                                           const float* __restrict__ W1e, int E, int N,
+                                                           float* __restrict__ demb) {
     const int m = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int e = wave; e < E; e += 4) {
         float s = 0.f;
-        for (int n = lane; n < N; n += 64) s += dZ1[(int64_t)m * lddz + n] * W1[(int64_t)n * ldw + I + e];
+        for (int n = lane; n < N; n += 64) s += dZ1[(int64_t)m * lddz + n] * W1e[(int64_t)n * E + e];
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
         if (lane == 0) demb[(int64_t)m * E + e] = s;
     }
@@ -581,7 +593,9 @@ int gdmcf_emb_bwd_f32(const float* dZ1, int64_t lddz, const float* W1, int64_t l
                       int M, int N, float* demb_ws, float* dWe, float* dbe, void* stream) {
     GD_CHECK_SHAPE(M > 0 && N > 0 && E > 0 && ldw >= I + E && lddz >= N, "emb_bwd: bad shape");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(emb_bwd_demb_kernel, dim3(M), dim3(256), 0, s, dZ1, lddz, W1, ldw, I, E, N, demb_ws);
+    float* W1e = demb_ws + (size_t)M * E;  // demb_ws holds [M*E] demb followed by [N*E] gathered weights
+    hipLaunchKernelGGL(emb_gather_w_kernel, dim3(gd_cdiv(N * E, 256)), dim3(256), 0, s, W1, ldw, I, E, N, W1e);
+    hipLaunchKernelGGL(emb_bwd_demb_kernel, dim3(M), dim3(256), 0, s, dZ1, lddz, W1e, E, N, demb_ws);
     hipLaunchKernelGGL(emb_bwd_w_kernel, dim3(E * E + E), dim3(64), 0, s, demb_ws, temb, M, E, dWe, dbe);
     return gd_launch_status("emb_bwd");
 }
@@ -660,7 +674,7 @@ int gd_splitk_reduce(const float* slabs, int64_t slab_stride, int splits, int64_
 }
 
 int gd_colsum(const float* dZ, int64_t ld, const float* rs, int M, int N, float* db, hipStream_t s) {
-    hipLaunchKernelGGL(colsum_kernel, dim3(gd_cdiv(N, 256)), dim3(256), 0, s, dZ, ld, rs, M, N, db);
+    hipLaunchKernelGGL(colsum_kernel, dim3(gd_cdiv(N, 64)), dim3(256), 0, s, dZ, ld, rs, M, N, db);
     return gd_launch_status("colsum");
 }
 

@@ -81,7 +81,7 @@ class DenoiserEngine:
         b.gradcoef = torch.zeros(B, **f32)
         b.rowdiv_mse = torch.full((B,), float(I), **f32)
         b.lu = torch.zeros(B, dtype=torch.float64, device=device)
-        b.demb = torch.zeros(B, max(E, 1), **f32)
+        b.demb = torch.zeros((B + layers[0][0].shape[0]) * max(E, 1), **f32)  # demb [B,E] + gathered W1[:, I:] [n0,E]
         ws = 0
         for (w, _, _) in layers:
             ws = max(ws, lib.gdmcf_linear_ws_bytes(B, w.shape[0], w.shape[1]))

@@ -30,12 +30,16 @@ class FusedAdamW(torch.optim.Optimizer):
                          p.numel(), blk))
             blk += (p.numel() + _BLOCK - 1) // _BLOCK
         key = tuple(rows)
-        cached = self._tables.get(gi)
-        if cached is None or cached[0] != key:
-            host = torch.tensor(rows, dtype=torch.int64)
-            cached = (key, host.to(plist[0].device), blk)
-            self._tables[gi] = cached
-        return cached[1], cached[2]
+        cache = self._tables.setdefault(gi, {})
+        hit = cache.get(key)
+        if hit is None:
+            # gradients are fresh tensors every step; the caching allocator cycles through a handful of
+            # addresses, so after a few steps every combination is resident and no H2D copy happens
+            if len(cache) >= 16:
+                cache.clear()
+            hit = (torch.tensor(rows, dtype=torch.int64).to(plist[0].device), blk)
+            cache[key] = hit
+        return hit
 
     @torch.no_grad()
     def step(self, closure=None):

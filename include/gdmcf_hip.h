@@ -137,7 +137,8 @@ int gdmcf_linear_bwd_weight_f32(const float* dZ, int64_t lddz, const float* A, i
 int gdmcf_rowscale_f32(const float* A, int64_t lda, const float* rowscale, int M, int K, float* out,
                        int64_t ldo, void* stream);
 /* Gradients of the timestep-embedding branch (models/DNN.py:73-74,78):
- *   demb[m,e] = sum_n dZ1[m,n]*W1[n, I+e] ;  dWe = demb^T @ temb ;  dbe = sum_m demb       */
+ *   demb[m,e] = sum_n dZ1[m,n]*W1[n, I+e] ;  dWe = demb^T @ temb ;  dbe = sum_m demb
+ * demb_ws: float32 scratch of (M + N) * E elements.                                         */
 int gdmcf_emb_bwd_f32(const float* dZ1, int64_t lddz, const float* W1, int64_t ldw, int I, int E,
                       const float* temb, int M, int N, float* demb_ws, float* dWe, float* dbe,
                       void* stream);
