@@ -1,0 +1,63 @@
+"""The training / evaluation loop surface of the reference driver (reference main.py:267-351), restated
+on top of the HIP path.  Host glue only: batches in, metrics out.
+
+* `train_one_epoch`  = main.py:327-351 (the body that is dead code behind a stray `continue` in the
+  shipped file): zero_grad -> training_losses -> mean -> backward -> step per batch.
+* `evaluate`         = main.py:267-310: p_sample -> history mask -> top-N -> computeTopNAccuracy.
+  The reference moves a dense [B, I] row block to the device per batch and masks with
+  `prediction[his_data.nonzero()] = -inf`; here the history stays CSR and the mask is applied inside the
+  top-k kernel.
+"""
+import numpy as np
+import torch
+
+from . import evaluate_utils
+from .evaluate_utils import masked_topk
+from .parallel import DataParallelStep
+
+
+def dense_rows(csr, rows, device):
+    """float32 dense [len(rows), n_items] block of a scipy CSR matrix, on `device` (what DataDiffusion +
+    DataLoader deliver in the reference, data_utils.py:216-226)."""
+    return torch.from_numpy(np.asarray(csr[rows].todense(), dtype=np.float32)).to(device)
+
+
+def train_one_epoch(diffusion, model, optimizer, train_csr, batch_size, device, reweight=True, shuffle=True,
+                    drop_last=True, generator=None, step=None):
+    """One pass over the users of `train_csr`.  Returns (sum of batch losses, number of batches), the two
+    numbers the reference prints per epoch (main.py:377)."""
+    model.train()
+    n = train_csr.shape[0]
+    order = torch.randperm(n, generator=generator).numpy() if shuffle else np.arange(n)
+    step = step or DataParallelStep(diffusion, model, optimizer)
+    total, count = None, 0
+    for lo in range(0, n, batch_size):
+        rows = order[lo:lo + batch_size]
+        if drop_last and len(rows) < batch_size:
+            break
+        batch = dense_rows(train_csr, rows, device)
+        loss = step(batch, reweight)
+        total = loss if total is None else total + loss
+        count += 1
+    return (float(total) if total is not None else 0.0), count
+
+
+@torch.no_grad()
+def evaluate(diffusion, model, data_csr, data_te, mask_his, topN, sampling_steps, sampling_noise, batch_size,
+             device):
+    """Precision / Recall / NDCG / MRR @topN exactly as reference main.py:267-310.
+
+    data_csr: rows fed to p_sample (the reference feeds the training rows); data_te: ground-truth CSR;
+    mask_his: CSR of interactions to exclude from the ranking."""
+    model.eval()
+    n = mask_his.shape[0]
+    target_items = [data_te[i, :].nonzero()[1].tolist() for i in range(n)]
+    predict_items = []
+    for lo in range(0, n, batch_size):
+        rows = np.arange(lo, min(lo + batch_size, n))
+        batch = dense_rows(data_csr, rows, device)
+        prediction = diffusion.p_sample(model, batch, sampling_steps, sampling_noise)
+        indptr, cols = evaluate_utils.csr_rows_to_device(mask_his, rows, device)
+        indices = masked_topk(prediction, topN[-1], indptr, cols)
+        predict_items.extend(indices.cpu().numpy().tolist())
+    return evaluate_utils.computeTopNAccuracy(target_items, predict_items, topN)

@@ -400,3 +400,56 @@ def test_full_size_step_matches_oracle_yelp_shape():
         assert dp.max() < 0.25 * 1e-5, k
         assert (not big.any()) or dp[big].max() < 0.01 * 1e-5, k
     np.testing.assert_allclose(gdif.Lt_history.cpu().numpy(), od.Lt_history.numpy(), rtol=1e-4)
+
+
+def test_driver_train_and_evaluate_match_oracle_loop():
+    """reference main.py:327-351 + :267-310 end to end on a small synthetic problem: the HIP driver and the
+    oracle loop start from the same weights, see the same batches and the same injected randomness, and must
+    report the same Recall/NDCG@N."""
+    import scipy.sparse as sp
+    from gdmcf_amd import driver
+    rng = np.random.default_rng(0)
+    U, I, hid, T, B = 96, 300, 48, 5, 32
+    dense = (rng.random((U, I)) < 0.06).astype(np.float32)
+    test = ((rng.random((U, I)) < 0.03) & (dense == 0)).astype(np.float32)
+    train_csr, test_csr = sp.csr_matrix(dense), sp.csr_matrix(test)
+    torch.manual_seed(0)
+    om = O.DNN([I, hid], [hid, I], 10)
+    gm = gdmcf_amd.DNN([I, hid], [hid, I], 10)
+    gm.load_state_dict(om.state_dict())
+    gm = gm.to(DEV)
+    od = O.GaussianDiffusion(O.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, T)
+    gd_ = gdmcf_amd.GaussianDiffusion(ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, T, DEV)
+    oopt = O.make_optimizer(om, 1e-3)
+    gopt = gdmcf_amd.FusedAdamW(gm.parameters(), lr=1e-3, weight_decay=0.0)
+    g = torch.Generator().manual_seed(5)
+    om.train(), gm.train()
+    for epoch in range(3):  # the same three epochs on both sides, randomness injected
+        for lo in range(0, U, B):
+            x = torch.from_numpy(dense[lo:lo + B])
+            ts = torch.randint(0, T, (B,), generator=g)
+            noise = torch.randn(B, I, generator=g)
+            keep = (torch.rand(B, I, generator=g) < 0.5).float()
+            O.train_step(od, om, oopt, x, True, ts=ts, pt=torch.ones(B), noise=noise, drop_mask=keep)
+            gopt.zero_grad()
+            l = gd_.training_losses(gm, cu(x), True, ts=cu(ts), pt=cu(torch.ones(B)), noise=cu(noise), drop_mask=cu(keep))
+            l["loss"].mean().backward()
+            gopt.step()
+    topN = [10, 20, 50]
+    res = driver.evaluate(gd_, gm, train_csr, test_csr, train_csr, topN, 0, False, B, DEV)
+    # the oracle's evaluate loop
+    om.eval()
+    preds = []
+    with torch.no_grad():
+        for lo in range(0, U, B):
+            x = torch.from_numpy(dense[lo:lo + B])
+            p = od.p_sample(om, x, 0, False)
+            rows, cols = x.nonzero(as_tuple=True)
+            preds.extend(O.masked_topk(p, rows, cols, topN[-1]).tolist())
+    gt = [test_csr[i, :].nonzero()[1].tolist() for i in range(U)]
+    ref = O.computeTopNAccuracy(gt, preds, topN)
+    # three Adam steps amplify fp32 noise a little: metrics (4 decimals, averaged over 96 users) agree to 1e-3
+    np.testing.assert_allclose(np.array(res), np.array(ref), rtol=0, atol=1.1e-3)
+    # unseeded smoke of the epoch loop itself (Philox path): runs, finite, counts batches
+    total, count = driver.train_one_epoch(gd_, gm, gopt, train_csr, B, DEV, generator=torch.Generator().manual_seed(1))
+    assert count == U // B and np.isfinite(total)
