@@ -244,20 +244,37 @@ __global__ __launch_bounds__(256) void spmm_generic_kernel(const int64_t* __rest
     }
 }
 
-// rows that were split: Y[r] = (sum of their partial slots, in order, + addends) * scale
+// rows that were split: Y[r] = (sum of their partial slots + addends) * scale.  One workgroup per split
+// row: wave w adds slots w, w+4, ... (independent loads, 4 in flight), the four partial sums are added in
+// wave order -> fixed summation order, no atomics.
 __global__ __launch_bounds__(256) void spmm_combine_kernel(const int32_t* __restrict__ lrow,
                                                            const int32_t* __restrict__ lptr, int n_long,
                                                            const float* __restrict__ partial, int d,
                                                            float* __restrict__ Y, int64_t ldy, const SpmmAdd add) {
-    const int lane = threadIdx.x & 63;
-    const int l = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (l >= n_long) return;
+    extern __shared__ float comb[];  // [4][d]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l = blockIdx.x;
     const int r = lrow[l];
+    const int beg = lptr[l], end = lptr[l + 1];
     for (int c0 = lane; c0 < d; c0 += 64) {
-        float s = 0.f;
-        for (int k = lptr[l]; k < lptr[l + 1]; ++k) s += partial[(int64_t)k * d + c0];
-        for (int k = 0; k < add.n; ++k) s += add.p[k][(int64_t)r * add.ld + c0];
-        Y[(int64_t)r * ldy + c0] = s * add.scale;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int k = beg + wave;
+        for (; k + 12 < end; k += 16) {
+            s0 += partial[(int64_t)k * d + c0];
+            s1 += partial[(int64_t)(k + 4) * d + c0];
+            s2 += partial[(int64_t)(k + 8) * d + c0];
+            s3 += partial[(int64_t)(k + 12) * d + c0];
+        }
+        for (; k < end; k += 4) s0 += partial[(int64_t)k * d + c0];
+        comb[wave * d + c0] = (s0 + s1) + (s2 + s3);
+    }
+    __syncthreads();
+    if (wave == 0) {
+        for (int c0 = lane; c0 < d; c0 += 64) {
+            float s = ((comb[c0] + comb[d + c0]) + comb[2 * d + c0]) + comb[3 * d + c0];
+            for (int k = 0; k < add.n; ++k) s += add.p[k][(int64_t)r * add.ld + c0];
+            Y[(int64_t)r * ldy + c0] = s * add.scale;
+        }
     }
 }
 
@@ -326,8 +343,8 @@ int gdmcf_spmm_csr_f32(const int64_t* vptr, const int32_t* vrow, const int32_t* 
         else GD_SPMM_LAUNCH(spmm_generic_kernel);
 #undef GD_SPMM_LAUNCH
         if (n_long > 0)
-            hipLaunchKernelGGL(spmm_combine_kernel, dim3(gd_cdiv(n_long, 4)), block, 0, s, lrow, lptr, n_long, partial_ws,
-                               d, Y, ldy, add);
+            hipLaunchKernelGGL(spmm_combine_kernel, dim3(n_long), block, (size_t)4 * d * sizeof(float), s, lrow, lptr,
+                               n_long, partial_ws, d, Y, ldy, add);
     }
     return gd_launch_status("spmm_csr");
 }

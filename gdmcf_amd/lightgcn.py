@@ -16,7 +16,9 @@ import torch.nn as nn
 
 from . import _lib
 
-SPMM_CHUNK = 256  # max nonzeros per virtual row
+import os
+
+SPMM_CHUNK = int(os.environ.get("GDMCF_SPMM_CHUNK", "256"))  # max nonzeros per virtual row
 
 
 def normalized_bipartite_csr(users, items, n_users, n_items):
