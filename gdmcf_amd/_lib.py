@@ -27,6 +27,7 @@ _SIGNATURES = {
     "gdmcf_prof_enable": (c_int, [c_int]),
     "gdmcf_prof_collect": (c_int, [c_int, P, P, P]),
     "gdmcf_schedule_build": (c_int, [c_int, c_double, c_double, c_double, c_int, c_int, P]),
+    "gdmcf_densify_rows_f32": (c_int, [P, P, P, P, c_int, c_int, P, c_int64, P]),
     "gdmcf_dnn_prep_input_f32": (c_int, [P, c_int64, P, P, P, c_int, P, c_int64, c_int, P, c_int64, c_float, c_uint64,
                                          c_uint64, c_int, P, P, c_int, c_int, c_int, P, c_int64, P, c_int64, P, P, P]),
     "gdmcf_dnn_emb_cols_f32": (c_int, [P, P, P, c_int, c_int, c_int, P, c_int64, P, P]),

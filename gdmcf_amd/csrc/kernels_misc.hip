@@ -519,6 +519,30 @@ __global__ __launch_bounds__(256) void adamw_kernel(const int64_t* __restrict__ 
     }
 }
 
+// dense[b, :] = row row_ids[b] of a CSR matrix (values NULL -> 1.0).  One workgroup per row: 16-byte zero fill,
+// barrier, scatter of the row's nonzeros.  Replaces scipy .todense() + a 55 MB host-to-device copy per batch.
+__global__ __launch_bounds__(256) void densify_rows_kernel(const int64_t* __restrict__ indptr,
+                                                           const int32_t* __restrict__ indices,
+                                                           const float* __restrict__ values,
+                                                           const int64_t* __restrict__ row_ids, int I,
+                                                           float* __restrict__ out, int64_t ldo) {
+    const int b = blockIdx.x;
+    float* row = out + (int64_t)b * ldo;
+    const bool al = ((reinterpret_cast<uintptr_t>(row) & 15u) == 0);
+    if (al) {
+        for (int i = threadIdx.x * 4; i + 3 < I; i += 1024) *reinterpret_cast<f32x4*>(row + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int i = (I & ~3) + threadIdx.x; i < I; i += 256) row[i] = 0.f;
+    } else {
+        for (int i = threadIdx.x; i < I; i += 256) row[i] = 0.f;
+    }
+    __syncthreads();
+    const int64_t u = row_ids ? row_ids[b] : b;
+    for (int64_t j = indptr[u] + threadIdx.x; j < indptr[u + 1]; j += 256) {
+        const int c = indices[j];
+        if (c >= 0 && c < I) row[c] = values ? values[j] : 1.f;
+    }
+}
+
 __global__ __launch_bounds__(256) void scale_kernel(const float* __restrict__ a, int64_t n, float s,
                                                     float* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -652,6 +676,14 @@ int gdmcf_adamw_f32(const int64_t* table, int n_tensors, int total_blocks, float
         hipLaunchKernelGGL(adamw_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, table, n_tensors, h);
     }
     return gd_launch_status("adamw");
+}
+
+int gdmcf_densify_rows_f32(const int64_t* indptr, const int32_t* indices, const float* values, const int64_t* row_ids,
+                           int B, int I, float* out, int64_t ldo, void* stream) {
+    GD_CHECK_SHAPE(B > 0 && I > 0 && ldo >= I, "densify_rows: bad shape");
+    hipLaunchKernelGGL(densify_rows_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, indptr, indices, values, row_ids,
+                       I, out, ldo);
+    return gd_launch_status("densify_rows");
 }
 
 int gdmcf_scale_f32(const float* acc, int64_t n, float scale, float* out, void* stream) {

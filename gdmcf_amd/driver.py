@@ -12,6 +12,7 @@ import numpy as np
 import torch
 
 from . import evaluate_utils
+from .data_utils import DeviceBatchLoader, DeviceCSR
 from .evaluate_utils import masked_topk
 from .parallel import DataParallelStep
 
@@ -27,15 +28,11 @@ def train_one_epoch(diffusion, model, optimizer, train_csr, batch_size, device, 
     """One pass over the users of `train_csr`.  Returns (sum of batch losses, number of batches), the two
     numbers the reference prints per epoch (main.py:377)."""
     model.train()
-    n = train_csr.shape[0]
-    order = torch.randperm(n, generator=generator).numpy() if shuffle else np.arange(n)
+    loader = DeviceBatchLoader(train_csr, batch_size, shuffle=shuffle, drop_last=drop_last, device=device,
+                               generator=generator)
     step = step or DataParallelStep(diffusion, model, optimizer)
     total, count = None, 0
-    for lo in range(0, n, batch_size):
-        rows = order[lo:lo + batch_size]
-        if drop_last and len(rows) < batch_size:
-            break
-        batch = dense_rows(train_csr, rows, device)
+    for batch, _index in loader:
         loss = step(batch, reweight)
         total = loss if total is None else total + loss
         count += 1
@@ -53,9 +50,10 @@ def evaluate(diffusion, model, data_csr, data_te, mask_his, topN, sampling_steps
     n = mask_his.shape[0]
     target_items = [data_te[i, :].nonzero()[1].tolist() for i in range(n)]
     predict_items = []
+    dcsr = data_csr if isinstance(data_csr, DeviceCSR) else DeviceCSR(data_csr, device)
     for lo in range(0, n, batch_size):
         rows = np.arange(lo, min(lo + batch_size, n))
-        batch = dense_rows(data_csr, rows, device)
+        batch = dcsr.rows(torch.from_numpy(rows))
         prediction = diffusion.p_sample(model, batch, sampling_steps, sampling_noise)
         indptr, cols = evaluate_utils.csr_rows_to_device(mask_his, rows, device)
         indices = masked_topk(prediction, topN[-1], indptr, cols)

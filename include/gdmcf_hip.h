@@ -63,6 +63,14 @@ int gdmcf_prof_collect(int cap, int* tags_host, float* ms_host, double* work_hos
 int gdmcf_schedule_build(int kind, double noise_scale, double noise_min, double noise_max, int T,
                          int beta_fixed, double* out_tables_host);
 
+/* ---- batch provider: dense user rows from a device-resident CSR interaction matrix ----------
+ * replaces DataDiffusion.__getitem__ + DataLoader collation + batch.to(device)
+ * (data_utils.py:216-226, main.py:155,343): out[b, 0:I] = dense row row_ids[b] (row_ids NULL -> b).
+ * indptr int64 [n_users+1], indices int32, values float32 or NULL (all ones); rows must hold each
+ * column at most once (scipy's csr_matrix constructor has already summed duplicates).        */
+int gdmcf_densify_rows_f32(const int64_t* indptr, const int32_t* indices, const float* values,
+                           const int64_t* row_ids, int B, int I, float* out, int64_t ldo, void* stream);
+
 /* ---- denoiser input: q_sample + F.normalize + dropout + timestep embedding + cat ------
  * replaces GaussianDiffusion.q_sample (:399-407) with _extract_into_tensor (:532-547),
  * and DNN.forward's prologue (models/DNN.py:73-78): timestep_embedding (:1806-1825),

@@ -294,8 +294,33 @@ def gen_metrics():
     np.savez_compressed(os.path.join(OUT, "metrics_hand.npz"), **out)
 
 
+def gen_data_load():
+    """reference data_utils.data_load on tiny (uid, iid) lists incl. a duplicated pair; inputs + CSR outputs."""
+    import contextlib
+    import io
+    import tempfile
+    import data_utils as ref_du  # the real reference module
+    rng = np.random.default_rng(3)
+    tr = np.stack([rng.integers(0, 12, 60), rng.integers(0, 9, 60)], axis=1)
+    tr = np.concatenate([tr, tr[:2]])  # duplicates -> value 2.0
+    tr[0] = (11, 8)
+    va = np.stack([rng.integers(0, 12, 10), rng.integers(0, 9, 10)], axis=1)
+    te = np.stack([rng.integers(0, 12, 14), rng.integers(0, 9, 14)], axis=1)
+    with tempfile.TemporaryDirectory() as d:
+        paths = []
+        for n, a in (("train", tr), ("valid", va), ("test", te)):
+            paths.append(os.path.join(d, n + "_list.npy"))
+            np.save(paths[-1], a)
+        with contextlib.redirect_stdout(io.StringIO()):
+            t, v, e, nu, ni = ref_du.data_load(*paths)
+    np.savez_compressed(os.path.join(OUT, "data_load.npz"), train_list=tr, valid_list=va, test_list=te,
+                        train=t.toarray(), valid=v.toarray(), test=e.toarray(), n_user=nu, n_item=ni)
+    print("data_load:", nu, ni, t.max())
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    gen_data_load()
     gen_schedules()
     gen_metrics()
     gen_train("tiny_x0", 8, 64, [16], 5, "x0", seed=1)

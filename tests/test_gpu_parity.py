@@ -453,3 +453,24 @@ def test_driver_train_and_evaluate_match_oracle_loop():
     # unseeded smoke of the epoch loop itself (Philox path): runs, finite, counts batches
     total, count = driver.train_one_epoch(gd_, gm, gopt, train_csr, B, DEV, generator=torch.Generator().manual_seed(1))
     assert count == U // B and np.isfinite(total)
+
+
+def test_device_batch_loader_matches_dense_rows():
+    import scipy.sparse as sp
+    from gdmcf_amd import data_utils
+    fx = H.load("data_load")
+    csr = sp.csr_matrix(fx["train"])  # contains a 2.0 and a 3.0 (duplicated pairs)
+    dcsr = data_utils.DeviceCSR(csr, DEV)
+    ids = torch.tensor([5, 0, 11, 11, 3])
+    np.testing.assert_array_equal(dcsr.rows(ids).cpu().numpy(), fx["train"][ids.numpy()].astype(np.float32))
+    rng = np.random.default_rng(0)
+    big = sp.random(257, 4099, density=0.01, format="csr", random_state=1, data_rvs=lambda n: np.ones(n))
+    loader = data_utils.DeviceBatchLoader(big, 64, shuffle=True, drop_last=True, device=DEV,
+                                          generator=torch.Generator().manual_seed(0))
+    assert len(loader) == 4
+    seen = []
+    for batch, idx in loader:
+        assert batch.shape == (64, 4099) and batch.is_cuda
+        np.testing.assert_array_equal(batch.cpu().numpy(), np.asarray(big[idx.numpy()].todense(), dtype=np.float32))
+        seen.extend(idx.tolist())
+    assert len(set(seen)) == 256

@@ -124,3 +124,21 @@ def test_lightgcn_adjacency_build_matches_reference(case):
     np.testing.assert_array_equal(indices, fx["A_col"])
     np.testing.assert_allclose(vals, fx["A_val"], rtol=2e-7, atol=0)
     assert indptr.dtype == np.int64 and indices.dtype == np.int32 and vals.dtype == np.float32
+
+
+def test_data_load_matches_reference(tmp_path):
+    """reference data_utils.data_load (npy [nnz,2] pairs -> CSR float64, duplicates summed) on the fixture lists."""
+    from gdmcf_amd import data_utils
+    fx = H.load("data_load")
+    paths = []
+    for n in ("train", "valid", "test"):
+        paths.append(str(tmp_path / f"{n}_list.npy"))
+        np.save(paths[-1], fx[f"{n}_list"])
+    tr, va, te, nu, ni = data_utils.data_load(*paths)
+    assert (nu, ni) == (int(fx["n_user"]), int(fx["n_item"]))
+    for got, key in ((tr, "train"), (va, "valid"), (te, "test")):
+        assert got.dtype == np.float64 and got.format == "csr"
+        np.testing.assert_array_equal(got.toarray(), fx[key])
+    ds = data_utils.DataDiffusion(torch.from_numpy(tr.toarray()))
+    row, idx = ds[3]
+    assert idx == 3 and len(ds) == nu and torch.equal(row, torch.from_numpy(tr.toarray())[3])
