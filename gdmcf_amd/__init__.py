@@ -6,6 +6,7 @@ from .gaussian_diffusion import GaussianDiffusion, ModelMeanType  # noqa: F401
 from .optim import FusedAdamW  # noqa: F401
 from .evaluate_utils import computeTopNAccuracy, masked_topk, print_results  # noqa: F401
 from .lightgcn import LightGCN  # noqa: F401
+from . import checkpoint, data_utils, driver, parallel  # noqa: F401
 
 __all__ = ["DNN", "timestep_embedding", "GaussianDiffusion", "ModelMeanType", "FusedAdamW", "computeTopNAccuracy",
            "masked_topk", "print_results", "LightGCN"]

@@ -474,3 +474,45 @@ def test_device_batch_loader_matches_dense_rows():
         np.testing.assert_array_equal(batch.cpu().numpy(), np.asarray(big[idx.numpy()].todense(), dtype=np.float32))
         seen.extend(idx.tolist())
     assert len(set(seen)) == 256
+
+
+def test_checkpoint_resume_is_bit_exact(tmp_path):
+    """2 steps + save + 2 steps  ==  load + 2 steps, bit for bit, on the unseeded Philox path (weights, AdamW
+    moments, Lt-history and the random stream position all restored)."""
+    from gdmcf_amd import checkpoint
+
+    def build():
+        torch.manual_seed(7)
+        m = gdmcf_amd.DNN([515, 64], [64, 515], 10).to(DEV)
+        d = gdmcf_amd.GaussianDiffusion(ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, 5, DEV)
+        o = gdmcf_amd.FusedAdamW(m.parameters(), lr=1e-3, weight_decay=0.01)
+        return m.train(), d, o
+
+    g = torch.Generator().manual_seed(0)
+    xs = [(torch.rand(32, 515, generator=g) < 0.05).float().to(DEV) for _ in range(4)]
+
+    def run(m, d, o, batches):
+        out = []
+        for x in batches:
+            o.zero_grad()
+            l = d.training_losses(m, x, True)["loss"].mean()
+            l.backward()
+            o.step()
+            out.append(float(l.detach()))
+        return out
+
+    m, d, o = build()
+    run(m, d, o, xs[:2])
+    checkpoint.save_checkpoint(tmp_path / "ck.pt", m, d, o, epoch=3)
+    ref_losses = run(m, d, o, xs[2:])
+    m2, d2, o2 = build()
+    epoch, _ = checkpoint.load_checkpoint(tmp_path / "ck.pt", m2, d2, o2)
+    assert epoch == 3
+    got = run(m2, d2, o2, xs[2:])
+    assert got == ref_losses
+    for a, b in zip(m.parameters(), m2.parameters()):
+        assert torch.equal(a, b)
+    assert torch.equal(d.Lt_history, d2.Lt_history) and torch.equal(d.Lt_count, d2.Lt_count)
+    # the model part loads into the oracle (= reference layout) as well
+    om = O.DNN([515, 64], [64, 515], 10)
+    om.load_state_dict(torch.load(tmp_path / "ck.pt", weights_only=False)["model"])
