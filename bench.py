@@ -247,6 +247,7 @@ def bench_spmm(gdmcf_amd, lib, workload, dev, layers=3, d=64, iters=20):
     m = gdmcf_amd.LightGCN({"user_id_idx": users, "item_id_idx": indices}, cfg["n_users"], I, layers, d, device=dev).to(dev)
     nnz = m.nnz
     N = cfg["n_users"] + I
+    torch.set_grad_enabled(False)
     for _ in range(3):
         m.propagate_through_layers()
     torch.cuda.synchronize()
@@ -256,6 +257,7 @@ def bench_spmm(gdmcf_amd, lib, workload, dev, layers=3, d=64, iters=20):
     torch.cuda.synchronize()
     k = collect_prof(lib).get(8)
     lib.gdmcf_prof_enable(0)
+    torch.set_grad_enabled(True)
     ms = k["ms"] / k["n"]
     alg = m.algorithmic_bytes()
     gbps = alg / (ms * 1e-3) / 1e9

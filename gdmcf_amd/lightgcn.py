@@ -92,15 +92,15 @@ class LightGCN(nn.Module):
         return self.nnz * 8.0 + (N + 1) * 8.0 + 2.0 * N * d * 4.0
 
     @torch.no_grad()
-    def propagate_through_layers(self, return_layers=False):
+    def _propagate(self, X, return_layers=False):
+        """mean_l (A~^l X), l = 0..n_layers, through gdmcf_spmm_csr_f32 (layer mean fused into the last SpMM)."""
         lib = _lib.load()
-        E0 = self.E0.weight.detach()
-        _lib.require_gpu(E0, "LightGCN.E0")
+        _lib.require_gpu(X, "LightGCN embeddings")
         _, indices, vals = self.norm_adj_csr
         pl = self._plan
-        N, d = E0.shape
+        N, d = X.shape
         st = _lib.stream_ptr()
-        cur = E0.contiguous()
+        cur = X.contiguous()
         layers = [cur]
         nv, nl = pl["vrow"].numel(), pl["lrow"].numel()
         for layer in range(self.n_layers):
@@ -117,14 +117,71 @@ class LightGCN(nn.Module):
             cur = out
         if return_layers:
             mean = torch.stack(layers).sum(0) / (self.n_layers + 1)  # test/debug path only
-        else:
-            mean = cur if self.n_layers > 0 else E0
-        final_user, final_item = torch.split(mean, [self.n_users, self.n_items])
-        init_user, init_item = torch.split(E0, [self.n_users, self.n_items])
+            return mean, layers[1:]
+        return (cur if self.n_layers > 0 else X), None
+
+    def propagate_through_layers(self, return_layers=False):
+        """(final_user, final_item, initial_user, initial_item) as reference lightGCN.py:180-194.  Differentiable
+        w.r.t. E0 when autograd is on (the backward is the same propagation: A~ is symmetric)."""
+        E0 = self.E0.weight
         if return_layers:
-            return final_user, final_item, init_user, init_item, layers[1:]
+            mean, layers = self._propagate(E0.detach(), return_layers=True)
+        elif torch.is_grad_enabled() and E0.requires_grad:
+            mean, layers = _PropagateMean.apply(self, E0), None
+        else:
+            mean, layers = self._propagate(E0.detach())[0], None
+        final_user, final_item = torch.split(mean, [self.n_users, self.n_items])
+        init_user, init_item = torch.split(E0 if layers is None else E0.detach(), [self.n_users, self.n_items])
+        if return_layers:
+            return final_user, final_item, init_user, init_item, layers
         return final_user, final_item, init_user, init_item
 
     def forward(self, users, pos_items, neg_items):
         fu, fi, iu, ii = self.propagate_through_layers()
         return fu[users], fi[pos_items], fi[neg_items], iu[users], ii[pos_items], ii[neg_items]
+
+
+class _PropagateMean(torch.autograd.Function):
+    """mean over layers of A~^l E0.  d(mean)/d(E0) applied to a cotangent G is mean_l (A~^l)^T G = mean_l A~^l G
+    because the normalised adjacency is symmetric (reference lightGCN.py:149-164): the backward pass is the
+    forward kernel run on the gradient."""
+
+    @staticmethod
+    def forward(ctx, module, E0):
+        ctx.module = module
+        return module._propagate(E0.detach())[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        return None, ctx.module._propagate(g.contiguous())[0]
+
+
+def bpr_loss(users, users_emb, pos_emb, neg_emb, userEmb0, posEmb0, negEmb0):
+    """(mf_loss, reg_loss) of reference lightGCN.py:207-219."""
+    reg_loss = (1 / 2) * (userEmb0.norm().pow(2) + posEmb0.norm().pow(2) + negEmb0.norm().pow(2)) / float(len(users))
+    pos_scores = torch.sum(torch.mul(users_emb, pos_emb), dim=1)
+    neg_scores = torch.sum(torch.mul(users_emb, neg_emb), dim=1)
+    loss = torch.mean(torch.nn.functional.softplus(neg_scores - pos_scores))
+    return loss, reg_loss
+
+
+def sample_bpr_batch(indptr, indices, n_users, n_items, batch_size, rng):
+    """(users, pos_items, neg_items) as the reference sampler (lightGCN.py:221-251, minus its stray
+    pdb.set_trace): sorted users drawn without replacement (with replacement if n_users < batch_size), one random
+    interacted item and one random non-interacted item per user.  Vectorised numpy; `rng` = np.random.Generator."""
+    if n_users < batch_size:
+        users = np.sort(rng.integers(0, n_users, batch_size))
+    else:
+        users = np.sort(rng.choice(n_users, batch_size, replace=False))
+    deg = indptr[users + 1] - indptr[users]
+    if np.any(deg == 0):
+        raise ValueError("sample_bpr_batch: every sampled user needs at least one interaction")
+    pos = indices[indptr[users] + (rng.random(batch_size) * deg).astype(np.int64)]
+    neg = rng.integers(0, n_items, batch_size)
+    for _ in range(64):  # rejection: resample the (few) negatives that hit an interacted item
+        bad = np.array([n in indices[indptr[u]:indptr[u + 1]] for u, n in zip(users, neg)]) if batch_size <= 4096 else \
+            np.zeros(batch_size, bool)
+        if not bad.any():
+            break
+        neg[bad] = rng.integers(0, n_items, int(bad.sum()))
+    return users.astype(np.int64), pos.astype(np.int64), neg.astype(np.int64)

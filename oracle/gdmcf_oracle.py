@@ -430,3 +430,24 @@ def lightgcn_propagate(A_csr, E0, n_layers, n_users):
         acc = acc + L
     mean = (acc / np.float32(len(layers))).astype(np.float32)
     return mean[:n_users], mean[n_users:], E0[:n_users], E0[n_users:], layers
+
+
+def lightgcn_bpr_step(A_csr, E0, n_layers, n_users, users, pos, neg, decay):
+    """One BPR objective evaluation with autograd (reference lightGCN.py:196-219, :291-298): returns
+    (mf_loss, reg_loss, dE0) using torch.sparse.mm on the same normalised adjacency."""
+    coo = A_csr.tocoo()
+    A = torch.sparse_coo_tensor(np.vstack([coo.row, coo.col]), coo.data.astype(np.float32), coo.shape).coalesce()
+    E = torch.tensor(np.asarray(E0, dtype=np.float32), requires_grad=True)
+    layers, cur = [E], E
+    for _ in range(n_layers):
+        cur = torch.sparse.mm(A, cur)
+        layers.append(cur)
+    mean = torch.mean(torch.stack(layers), dim=0)
+    fu, fi = mean[:n_users], mean[n_users:]
+    iu, ii = E[:n_users], E[n_users:]
+    users, pos, neg = (torch.as_tensor(v, dtype=torch.int64) for v in (users, pos, neg))
+    ue, pe, ne, u0, p0, n0 = fu[users], fi[pos], fi[neg], iu[users], ii[pos], ii[neg]
+    reg = 0.5 * (u0.norm().pow(2) + p0.norm().pow(2) + n0.norm().pow(2)) / float(len(users))
+    mf = torch.mean(torch.nn.functional.softplus((ue * ne).sum(1) - (ue * pe).sum(1)))
+    (mf + decay * reg).backward()
+    return float(mf), float(reg), E.grad.numpy()

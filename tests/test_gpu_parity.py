@@ -201,13 +201,15 @@ def test_lightgcn_propagation_matches_reference(case):
     with torch.no_grad():
         m.E0.weight.copy_(torch.from_numpy(fx["E0"]))
     m = m.to(DEV)
-    fu, fi, iu, ii, layers = m.propagate_through_layers(return_layers=True)
+    with torch.no_grad():
+        fu, fi, iu, ii, layers = m.propagate_through_layers(return_layers=True)
     for l in range(L):
         np.testing.assert_allclose(layers[l].cpu().numpy(), fx["layers"][l], rtol=0, atol=3e-7)
     np.testing.assert_allclose(fu.cpu().numpy(), fx["final_user"], rtol=0, atol=3e-7)
     np.testing.assert_allclose(fi.cpu().numpy(), fx["final_item"], rtol=0, atol=3e-7)
     np.testing.assert_array_equal(iu.cpu().numpy(), fx["E0"][:U])
-    fu2, fi2, _, _ = m.propagate_through_layers()  # production path: layer mean fused into the last SpMM
+    with torch.no_grad():
+        fu2, fi2, _, _ = m.propagate_through_layers()  # production path: layer mean fused into the last SpMM
     np.testing.assert_allclose(fu2.cpu().numpy(), fx["final_user"], rtol=0, atol=3e-7)
     np.testing.assert_allclose(fi2.cpu().numpy(), fx["final_item"], rtol=0, atol=3e-7)
 
@@ -226,7 +228,8 @@ def test_spmm_hub_rows_are_split_and_exact():
     with torch.no_grad():
         m.E0.weight.copy_(torch.from_numpy(E0))
     m = m.to(DEV)
-    fu, fi, _, _ = m.propagate_through_layers()
+    with torch.no_grad():
+        fu, fi, _, _ = m.propagate_through_layers()
     # a 3000-term fp32 sum is order sensitive: judge both against the float64 evaluation of the SAME
     # float32 adjacency.  The oracle (sequential fp32) is within 3e-5 of it, the kernel (tree order) within 5e-6.
     A64, E64 = A.astype(np.float64), E0.astype(np.float64)
@@ -238,7 +241,8 @@ def test_spmm_hub_rows_are_split_and_exact():
     np.testing.assert_allclose(ref[1], mean64[U:], rtol=0, atol=3e-5)
     np.testing.assert_allclose(fu.cpu().numpy(), mean64[:U], rtol=0, atol=5e-6)
     np.testing.assert_allclose(fi.cpu().numpy(), mean64[U:], rtol=0, atol=5e-6)
-    fu2, fi2, _, _ = m.propagate_through_layers()
+    with torch.no_grad():
+        fu2, fi2, _, _ = m.propagate_through_layers()
     assert torch.equal(fi, fi2) and torch.equal(fu, fu2)  # deterministic (no atomics)
 
 
@@ -305,7 +309,8 @@ def test_spmm_widths_against_oracle(d):
     with torch.no_grad():
         m.E0.weight.copy_(torch.from_numpy(E0))
     m = m.to(DEV)
-    fu, fi, _, _ = m.propagate_through_layers()
+    with torch.no_grad():
+        fu, fi, _, _ = m.propagate_through_layers()
     np.testing.assert_allclose(fu.cpu().numpy(), ref[0], rtol=0, atol=2e-6)
     np.testing.assert_allclose(fi.cpu().numpy(), ref[1], rtol=0, atol=2e-6)
 
@@ -516,3 +521,38 @@ def test_checkpoint_resume_is_bit_exact(tmp_path):
     # the model part loads into the oracle (= reference layout) as well
     om = O.DNN([515, 64], [64, 515], 10)
     om.load_state_dict(torch.load(tmp_path / "ck.pt", weights_only=False)["model"])
+
+
+def test_lightgcn_bpr_step_gradients_match_oracle():
+    """reference lightGCN.py:196-219 + :291-298: BPR loss and dE0 through the HIP SpMM (backward = the same
+    propagation, A~ symmetric) vs torch.sparse autograd on the CPU; then a few optimiser steps reduce the loss."""
+    from gdmcf_amd.lightgcn import bpr_loss, sample_bpr_batch
+    rng = np.random.default_rng(0)
+    U, It, d, L, nnz = 400, 250, 64, 3, 5000
+    users = np.concatenate([rng.integers(0, U, nnz), np.arange(U)])
+    items = np.concatenate([np.minimum((rng.pareto(1.2, nnz) * It / 20).astype(np.int64), It - 1), rng.integers(0, It, U)])
+    A = O.lightgcn_norm_adj(users, items, U, It)
+    m = gdmcf_amd.LightGCN({"user_id_idx": users, "item_id_idx": items}, U, It, L, d, device=DEV).to(DEV)
+    E0 = m.E0.weight.detach().cpu().numpy().copy()
+    R = A[:U, U:].tocsr()
+    bu, bp, bn = sample_bpr_batch(R.indptr, R.indices, U, It, 128, rng)
+    assert all(p in R.indices[R.indptr[u]:R.indptr[u + 1]] for u, p in zip(bu, bp))
+    assert not any(n in R.indices[R.indptr[u]:R.indptr[u + 1]] for u, n in zip(bu, bn))
+    decay = 1e-4
+    mf_ref, reg_ref, g_ref = O.lightgcn_bpr_step(A, E0, L, U, bu, bp, bn, decay)
+    ue, pe, ne, u0, p0, n0 = m(cu(torch.from_numpy(bu)), cu(torch.from_numpy(bp)), cu(torch.from_numpy(bn)))
+    mf, reg = bpr_loss(bu, ue, pe, ne, u0, p0, n0)
+    (mf + decay * reg).backward()
+    assert abs(float(mf) - mf_ref) < 1e-6 and abs(float(reg) - reg_ref) < 1e-4 * reg_ref
+    assert H.relerr(m.E0.weight.grad.cpu().numpy(), g_ref) < 1e-5
+    opt = torch.optim.Adam(m.parameters(), lr=0.005)  # as the reference script (lightGCN.py:255)
+    losses = []
+    for _ in range(30):
+        opt.zero_grad()
+        bu, bp, bn = sample_bpr_batch(R.indptr, R.indices, U, It, 128, rng)
+        out = m(cu(torch.from_numpy(bu)), cu(torch.from_numpy(bp)), cu(torch.from_numpy(bn)))
+        mf, reg = bpr_loss(bu, *out)
+        (mf + decay * reg).backward()
+        opt.step()
+        losses.append(float(mf))
+    assert np.mean(losses[-5:]) < np.mean(losses[:5])
