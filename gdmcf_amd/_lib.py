@@ -48,7 +48,7 @@ _SIGNATURES = {
     "gdmcf_sample_timesteps": (c_int, [P, P, c_int, c_int, c_int, c_double, c_uint64, c_uint64, P, P, P, P]),
     "gdmcf_adamw_f32": (c_int, [P, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_int, c_float, P]),
     "gdmcf_topk_masked_f32": (c_int, [P, c_int64, c_int, c_int, P, P, c_int, P, P, P]),
-    "gdmcf_spmm_csr_f32": (c_int, [P, P, P, c_int, P, P, c_int, P, P, c_int, P, c_int64, c_int, P, c_int64, P, P, c_int,
+    "gdmcf_spmm_csr_f32": (c_int, [P, P, P, P, c_int, c_int, P, P, c_int, P, P, c_int, P, c_int64, c_int, P, c_int64, P, P, c_int,
                                    c_int64, c_float, c_double, P]),
     "gdmcf_scale_f32": (c_int, [P, c_int64, c_float, P, P]),
 }

@@ -167,7 +167,7 @@ struct SpmmAdd {
 };
 
 template <int LPR>
-__global__ __launch_bounds__(256) void spmm_vec_kernel(const int64_t* __restrict__ vptr,
+__global__ __launch_bounds__(256) void spmm_vec_kernel(const int64_t* __restrict__ vbeg, const int64_t* __restrict__ vend,
                                                        const int32_t* __restrict__ vrow,
                                                        const int32_t* __restrict__ vslot, int n_virtual,
                                                        const int32_t* __restrict__ col,
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void spmm_vec_kernel(const int64_t* __restrict
     const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (v >= n_virtual) return;
     const int sub = lane / LPR, cl = lane % LPR;
-    const int64_t beg = vptr[v], end = vptr[v + 1];
+    const int64_t beg = vbeg[v], end = vend[v];
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
     int64_t j = beg + sub;
     for (; j + 3 * NPAR < end; j += 4 * NPAR) {
@@ -219,8 +219,58 @@ __global__ __launch_bounds__(256) void spmm_vec_kernel(const int64_t* __restrict
     }
 }
 
+// Short rows (the bulk of a user-item graph: median degree ~ 20): LPR lanes own one whole row, so a wave
+// works on 64/LPR rows at once.  With one row per wave the kernel is bound by the dependent chain
+// vptr -> col/val -> gather -> store of 50 k+ tiny waves (measured 39 us for the user half of the Yelp graph);
+// here each lane group fetches up to LPR (col, val) pairs with one coalesced load, broadcasts them with
+// group-local shuffles and keeps 4 gathers in flight.  Accumulation is in CSR order (deterministic).
+template <int LPR>
+__global__ __launch_bounds__(256) void spmm_short_kernel(const int64_t* __restrict__ vbeg, const int64_t* __restrict__ vend,
+                                                         const int32_t* __restrict__ vrow, int n_short,
+                                                         const int32_t* __restrict__ col,
+                                                         const float* __restrict__ val, const float* __restrict__ X,
+                                                         int64_t ldx, float* __restrict__ Y, int64_t ldy,
+                                                         const SpmmAdd add) {
+    constexpr int G = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int grp = lane / LPR, gl = lane % LPR;
+    const int v = (blockIdx.x * 4 + (threadIdx.x >> 6)) * G + grp;
+    if (v >= n_short) return;  // whole lane group leaves together
+    const int64_t beg = vbeg[v], end = vend[v];
+    const int r = vrow[v];
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t base = beg; base < end; base += LPR) {
+        const bool have = base + gl < end;
+        const int my_c = have ? col[base + gl] : 0;
+        const float my_w = have ? val[base + gl] : 0.f;
+        const int n = (int)min((int64_t)LPR, end - base);
+        int j = 0;
+        for (; j + 3 < n; j += 4) {
+            const int c0 = __shfl(my_c, j, LPR), c1 = __shfl(my_c, j + 1, LPR), c2 = __shfl(my_c, j + 2, LPR),
+                      c3 = __shfl(my_c, j + 3, LPR);
+            const float w0 = __shfl(my_w, j, LPR), w1 = __shfl(my_w, j + 1, LPR), w2 = __shfl(my_w, j + 2, LPR),
+                        w3 = __shfl(my_w, j + 3, LPR);
+            const f32x4 x0 = *reinterpret_cast<const f32x4*>(X + (int64_t)c0 * ldx + gl * 4);
+            const f32x4 x1 = *reinterpret_cast<const f32x4*>(X + (int64_t)c1 * ldx + gl * 4);
+            const f32x4 x2 = *reinterpret_cast<const f32x4*>(X + (int64_t)c2 * ldx + gl * 4);
+            const f32x4 x3 = *reinterpret_cast<const f32x4*>(X + (int64_t)c3 * ldx + gl * 4);
+            s += w0 * x0;
+            s += w1 * x1;
+            s += w2 * x2;
+            s += w3 * x3;
+        }
+        for (; j < n; ++j) {
+            const int c0 = __shfl(my_c, j, LPR);
+            const float w0 = __shfl(my_w, j, LPR);
+            s += w0 * *reinterpret_cast<const f32x4*>(X + (int64_t)c0 * ldx + gl * 4);
+        }
+    }
+    for (int k = 0; k < add.n; ++k) s += *reinterpret_cast<const f32x4*>(add.p[k] + (int64_t)r * add.ld + gl * 4);
+    *reinterpret_cast<f32x4*>(Y + (int64_t)r * ldy + gl * 4) = s * add.scale;
+}
+
 // generic fallback (any d): one neighbour at a time, lanes stride over columns
-__global__ __launch_bounds__(256) void spmm_generic_kernel(const int64_t* __restrict__ vptr,
+__global__ __launch_bounds__(256) void spmm_generic_kernel(const int64_t* __restrict__ vbeg, const int64_t* __restrict__ vend,
                                                            const int32_t* __restrict__ vrow,
                                                            const int32_t* __restrict__ vslot, int n_virtual,
                                                            const int32_t* __restrict__ col,
@@ -230,7 +280,7 @@ __global__ __launch_bounds__(256) void spmm_generic_kernel(const int64_t* __rest
     const int lane = threadIdx.x & 63;
     const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (v >= n_virtual) return;
-    const int64_t beg = vptr[v], end = vptr[v + 1];
+    const int64_t beg = vbeg[v], end = vend[v];
     const int slot = vslot[v], r = vrow[v];
     for (int c0 = lane; c0 < d; c0 += 64) {
         float s = 0.f;
@@ -311,12 +361,12 @@ int gdmcf_topk_masked_f32(const float* pred, int64_t ldp, int B, int I, const in
     return gd_launch_status("topk");
 }
 
-int gdmcf_spmm_csr_f32(const int64_t* vptr, const int32_t* vrow, const int32_t* vslot, int n_virtual,
+int gdmcf_spmm_csr_f32(const int64_t* vbeg, const int64_t* vend, const int32_t* vrow, const int32_t* vslot, int n_virtual, int n_short,
                        const int32_t* lrow, const int32_t* lptr, int n_long, const int32_t* col, const float* val,
                        int n_rows, const float* X, int64_t ldx, int d, float* Y, int64_t ldy, float* partial_ws,
                        const float* const* addends_host, int n_add, int64_t ld_add, float scale, double alg_bytes,
                        void* stream) {
-    GD_CHECK_SHAPE(n_rows > 0 && n_virtual >= n_rows - 0 * n_rows && d > 0 && ldx >= d && ldy >= d, "spmm: bad shape");
+    GD_CHECK_SHAPE(n_rows > 0 && n_virtual > 0 && d > 0 && ldx >= d && ldy >= d, "spmm: bad shape");
     GD_CHECK_ARG(n_add >= 0 && n_add <= SPMM_MAX_ADD && (n_add == 0 || (addends_host && ld_add >= d)), "spmm: bad addends");
     GD_CHECK_ARG(n_long == 0 || (lrow && lptr && partial_ws), "spmm: split rows need lrow/lptr/partial_ws");
     hipStream_t s = (hipStream_t)stream;
@@ -327,20 +377,44 @@ int gdmcf_spmm_csr_f32(const int64_t* vptr, const int32_t* vrow, const int32_t* 
         add.p[k] = addends_host[k];
         add_al = add_al && gd_aligned16(add.p[k]);
     }
-    const dim3 grid(gd_cdiv(n_virtual, 4)), block(256);
+    GD_CHECK_ARG(n_short >= 0 && n_short <= n_virtual, "spmm: n_short out of range");
+    const dim3 block(256);
     const bool vec = (d % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && gd_aligned16(X) && gd_aligned16(Y) &&
                      (n_add == 0 || ((ld_add % 4 == 0) && add_al)) && (partial_ws == nullptr || gd_aligned16(partial_ws));
     const int lpr = d / 4;
+    const bool pow2 = vec && (lpr == 2 || lpr == 4 || lpr == 8 || lpr == 16 || lpr == 32 || lpr == 64);
+    if (!pow2 && n_short > 0) {
+        gdmcf_set_error("spmm: the short-row path needs d in {8,16,32,64,128,256}; build the plan with n_short = 0");
+        return GDMCF_E_ARG;
+    }
     {
         GdProfScope prof(8, alg_bytes, s);
-#define GD_SPMM_LAUNCH(K) hipLaunchKernelGGL(K, grid, block, 0, s, vptr, vrow, vslot, n_virtual, col, val, X, ldx, Y, ldy, partial_ws, d, add)
-        if (vec && lpr == 16) GD_SPMM_LAUNCH(spmm_vec_kernel<16>);
-        else if (vec && lpr == 8) GD_SPMM_LAUNCH(spmm_vec_kernel<8>);
-        else if (vec && lpr == 32) GD_SPMM_LAUNCH(spmm_vec_kernel<32>);
-        else if (vec && lpr == 64) GD_SPMM_LAUNCH(spmm_vec_kernel<64>);
-        else if (vec && lpr == 4) GD_SPMM_LAUNCH(spmm_vec_kernel<4>);
-        else if (vec && lpr == 2) GD_SPMM_LAUNCH(spmm_vec_kernel<2>);
-        else GD_SPMM_LAUNCH(spmm_generic_kernel);
+        if (n_short > 0) {
+#define GD_SPMM_SHORT(L) hipLaunchKernelGGL(spmm_short_kernel<L>, dim3(gd_cdiv(n_short, 4 * (64 / L))), block, 0, s, vbeg, vend, vrow, n_short, col, val, X, ldx, Y, ldy, add)
+            if (lpr == 16) GD_SPMM_SHORT(16);
+            else if (lpr == 8) GD_SPMM_SHORT(8);
+            else if (lpr == 32) GD_SPMM_SHORT(32);
+            else if (lpr == 64) GD_SPMM_SHORT(64);
+            else if (lpr == 4) GD_SPMM_SHORT(4);
+            else GD_SPMM_SHORT(2);
+#undef GD_SPMM_SHORT
+        }
+        const int n_rest = n_virtual - n_short;
+        const dim3 grid(gd_cdiv(n_rest > 0 ? n_rest : 1, 4));
+        const int64_t* vbeg_r = vbeg + n_short;
+        const int64_t* vend_r = vend + n_short;
+        const int32_t* vrow_r = vrow + n_short;
+        const int32_t* vslot_r = vslot + n_short;
+#define GD_SPMM_LAUNCH(K) hipLaunchKernelGGL(K, grid, block, 0, s, vbeg_r, vend_r, vrow_r, vslot_r, n_rest, col, val, X, ldx, Y, ldy, partial_ws, d, add)
+        if (n_rest > 0) {
+            if (vec && lpr == 16) GD_SPMM_LAUNCH(spmm_vec_kernel<16>);
+            else if (vec && lpr == 8) GD_SPMM_LAUNCH(spmm_vec_kernel<8>);
+            else if (vec && lpr == 32) GD_SPMM_LAUNCH(spmm_vec_kernel<32>);
+            else if (vec && lpr == 64) GD_SPMM_LAUNCH(spmm_vec_kernel<64>);
+            else if (vec && lpr == 4) GD_SPMM_LAUNCH(spmm_vec_kernel<4>);
+            else if (vec && lpr == 2) GD_SPMM_LAUNCH(spmm_vec_kernel<2>);
+            else GD_SPMM_LAUNCH(spmm_generic_kernel);
+        }
 #undef GD_SPMM_LAUNCH
         if (n_long > 0)
             hipLaunchKernelGGL(spmm_combine_kernel, dim3(n_long), block, (size_t)4 * d * sizeof(float), s, lrow, lptr,

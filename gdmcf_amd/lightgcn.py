@@ -39,24 +39,39 @@ def normalized_bipartite_csr(users, items, n_users, n_items):
     return A.indptr.astype(np.int64), A.indices.astype(np.int32), data
 
 
-def spmm_plan(indptr, chunk=SPMM_CHUNK):
-    """Virtual-row plan for gdmcf_spmm_csr_f32 (see include/gdmcf_hip.h): every row is cut into pieces
-    of <= chunk nonzeros; rows cut into more than one piece get partial slots + an entry in lrow/lptr."""
+SPMM_SHORT = int(os.environ.get("GDMCF_SPMM_SHORT", "48"))  # rows up to this many nonzeros run four-to-a-wave
+
+
+def spmm_plan(indptr, chunk=SPMM_CHUNK, short=SPMM_SHORT, d=64):
+    """Virtual-row plan for gdmcf_spmm_csr_f32 (see include/gdmcf_hip.h).  Rows with <= `short` nonzeros come
+    first, whole (they run 64/(d/4) to a wave); every other row is cut into pieces of <= chunk nonzeros; rows cut
+    into more than one piece get partial slots + an entry in lrow/lptr."""
     indptr = np.asarray(indptr, dtype=np.int64)
     deg = np.diff(indptr)
-    pieces = np.maximum(1, -(-deg // chunk)).astype(np.int64)
-    n_virtual = int(pieces.sum())
-    vrow = np.repeat(np.arange(len(deg), dtype=np.int32), pieces)
-    first = np.concatenate([[0], np.cumsum(pieces)[:-1]])
-    k = np.arange(n_virtual, dtype=np.int64) - first[vrow]  # piece index inside its row
-    beg = indptr[vrow] + k * chunk
-    vptr = np.concatenate([beg, indptr[-1:]]).astype(np.int64)
-    is_long = pieces[vrow] > 1
-    vslot = np.full(n_virtual, -1, dtype=np.int32)
-    vslot[is_long] = np.arange(int(is_long.sum()), dtype=np.int32)
-    lrow = np.nonzero(pieces > 1)[0].astype(np.int32)
-    lptr = np.concatenate([[0], np.cumsum(pieces[lrow])]).astype(np.int32)
-    return dict(vptr=vptr, vrow=vrow, vslot=vslot, lrow=lrow, lptr=lptr, n_slots=int(is_long.sum()))
+    lpr = d // 4
+    if d % 4 != 0 or lpr not in (2, 4, 8, 16, 32, 64):
+        short = -1  # the short-row kernel needs power-of-two lane groups
+    is_short = deg <= short
+    srows = np.nonzero(is_short)[0]
+    lrows_all = np.nonzero(~is_short)[0]
+    ldeg = deg[lrows_all]
+    pieces = np.maximum(1, -(-ldeg // chunk)).astype(np.int64)
+    n_rest = int(pieces.sum())
+    rrow = np.repeat(lrows_all, pieces)
+    first = np.concatenate([[0], np.cumsum(pieces)[:-1]]) if len(pieces) else np.zeros(0, np.int64)
+    k = np.arange(n_rest, dtype=np.int64) - np.repeat(first, pieces)  # piece index inside its row
+    rbeg = indptr[rrow] + k * chunk
+    rend = np.minimum(rbeg + chunk, indptr[rrow + 1])
+    cut = np.repeat(pieces > 1, pieces)
+    rslot = np.full(n_rest, -1, dtype=np.int32)
+    rslot[cut] = np.arange(int(cut.sum()), dtype=np.int32)
+    lrow = lrows_all[pieces > 1].astype(np.int32)
+    lptr = np.concatenate([[0], np.cumsum(pieces[pieces > 1])]).astype(np.int32)
+    return dict(vbeg=np.concatenate([indptr[srows], rbeg]).astype(np.int64),
+                vend=np.concatenate([indptr[srows + 1], rend]).astype(np.int64),
+                vrow=np.concatenate([srows, rrow]).astype(np.int32),
+                vslot=np.concatenate([np.full(len(srows), -1, np.int32), rslot]).astype(np.int32),
+                lrow=lrow, lptr=lptr, n_slots=int(cut.sum()), n_short=int(len(srows)))
 
 
 class LightGCN(nn.Module):
@@ -80,7 +95,7 @@ class LightGCN(nn.Module):
                                                          np.asarray(self.data["item_id_idx"]), self.n_users,
                                                          self.n_items)
         dev = self._device
-        plan = spmm_plan(indptr)
+        plan = spmm_plan(indptr, d=self.latent_dim)
         self._plan = {k: (torch.from_numpy(v).to(dev) if isinstance(v, np.ndarray) else v) for k, v in plan.items()}
         self._partial = torch.empty(max(plan["n_slots"], 1), self.latent_dim, dtype=torch.float32, device=dev)
         self.nnz = int(indices.size)
@@ -109,7 +124,8 @@ class LightGCN(nn.Module):
             adds = layers if last else []
             arr = (ctypes.c_void_p * max(len(adds), 1))(*[a.data_ptr() for a in adds])
             _lib.check(lib.gdmcf_spmm_csr_f32(
-                pl["vptr"].data_ptr(), pl["vrow"].data_ptr(), pl["vslot"].data_ptr(), nv, _lib.ptr(pl["lrow"]) if nl else None,
+                pl["vbeg"].data_ptr(), pl["vend"].data_ptr(), pl["vrow"].data_ptr(), pl["vslot"].data_ptr(), nv,
+                pl["n_short"], _lib.ptr(pl["lrow"]) if nl else None,
                 _lib.ptr(pl["lptr"]) if nl else None, nl, indices.data_ptr(), vals.data_ptr(), N, cur.data_ptr(),
                 cur.stride(0), d, out.data_ptr(), out.stride(0), self._partial.data_ptr(), arr, len(adds),
                 cur.stride(0), 1.0 / (self.n_layers + 1) if last else 1.0, self.algorithmic_bytes(), st))

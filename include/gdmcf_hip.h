@@ -195,19 +195,22 @@ int gdmcf_topk_masked_f32(const float* pred, int64_t ldp, int B, int I, const in
 
 /* ---- LightGCN propagation: CSR SpMM (lightGCN.py:184-189) --------------------------------
  * Y[r,:] = ( sum_j val[j]*X[col[j],:]  +  sum_k addend_k[r,:] ) * scale
- * The adjacency is plain CSR (col int32, val float32) plus a host-built execution plan that splits
- * every row into "virtual rows" of at most `chunk` nonzeros so that hub nodes spread over many waves:
- *   vptr  int64 [n_virtual+1]  nonzero range of each virtual row (consecutive, covering the CSR)
- *   vrow  int32 [n_virtual]    the real row it belongs to
- *   vslot int32 [n_virtual]    -1: the row is whole, write Y directly; >= 0: slot in partial_ws
- *   lrow  int32 [n_long], lptr int32 [n_long+1]: the split rows and their slot ranges
- *   partial_ws float32 [n_slots, d]
- * With chunk = infinity the plan degenerates to vptr = rowptr (n_virtual = n_rows, n_long = 0).
+ * The adjacency is plain CSR (col int32, val float32) plus a host-built execution plan of "virtual rows"
+ * (gdmcf_amd/lightgcn.py:spmm_plan):
+ *   vbeg, vend int64 [n_virtual]  nonzero range of each virtual row
+ *   vrow  int32 [n_virtual]       the real row it belongs to
+ *   vslot int32 [n_virtual]       -1: the row is whole, write Y directly; >= 0: slot in partial_ws
+ *   the first n_short virtual rows are WHOLE rows of at most a few dozen nonzeros: they run 64/(d/4) rows per
+ *   wave (four at d = 64), because one-row-per-wave is latency bound on such rows;
+ *   the remaining ones are pieces of <= chunk nonzeros, one wave each, so hub nodes spread over many waves;
+ *   lrow  int32 [n_long], lptr int32 [n_long+1]: the rows that were cut and their slot ranges in
+ *   partial_ws float32 [n_slots, d], added up in slot order by a second small kernel (no atomics).
+ * With n_short = 0 and chunk = infinity the plan degenerates to plain CSR (vbeg = rowptr[:-1], vend = rowptr[1:]).
  * addends_host: HOST array of n_add (<= 8) device pointers [n_rows, ld_add] -- the last LightGCN
  * layer passes E_0..E_{L-1} and scale = 1/(L+1) so the layer mean (:188-189) costs no extra pass.
  * alg_bytes: algorithmic bytes of this launch, forwarded to the profiling hook only.          */
-int gdmcf_spmm_csr_f32(const int64_t* vptr, const int32_t* vrow, const int32_t* vslot, int n_virtual,
-                       const int32_t* lrow, const int32_t* lptr, int n_long, const int32_t* col,
+int gdmcf_spmm_csr_f32(const int64_t* vbeg, const int64_t* vend, const int32_t* vrow, const int32_t* vslot,
+                       int n_virtual, int n_short, const int32_t* lrow, const int32_t* lptr, int n_long, const int32_t* col,
                        const float* val, int n_rows, const float* X, int64_t ldx, int d, float* Y,
                        int64_t ldy, float* partial_ws, const float* const* addends_host, int n_add,
                        int64_t ld_add, float scale, double alg_bytes, void* stream);
