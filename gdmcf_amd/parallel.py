@@ -111,17 +111,32 @@ class DataParallelStep:
             self._small.append(g)
 
     def _finish_exchange(self):
-        if self._small:
-            flat = torch.cat([g.reshape(-1) for g in self._small])
-            _all_reduce(flat, self.group)
-            off = 0
-            for g in self._small:
-                g.copy_(flat[off:off + g.numel()].view_as(g))
-                off += g.numel()
+        """One small float64 all-reduce carries (a) every small gradient and (b) the (ts, unscaled loss) pairs of
+        all ranks: each rank writes its slice of a zero-initialised [world, B, 2] block, so SUM == all-gather in
+        rank order.  Returns (ts_all, lu_all) of the global batch."""
+        d = self.diffusion
+        ts, lu = d.last_ts, d.last_loss_unscaled
+        B, dev = ts.numel(), ts.device
+        n_small = sum(g.numel() for g in self._small)
+        flat = torch.zeros(n_small + self.world * B * 2, dtype=torch.float64, device=dev)
+        off = 0
+        for g in self._small:
+            flat[off:off + g.numel()] = g.reshape(-1)
+            off += g.numel()
+        hist = flat[n_small:].view(self.world, B, 2)
+        rank = dist.get_rank(self.group)
+        hist[rank, :, 0] = ts.to(torch.float64)  # exact for any realistic number of diffusion steps
+        hist[rank, :, 1] = lu
+        _all_reduce(flat, self.group)
+        off = 0
+        for g in self._small:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
         for h in self._handles:
             if h is not None:
                 h.wait()
         self._handles, self._small = [], []
+        return hist[:, :, 0].reshape(-1).to(torch.int64).contiguous(), hist[:, :, 1].reshape(-1).contiguous()
 
     def __call__(self, batch, reweight=True, **rand):
         from . import _lib
@@ -130,12 +145,12 @@ class DataParallelStep:
         loss = losses["loss"].mean()
         loss.backward()
         if self.world > 1:
+            d = self.diffusion
             if self.model.engine.grad_sink is not None:
-                self._finish_exchange()
+                ts_all, lu_all = self._finish_exchange()
             else:
                 allreduce_grads(self.model.parameters(), self.group)
-            d = self.diffusion
-            ts_all, lu_all = gather_history_inputs(d.last_ts, d.last_loss_unscaled, self.group)
+                ts_all, lu_all = gather_history_inputs(d.last_ts, d.last_loss_unscaled, self.group)
             _lib.check(_lib.load().gdmcf_lt_history_update(ts_all.data_ptr(), lu_all.data_ptr(), ts_all.numel(),
                                                            d.steps, d.history_num_per_term, d.Lt_history.data_ptr(),
                                                            d.Lt_count.data_ptr(), _lib.stream_ptr()))
