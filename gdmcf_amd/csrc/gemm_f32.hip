@@ -16,6 +16,12 @@
 
 #include "common.h"
 
+#ifdef GD_PROBE_NO_LDSWRITE
+#define GD_PROBE_LDSWRITE_OFF 1
+#else
+#define GD_PROBE_LDSWRITE_OFF 0
+#endif
+
 namespace {
 
 constexpr int NTHREADS = 256;
@@ -211,6 +217,10 @@ template <int LAY, int R, int BK, int T>
 __device__ __forceinline__ void load_frag(const float* __restrict__ lds, int row_base, int c, int r, int q,
                                           float (&f)[T][4]) {
     using G = TileGeom<LAY, R, BK>;
+#ifdef GD_PROBE_NO_LDSREAD  // ablation (tools/gemm_probe.hip): operands stay whatever the registers hold
+    for (int t = 0; t < T; ++t) for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(f[t][s]));
+    return;
+#endif
 #pragma unroll
     for (int t = 0; t < T; ++t) {
         if (LAY == GD_LAY_KC) {
@@ -319,6 +329,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GdGemm g) {
 #define GD_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 #ifdef GD_PROBE_NO_BARRIER
 #define __syncthreads() ((void)0)
+#define GD_RAW_BARRIER() ((void)0)
+#else
+#define GD_RAW_BARRIER() __builtin_amdgcn_s_barrier()
 #endif
     if (nt > 0) {
         sa0.load(g.A, g.lda, m0, g.M, kbeg, kend, kbeg, a_full, tid);
@@ -364,52 +377,69 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GdGemm g) {
         constexpr int NLT = GA::NL + GB::NL;  // loads (and LDS writes) per tile and thread
         constexpr int NCH = BK / 16;          // k-chunks per tile, 4 MFMA groups each
         constexpr int NG = 4 * NCH;           // MFMA groups per tile
-        constexpr int HG = NG / 2;            // loads ride in groups [0,HG), LDS writes in [HG,NG)
-        constexpr int PER = (NLT + HG - 1) / HG;
+        constexpr int HG = NG / 2;            // loads ride in groups [0,HG), LDS writes in [HG,NG-1)
+        constexpr int PERL = (NLT + HG - 1) / HG;
+        constexpr int WG_ = NG - 1 - HG;      // groups that carry LDS writes
+        constexpr int PERW = (NLT + WG_ - 1) / WG_;
+        static_assert(WG_ >= 1, "need at least one group for the LDS writes");
 
-        // one half-iteration: compute tile from Lc, load next-next tile into (la, lb), write (sa_, sb_) to Ln
-#define GD_HALF(Lc, Ln, la, lb, sa_, sb_)                                                                          \
+        // Fragment registers live across half-iterations: chunk c of a tile uses parity (P0 + c) & 1 and the
+        // first fragments of the NEXT tile are fetched (after the barrier) under the last MFMA group.
+        float fra[2][TM][4], frb[2][TN][4];
+        load_frag<LAYA, BM, BK, TM>(L0, wm0, 0, r, q, fra[0]);
+        load_frag<LAYB, BN, BK, TN>(L0 + GA::FLOATS, wn0, 0, r, q, frb[0]);
+
+        // one half-iteration: compute tile from Lc, load next-next tile into (la, lb), write (sa_, sb_) to Ln.
+        // All LDS reads of Lc are issued by group 1 of the last chunk, all writes to Ln by group NG-2: ONE barrier
+        // before the last group covers both hazards, and the last group's MFMAs hide the barrier skew and the
+        // latency of the next tile's first fragment reads.
+#define GD_HALF(Lc, Ln, la, lb, sa_, sb_, P0)                                                                      \
         {                                                                                                          \
-            float fra[2][TM][4], frb[2][TN][4];                                                                    \
-            load_frag<LAYA, BM, BK, TM>(Lc, wm0, 0, r, q, fra[0]);                                                 \
-            load_frag<LAYB, BN, BK, TN>(Lc + GA::FLOATS, wn0, 0, r, q, frb[0]);                                    \
             _Pragma("unroll") for (int gi = 0; gi < NG; ++gi) {                                                    \
-                const int ch = gi >> 2, sgrp = gi & 3;                                                             \
+                const int ch = gi >> 2, sgrp = gi & 3, par = ((P0) + ch) & 1;                                      \
                 if (gi == HG) {                                                                                    \
                     GD_WAIT_VM(NLT); /* the tile loaded one half-iteration ago has landed; the new one flies */    \
                     sa_.pin();                                                                                     \
                     sb_.pin();                                                                                     \
                 }                                                                                                  \
+                if (gi == NG - 1) {                                                                                \
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                             \
+                    GD_RAW_BARRIER();                                                                              \
+                    load_frag<LAYA, BM, BK, TM>(Ln, wm0, 0, r, q, fra[((P0) + NCH) & 1]);                          \
+                    load_frag<LAYB, BN, BK, TN>(Ln + GA::FLOATS, wn0, 0, r, q, frb[((P0) + NCH) & 1]);             \
+                }                                                                                                  \
                 _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                     \
                     _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                 \
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fra[ch & 1][i][sgrp], frb[ch & 1][j][sgrp], acc[i][j], 0, 0, 0); \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fra[par][i][sgrp], frb[par][j][sgrp], acc[i][j], 0, 0, 0); \
                 if (gi < HG) {                                                                                     \
-                    _Pragma("unroll") for (int u = gi * PER; u < (gi + 1) * PER && u < NLT; ++u) {                  \
+                    _Pragma("unroll") for (int u = gi * PERL; u < (gi + 1) * PERL && u < NLT; ++u) {                \
                         if (u < GA::NL) { la.reg[u] = gload16(pa[u]); pa[u] += stepa; }                             \
                         else { lb.reg[u - GA::NL] = gload16(pb[u - GA::NL]); pb[u - GA::NL] += stepb; }             \
                     }                                                                                              \
-                } else {                                                                                           \
-                    _Pragma("unroll") for (int u = (gi - HG) * PER; u < (gi - HG + 1) * PER && u < NLT; ++u) {      \
+                } else if (gi < NG - 1) {                                                                          \
+                    _Pragma("unroll") for (int u = (gi - HG) * PERW; u < (gi - HG + 1) * PERW && u < NLT; ++u) {    \
+                        if (GD_PROBE_LDSWRITE_OFF) continue;                                                        \
                         if (u < GA::NL) { if (wa[u] >= 0) *reinterpret_cast<f32x4*>(&(Ln)[wa[u]]) = sa_.reg[u]; }   \
                         else if (wb[u - GA::NL] >= 0)                                                               \
                             *reinterpret_cast<f32x4*>(&(Ln)[GA::FLOATS + wb[u - GA::NL]]) = sb_.reg[u - GA::NL];    \
                     }                                                                                              \
                 }                                                                                                  \
                 if (sgrp == 1 && ch + 1 < NCH) { /* fetch the next chunk's fragments under this chunk's MFMAs */  \
-                    load_frag<LAYA, BM, BK, TM>(Lc, wm0, ch + 1, r, q, fra[(ch + 1) & 1]);                         \
-                    load_frag<LAYB, BN, BK, TN>(Lc + GA::FLOATS, wn0, ch + 1, r, q, frb[(ch + 1) & 1]);            \
+                    load_frag<LAYA, BM, BK, TM>(Lc, wm0, ch + 1, r, q, fra[par ^ 1]);                              \
+                    load_frag<LAYB, BN, BK, TN>(Lc + GA::FLOATS, wn0, ch + 1, r, q, frb[par ^ 1]);                 \
                 }                                                                                                  \
                 __builtin_amdgcn_sched_barrier(0);                                                                 \
             }                                                                                                      \
-            __syncthreads();                                                                                       \
         }
-        // invariant at the top (even `it`): L0 holds tile it, stage-1 registers hold tile it+1 (in flight),
-        // stage-0 registers are free; tiles it+2 and it+3 are interior.
+        // invariant at the top (even `it`): L0 holds tile it (its chunk-0 fragments already in registers),
+        // stage-1 registers hold tile it+1 (in flight), stage-0 registers are free; tiles it+2, it+3 interior.
         for (; it + 3 < nt_full; it += 2) {
-            GD_HALF(L0, L1, sa0, sb0, sa1, sb1);  // tile it;   loads tile it+2 -> stage 0, writes tile it+1 -> L1
-            GD_HALF(L1, L0, sa1, sb1, sa0, sb0);  // tile it+1; loads tile it+3 -> stage 1, writes tile it+2 -> L0
+            GD_HALF(L0, L1, sa0, sb0, sa1, sb1, 0);          // tile it;   loads it+2 -> stage 0, writes it+1 -> L1
+            GD_HALF(L1, L0, sa1, sb1, sa0, sb0, (NCH & 1));  // tile it+1; loads it+3 -> stage 1, writes it+2 -> L0
         }
 #undef GD_HALF
+        // (the fragments prefetched for tile `it` are simply re-read by the generic loop below)
+        __syncthreads();
         sa0.mode = sb0.mode = sa1.mode = sb1.mode = 0;
     }
 
