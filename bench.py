@@ -33,6 +33,25 @@ PEAK_HBM_GBPS = 8000.0
 TAGS = {1: "linear_fwd_gemm", 2: "loss_fwd_gemm", 3: "posterior_gemm", 4: "bwd_input_gemm", 5: "bwd_weight_gemm",
         6: "adamw", 7: "prep_input", 8: "spmm_csr", 9: "topk"}
 GEMM_TAGS = (1, 2, 3, 4, 5)
+# rocprofv3 kernel names of the tagged launches at the Yelp-shape workload (for the PMC traffic lookup)
+TRAFFIC_KERNEL = {"bwd_weight_gemm": "gemm_f32_kernel<1, 1, 128, 128, 16, 2, 2, 4>",
+                  "loss_fwd_gemm": "gemm_f32_kernel<0, 0, 80, 128, 32, 1, 4, 2>",
+                  "bwd_input_gemm": "gemm_f32_kernel<0, 1, 80, 128, 32, 1, 4, 0>",
+                  "linear_fwd_gemm": "gemm_f32_kernel<0, 0, 80, 128, 32, 1, 4, 0>", "adamw": "adamw_kernel",
+                  "prep_input": "prep_input_kernel"}
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_final_hbm_traffic.json")
+
+
+def measured_traffic(kernel_tag, workload):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE and
+    WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950 note; profiles/summarize.py).  PMC counters
+    cannot be collected from inside the process, so this is a lookup; None when no profile matches."""
+    if workload != "yelp" or kernel_tag not in TRAFFIC_KERNEL or not os.path.exists(TRAFFIC_FILE):
+        return None
+    for row in json.load(open(TRAFFIC_FILE)):
+        if row["kernel"] == TRAFFIC_KERNEL[kernel_tag]:
+            return int(row["hbm_total_MB"] * 1e6)
+    return None
 
 
 def parse():
@@ -170,7 +189,11 @@ def main():
     if klist:
         k0 = klist[0]
         roofline = dict(bound=k0["bound"], achieved=k0["achieved"], peak=k0["peak"], unit=k0["unit"], frac=k0["frac"],
-                        traffic=None, kernel=k0["kernel"], avg_ms=k0["avg_ms"])
+                        traffic=measured_traffic(k0["kernel"], args.workload), kernel=k0["kernel"], avg_ms=k0["avg_ms"],
+                        launches_per_step=k0["launches"] // max(args.steps, 1),
+                        traffic_unit="HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE passes of this "
+                                     "command (profiles/r01_final_hbm_traffic.json)",
+                        algorithmic_unit="2*M*N*K FLOP per launch")
 
     spmm = None
     if args.spmm and rank == 0:
