@@ -556,3 +556,68 @@ def test_lightgcn_bpr_step_gradients_match_oracle():
         opt.step()
         losses.append(float(mf))
     assert np.mean(losses[-5:]) < np.mean(losses[:5])
+
+
+def test_linear_entry_points_random_shapes():
+    """Adversarial shapes for the branch-free edge loaders (clamped addresses, in-register shifts, K tails,
+    odd leading dimensions, split-K on/off): every dense entry point of the C ABI vs float64 matmul."""
+    import ctypes
+    from gdmcf_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+    st = _lib.stream_ptr()
+    shapes = [(1, 4, 4), (3, 5, 7), (16, 16, 16), (17, 33, 65), (80, 128, 32), (81, 129, 33), (100, 257, 36), (400, 130, 1000),
+              (7, 1000, 515), (129, 70, 4099), (65, 64, 8195), (33, 300, 31), (5, 6, 20000)]
+    for (M, N, K) in shapes:
+        for pad in (0, 3):
+            lda, ldw, ldc = K + pad, K + (1 if pad else 0), N + pad
+            A = torch.zeros(M, lda, device=DEV); A[:, :K] = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).to(DEV)
+            W = torch.zeros(N, ldw, device=DEV); W[:, :K] = torch.from_numpy((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)).to(DEV)
+            bias = torch.from_numpy(rng.standard_normal(N).astype(np.float32)).to(DEV)
+            ref = A[:, :K].double() @ W[:, :K].double().T + bias.double()
+            close = lambda got, want: float((got - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+            ws_bytes = int(lib.gdmcf_linear_ws_bytes(M, N, K))
+            ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=DEV)
+            # forward (+tanh)
+            C = torch.full((M, ldc), float("nan"), device=DEV)
+            _lib.check(lib.gdmcf_linear_fwd_f32(A.data_ptr(), lda, W.data_ptr(), ldw, bias.data_ptr(), 1, M, N, K, C.data_ptr(),
+                                                ldc, ws.data_ptr(), ws_bytes, st))
+            assert close(C[:, :N].double(), torch.tanh(ref)), ("fwd", M, N, K, pad)
+            assert pad == 0 or bool(torch.isnan(C[:, N:]).all())  # nothing written outside [M, N]
+            # fused loss
+            tgt = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32)).to(DEV)
+            alpha = torch.from_numpy(rng.uniform(0.5, 1.5, M).astype(np.float32)).to(DEV)
+            diff = torch.full((M, ldc), float("nan"), device=DEV)
+            out = torch.empty(M, N, device=DEV)
+            rowpart = torch.zeros(M, lib.gdmcf_loss_tiles(N), device=DEV)
+            rowsum = torch.zeros(M, device=DEV)
+            _lib.check(lib.gdmcf_linear_loss_fwd_f32(A.data_ptr(), lda, W.data_ptr(), ldw, bias.data_ptr(), tgt.data_ptr(), N,
+                                                     alpha.data_ptr(), M, N, K, out.data_ptr(), N, diff.data_ptr(), ldc,
+                                                     rowpart.data_ptr(), rowsum.data_ptr(), st))
+            dref = alpha.double()[:, None] * ref - tgt.double()
+            assert close(diff[:, :N].double(), dref) and close(out.double(), ref), ("loss", M, N, K, pad)
+            np.testing.assert_allclose(rowsum.cpu().numpy(), (dref ** 2).sum(1).cpu().numpy(), rtol=2e-5)
+            # backward wrt input: dA = rs * (dZ @ W) * (1 - act^2)
+            dZ = torch.zeros(M, ldc, device=DEV); dZ[:, :N] = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32)).to(DEV)
+            rs = torch.from_numpy(rng.uniform(0.5, 1.5, M).astype(np.float32)).to(DEV)
+            act = torch.zeros(M, lda, device=DEV); act[:, :K] = torch.from_numpy(rng.uniform(-0.9, 0.9, (M, K)).astype(np.float32)).to(DEV)
+            dA = torch.full((M, lda), float("nan"), device=DEV)
+            if N >= 4 and K >= 4:
+                _lib.check(lib.gdmcf_linear_bwd_input_f32(dZ.data_ptr(), ldc, W.data_ptr(), ldw, rs.data_ptr(), act.data_ptr(), lda, 1,
+                                                          M, N, K, dA.data_ptr(), lda, ws.data_ptr(), ws_bytes, st))
+                r2 = rs.double()[:, None] * (dZ[:, :N].double() @ W[:, :K].double()) * (1 - act[:, :K].double() ** 2)
+                assert close(dA[:, :K].double(), r2), ("bwd_input", M, N, K, pad)
+                # backward wrt weight: dW = dZ^T @ A, db = sum_m rs*dZ
+                dW = torch.full((N, ldw), float("nan"), device=DEV)
+                db = torch.empty(N, device=DEV)
+                _lib.check(lib.gdmcf_linear_bwd_weight_f32(dZ.data_ptr(), ldc, A.data_ptr(), lda, rs.data_ptr(), M, N, K, dW.data_ptr(),
+                                                           ldw, db.data_ptr(), 0, st))
+                r3 = dZ[:, :N].double().T @ A[:, :K].double()
+                assert close(dW[:, :K].double(), r3), ("bwd_weight", M, N, K, pad)
+                np.testing.assert_allclose(db.cpu().numpy(), (rs.double()[:, None] * dZ[:, :N].double()).sum(0).cpu().numpy(),
+                                           rtol=1e-4, atol=1e-4)
+    # degenerate shapes are refused loudly, not mis-computed
+    A = torch.zeros(4, 3, device=DEV); W = torch.zeros(5, 3, device=DEV); C = torch.zeros(4, 5, device=DEV)
+    ws = torch.empty(4096, dtype=torch.uint8, device=DEV)
+    with pytest.raises(NotImplementedError):
+        _lib.check(lib.gdmcf_linear_fwd_f32(A.data_ptr(), 3, W.data_ptr(), 3, None, 0, 4, 5, 3, C.data_ptr(), 5, ws.data_ptr(), 4096, st))
