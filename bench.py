@@ -59,7 +59,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="yelp", choices=["yelp", "amazon-book"])
+    ap.add_argument("--workload", default="yelp", choices=["yelp", "amazon-book", "stress"])
+    ap.add_argument("--T", type=int, default=5, help="diffusion steps")
     ap.add_argument("--batch", type=int, default=400)
     ap.add_argument("--hidden", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -89,7 +90,7 @@ def cpu_baseline(args, I, x_batches, seconds):
     from oracle import gdmcf_oracle as O
     torch.manual_seed(0)
     om = O.DNN([I, args.hidden], [args.hidden, I], 10)
-    od = O.GaussianDiffusion(O.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, 5)
+    od = O.GaussianDiffusion(O.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, args.T)
     opt = O.make_optimizer(om, 1e-5)
     om.train()
     xs = [torch.from_numpy(b) for b in x_batches[:2]]
@@ -102,7 +103,7 @@ def cpu_baseline(args, I, x_batches, seconds):
         if (el >= seconds and n >= 3) or n >= 50:
             break
     return dict(value=round(args.batch * n / el, 2), unit="users/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{n} train steps of B={args.batch}, I={I}, dims=[{args.hidden}], T=5 (oracle, PyTorch-CPU eager)",
+                sample=f"{n} train steps of B={args.batch}, I={I}, dims=[{args.hidden}], T={args.T} (oracle, PyTorch-CPU eager)",
                 ms_per_step=round(1e3 * el / n, 2))
 
 
@@ -124,7 +125,7 @@ def main():
     from gdmcf_amd.parallel import DataParallelStep
     lib = _lib.load()
 
-    B, hid, T = args.batch, args.hidden, 5
+    B, hid, T = args.batch, args.hidden, args.T
     n_pool = 4
     indptr, indices, I = data.synth_csr(args.workload, n_rows=(world * n_pool) * B, seed=0)
     lo = rank * n_pool * B
@@ -213,9 +214,9 @@ def main():
             "metric": "training users/sec", "value": round(users / el, 1), "unit": "users/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}-shape synthetic rows, batch={B}/GPU, dims=[{hid}], T=5, "
-                                   f"noise_scale=0.01, linear-var, mean_type=x0, reweight, AdamW lr=1e-5 "
-                                   f"(BASELINE configs[1])",
+            "config": {"workload": f"{args.workload}-shape synthetic rows, batch={B}/GPU, dims=[{hid}], T={T}, "
+                                   f"noise_scale=0.01, linear-var, mean_type=x0, reweight, AdamW lr=1e-5"
+                                   + (" (BASELINE configs[1])" if args.workload == "yelp" and T == 5 and hid == 1000 else ""),
                        "n_items": I, "global_batch": world * B, "parallelism": f"dp{world}"},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": klist, "final_loss": final_loss,
         }

@@ -27,6 +27,7 @@ __device__ __forceinline__ uint32_t masked_key(const float* __restrict__ row, co
     return order_key(row[i]);
 }
 
+template <bool STAGE>
 __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ pred, int64_t ldp, int I,
                                                    const int64_t* __restrict__ indptr,
                                                    const int32_t* __restrict__ indices, int k, int KP,
@@ -40,6 +41,10 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ pre
     const int row_id = blockIdx.x;
     const float* row = pred + (int64_t)row_id * ldp;
     const int nwords = (I + 31) >> 5;
+    uint32_t* keys = bitmap + nwords;                                            // [I] when STAGE
+    // key of element i: from the LDS copy when the row fits (one global pass, 8 loads in flight per thread),
+    // otherwise recomputed from global memory in every pass
+    auto KEY = [&](int i) -> uint32_t { return STAGE ? keys[i] : masked_key(row, bitmap, i); };
 
     for (int w = tid; w < nwords; w += 256) bitmap[w] = 0u;
     for (int j = tid; j < KP; j += 256) cand[j] = 0ull;
@@ -52,28 +57,69 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ pre
         }
     }
     __syncthreads();
+    if (STAGE) {
+        int i = tid;
+        for (; i + 7 * 256 < I; i += 8 * 256) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = row[i + u * 256];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int e = i + u * 256;
+                keys[e] = (bitmap[e >> 5] & (1u << (e & 31))) ? NEG_INF_KEY : order_key(v[u]);
+            }
+        }
+        for (; i < I; i += 256) keys[i] = masked_key(row, bitmap, i);
+        __syncthreads();
+    }
 
     // radix select
     uint32_t prefix = 0, pmask = 0;
     int need = k;
     for (int shift = 24; shift >= 0; shift -= 8) {
         hist[tid] = 0u;
+        // Scores cluster (pass 1 sees ~2 exponent bins), so plain LDS atomics would serialise on one counter:
+        // every thread counts the bin of a sampled key privately and only the other bins go through atomics.
+        const uint32_t guess = (KEY(I >> 1) >> shift) & 255u;
+        uint32_t local = 0;
         __syncthreads();
         for (int i = tid; i < I; i += 256) {
-            const uint32_t key = masked_key(row, bitmap, i);
-            if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
-        }
-        __syncthreads();
-        if (tid == 0) {
-            uint32_t cum = 0;
-            int b = 255;
-            for (; b > 0; --b) {
-                if (cum + hist[b] >= (uint32_t)need) break;
-                cum += hist[b];
+            const uint32_t key = KEY(i);
+            if ((key & pmask) == prefix) {
+                const uint32_t b = (key >> shift) & 255u;
+                if (b == guess) ++local;
+                else atomicAdd(&hist[b], 1u);
             }
-            ctl[0] = (uint32_t)b;
-            ctl[1] = cum;      // elements strictly above bin b (within the prefix)
-            ctl[2] = hist[b];  // elements in bin b
+        }
+        if (local) atomicAdd(&hist[guess], local);
+        __syncthreads();
+        if (tid < 64) {
+            // find the bin holding the need-th largest key: wave 0 scans the 256 bins from the top, 4 per lane,
+            // with a shuffle prefix sum (a serial walk by one thread costs 256 dependent LDS reads per pass)
+            const int lane = tid;
+            uint32_t c[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c[j] = hist[255 - 4 * lane - j];
+            const uint32_t sum4 = c[0] + c[1] + c[2] + c[3];
+            uint32_t pre = sum4;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t t = __shfl_up(pre, o);
+                if (lane >= o) pre += t;
+            }
+            const unsigned long long hit = __ballot(pre >= (uint32_t)need);
+            const int L = hit ? (__ffsll((long long)hit) - 1) : 63;
+            if (lane == L) {
+                uint32_t cum = pre - sum4;
+                int j = 0;
+                for (; j < 3; ++j) {
+                    if (cum + c[j] >= (uint32_t)need) break;
+                    cum += c[j];
+                }
+                ctl[0] = (uint32_t)(255 - 4 * lane - j);
+                ctl[1] = cum;   // elements strictly above the bin (within the prefix)
+                ctl[2] = c[j];  // elements in the bin
+            }
         }
         __syncthreads();
         prefix |= ctl[0] << shift;
@@ -91,7 +137,7 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ pre
     if (n_eq_total == need) {
         // no surplus ties: order of collection is irrelevant
         for (int i = tid; i < I; i += 256) {
-            const uint32_t key = masked_key(row, bitmap, i);
+            const uint32_t key = KEY(i);
             if (key >= thr) {
                 const uint32_t slot = atomicAdd(&ctl[3], 1u);
                 cand[slot] = ((unsigned long long)key << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)i);
@@ -99,7 +145,7 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ pre
         }
     } else {
         for (int i = tid; i < I; i += 256) {
-            const uint32_t key = masked_key(row, bitmap, i);
+            const uint32_t key = KEY(i);
             if (key > thr) {
                 const uint32_t slot = atomicAdd(&ctl[3], 1u);
                 cand[slot] = ((unsigned long long)key << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)i);
@@ -110,7 +156,7 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ pre
         const int lane = tid & 63, wave = tid >> 6;
         for (int base = 0; base < I && taken < need; base += 256) {
             const int i = base + tid;
-            const bool f = (i < I) && (masked_key(row, bitmap, i) == thr);
+            const bool f = (i < I) && (KEY(i) == thr);
             const unsigned long long bal = __ballot(f);
             if (lane == 0) ctl[4 + wave] = (uint32_t)__popcll(bal);
             __syncthreads();
@@ -340,24 +386,32 @@ int gdmcf_topk_masked_f32(const float* pred, int64_t ldp, int B, int I, const in
     GD_CHECK_ARG((mask_indptr == nullptr) == (mask_indices == nullptr), "topk: mask indptr/indices mismatch");
     int KP = 2;
     while (KP < k) KP <<= 1;
-    const size_t lds = (size_t)KP * 8 + (256 + 8) * 4 + (size_t)((I + 31) / 32) * 4;
+    const size_t lds_base = (size_t)KP * 8 + (256 + 8) * 4 + (size_t)((I + 31) / 32) * 4;
+    const bool stage = lds_base + (size_t)I * 4 <= 150 * 1024;
+    const size_t lds = lds_base + (stage ? (size_t)I * 4 : 0);
     if (lds > 160 * 1024) {
         gdmcf_set_error("topk: row width %d needs %zu B of LDS (> 160 KiB)", I, lds);
         return GDMCF_E_UNSUPPORTED;
     }
-    static size_t attr_lds = 0;
-    if (lds > 48 * 1024 && lds > attr_lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(topk_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) {
-            gdmcf_set_error("topk: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(topk_kernel<true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(topk_kernel<false>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e1 != hipSuccess || e2 != hipSuccess) {
+            gdmcf_set_error("topk: hipFuncSetAttribute failed");
             return GDMCF_E_HIP;
         }
-        attr_lds = 160 * 1024;
+        attr_set = true;
     }
     GdProfScope prof(9, 4.0 * B * (double)I, (hipStream_t)stream);
-    hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, pred, ldp, I, mask_indptr,
-                       mask_indices, k, KP, idx_out, val_out);
+    if (stage)
+        hipLaunchKernelGGL(topk_kernel<true>, dim3(B), dim3(256), lds, (hipStream_t)stream, pred, ldp, I, mask_indptr,
+                           mask_indices, k, KP, idx_out, val_out);
+    else
+        hipLaunchKernelGGL(topk_kernel<false>, dim3(B), dim3(256), lds, (hipStream_t)stream, pred, ldp, I, mask_indptr,
+                           mask_indices, k, KP, idx_out, val_out);
     return gd_launch_status("topk");
 }
 
