@@ -222,6 +222,25 @@ class GaussianDiffusion(nn.Module):
                                               noise0=noise0, step_noise=step_noise, capture=capture)
 
 
+class GaussianDiffusionDiscrete(GaussianDiffusion):
+    """The class the shipped main.py actually constructs (main.py:192-193; reference :552-1135).
+
+    With `CatOneHot=False` its `training_losses` is bit-identical to `GaussianDiffusion.training_losses`
+    (SURVEY F6), which is what runs here.  Its `p_sample` additionally samples a degree-guided one-hot graph per
+    step (:706-744) that only GCN backbones consume (`graph=` argument of DNNOneHotEmbeddingGCN, SURVEY 8f1);
+    the plain DNN denoiser never sees it, so with a `gdmcf_amd.DNN` model the result equals the continuous
+    reverse loop implemented by the parent class.  The one-hot / GCN variant itself is a "next" row (f1)."""
+
+    def __init__(self, mean_type, noise_schedule, noise_scale, noise_min, noise_max, steps, device,
+                 history_num_per_term=10, beta_fixed=True, discrete=0.99, CatOneHot=False, epps=0.9995, args=None):
+        super().__init__(mean_type, noise_schedule, noise_scale, noise_min, noise_max, steps, device,
+                         history_num_per_term=history_num_per_term, beta_fixed=beta_fixed, discrete=discrete,
+                         CatOneHot=CatOneHot, epps=epps, args=args)
+        self.args = args
+        self.discrete_noise = True
+        self.indexIn = False
+
+
 # ---- module-level helpers of the reference file (kept for API parity) -------------------------------
 def betas_from_linear_variance(steps, variance, max_beta=0.999):
     alpha_bar = 1 - variance

@@ -61,6 +61,13 @@ def test_diffusion_object_surface_and_weights():
     np.testing.assert_array_equal(d._weights["x0"].numpy(), fx["c0.snr_weight_x0"])
     np.testing.assert_array_equal(d.posterior_mean_coef1.numpy(), fx["c0.posterior_mean_coef1"])
     d.gcn, d.indexIn = 0, None  # attributes main.py pokes (:222, :241)
+    # main.py:192-193 builds the Discrete class with these extra keywords and calls .to(device)
+    dd = gdmcf_amd.GaussianDiffusionDiscrete(gdmcf_amd.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, 5, "cpu",
+                                             discrete=0.99, CatOneHot=False, epps=0.9995, args=None).to("cpu")
+    np.testing.assert_array_equal(dd.betas.numpy(), d.betas.numpy())
+    with pytest.raises(NotImplementedError):
+        gdmcf_amd.GaussianDiffusionDiscrete(gdmcf_amd.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, 5, "cpu",
+                                            CatOneHot=True)
 
 
 def test_dnn_surface_matches_reference_init_and_names():
