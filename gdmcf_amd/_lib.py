@@ -41,6 +41,8 @@ _SIGNATURES = {
     "gdmcf_linear_bwd_input_f32": (c_int, [P, c_int64, P, c_int64, P, P, c_int64, c_int, c_int, c_int, c_int, P,
                                            c_int64, P, c_size_t, P]),
     "gdmcf_linear_bwd_weight_f32": (c_int, [P, c_int64, P, c_int64, P, c_int, c_int, c_int, P, c_int64, P, c_int, P]),
+    "gdmcf_linear_bwd_weight_adamw_f32": (c_int, [P, c_int64, P, c_int64, P, c_int, c_int, c_int, P, c_int64, P, P, P, c_float,
+                                                  c_float, c_float, c_float, c_float, c_int, c_float, P]),
     "gdmcf_rowscale_f32": (c_int, [P, c_int64, P, c_int, c_int, P, c_int64, P]),
     "gdmcf_emb_bwd_f32": (c_int, [P, c_int64, P, c_int64, c_int, c_int, P, c_int, c_int, P, P, P, P]),
     "gdmcf_row_loss_finish_f64": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, P, P, c_int, P, P, P, P]),

@@ -55,7 +55,30 @@ static inline bool gd_aligned16(const void* p) { return (reinterpret_cast<uintpt
 
 // ---- GEMM core (gemm_f32.hip) -----------------------------------------------------------
 enum { GD_LAY_KC = 0, GD_LAY_MC = 1 };  // operand stored [rows][K] (K contiguous) / [K][rows]
-enum { GD_EPI_SLAB = 0, GD_EPI_BIAS_ACT = 1, GD_EPI_LOSS = 2, GD_EPI_POST = 3, GD_EPI_STORE = 4 };
+enum { GD_EPI_SLAB = 0, GD_EPI_BIAS_ACT = 1, GD_EPI_LOSS = 2, GD_EPI_POST = 3, GD_EPI_STORE = 4, GD_EPI_ADAMW = 5 };
+
+// AdamW scalars (torch.optim.AdamW single-tensor math), shared by the stand-alone kernel and the fused epilogue
+struct GdAdamHyper {
+    float decay;     // 1 - lr*wd
+    float one_m_b1;  // 1 - beta1
+    float beta2;
+    float one_m_b2;
+    float bc2_sqrt;  // sqrt(1 - beta2^step)
+    float eps;
+    float neg_step;  // -lr / (1 - beta1^step)
+    float grad_scale;
+};
+GdAdamHyper gd_adam_hyper(float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale);
+
+__device__ __forceinline__ void gd_adam_elem(float& p, float g, float& m, float& v, const GdAdamHyper& h) {
+    g *= h.grad_scale;
+    p = p * h.decay;
+    m = m + (g - m) * h.one_m_b1;
+    v = v * h.beta2;
+    v = v + (h.one_m_b2 * g) * g;
+    const float denom = sqrtf(v) / h.bc2_sqrt + h.eps;
+    p = p + (h.neg_step * m) / denom;
+}
 
 struct GdGemm {
     const float* A;
@@ -87,6 +110,7 @@ struct GdGemm {
     int ld_rowpart;
     int accumulate;
     int prof_tag;
+    GdAdamHyper adam;  // GD_EPI_ADAMW: C = parameter, aux = exp_avg, aux2 = exp_avg_sq (all [M,N], ldc)
     int stagger;  // startup delay (x512 clocks) for workgroups in odd wave slots; de-phases co-resident workgroups
 };
 

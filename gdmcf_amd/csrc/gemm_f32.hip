@@ -499,7 +499,42 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GdGemm g) {
         biasv[j] = 0.f;
         if ((EPI == GD_EPI_BIAS_ACT || EPI == GD_EPI_LOSS || EPI == GD_EPI_POST) && g.bias) biasv[j] = g.bias[ncl[j]];
     }
-    if (EPI == GD_EPI_SLAB || EPI == GD_EPI_STORE || EPI == GD_EPI_BIAS_ACT) {
+    if (EPI == GD_EPI_ADAMW) {
+        // Fused optimiser: the tile of the weight gradient never leaves the accumulators.  Per 16-row block:
+        // load p, exp_avg, exp_avg_sq (clamped indices, all in flight), update, predicated stores.
+        float* __restrict__ P = g.C;
+        float* __restrict__ Mo = const_cast<float*>(g.aux);
+        float* __restrict__ Vo = const_cast<float*>(g.aux2);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float pv[4][TN], mv[4][TN], vv[4][TN];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int mc = min(m0 + wm0 + 16 * i + 4 * q + e, g.M - 1);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int64_t o = (int64_t)mc * g.ldc + ncl[j];
+                    pv[e][j] = P[o];
+                    mv[e][j] = Mo[o];
+                    vv[e][j] = Vo[o];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = m0 + wm0 + 16 * i + 4 * q + e;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    gd_adam_elem(pv[e][j], acc[i][j][e], mv[e][j], vv[e][j], g.adam);
+                    if (m < g.M && nok[j]) {
+                        const int64_t o = (int64_t)m * g.ldc + ncl[j];
+                        P[o] = pv[e][j];
+                        Mo[o] = mv[e][j];
+                        Vo[o] = vv[e][j];
+                    }
+                }
+            }
+        }
+    } else if (EPI == GD_EPI_SLAB || EPI == GD_EPI_STORE || EPI == GD_EPI_BIAS_ACT) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -691,6 +726,7 @@ int gd_gemm_launch(int layA, int layB, int epi, int cls, GdGemm& g, hipStream_t 
         static const int tn_bk = getenv("GDMCF_TN_BK") ? atoi(getenv("GDMCF_TN_BK")) : 16;  // tuning knob
         if (epi == GD_EPI_STORE && tn_bk == 32) return launch_class<GD_LAY_MC, GD_LAY_MC, 32, GD_EPI_STORE>(cls, g, s);
         if (epi == GD_EPI_STORE) return launch_class<GD_LAY_MC, GD_LAY_MC, 16, GD_EPI_STORE>(cls, g, s);
+        if (epi == GD_EPI_ADAMW) return launch_class<GD_LAY_MC, GD_LAY_MC, 16, GD_EPI_ADAMW>(cls, g, s);
     }
     gdmcf_set_error("unsupported gemm variant (layA=%d layB=%d epi=%d)", layA, layB, epi);
     return GDMCF_E_UNSUPPORTED;

@@ -459,26 +459,8 @@ __global__ __launch_bounds__(256) void sample_timesteps_kernel(const double* __r
 // ---------------------------------------------------------------------------------------------
 constexpr int ADAM_BLOCK_ELEMS = 4096;
 
-struct AdamHyper {
-    float decay;      // 1 - lr*wd
-    float one_m_b1;   // 1 - beta1
-    float beta2;
-    float one_m_b2;
-    float bc2_sqrt;   // sqrt(1 - beta2^step)
-    float eps;
-    float neg_step;   // -lr / (1 - beta1^step)
-    float grad_scale;
-};
-
-__device__ __forceinline__ void adam_elem(float& p, float g, float& m, float& v, const AdamHyper& h) {
-    g *= h.grad_scale;
-    p = p * h.decay;
-    m = m + (g - m) * h.one_m_b1;
-    v = v * h.beta2;
-    v = v + (h.one_m_b2 * g) * g;
-    const float denom = sqrtf(v) / h.bc2_sqrt + h.eps;
-    p = p + (h.neg_step * m) / denom;
-}
+typedef GdAdamHyper AdamHyper;
+#define adam_elem gd_adam_elem
 
 __global__ __launch_bounds__(256) void adamw_kernel(const int64_t* __restrict__ table, int n_tensors,
                                                     const AdamHyper h) {
@@ -659,18 +641,7 @@ int gdmcf_sample_timesteps(const double* Lt_history, const int64_t* Lt_count, in
 int gdmcf_adamw_f32(const int64_t* table, int n_tensors, int total_blocks, float lr, float beta1, float beta2,
                     float eps, float weight_decay, int step, float grad_scale, void* stream) {
     GD_CHECK_ARG(n_tensors > 0 && total_blocks > 0 && step >= 1, "adamw: bad arguments");
-    AdamHyper h;
-    // scalars formed in double exactly as torch/optim/adamw.py does, then narrowed to f32
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    h.decay = (float)(1.0 - (double)lr * (double)weight_decay);
-    h.one_m_b1 = (float)(1.0 - (double)beta1);
-    h.beta2 = beta2;
-    h.one_m_b2 = (float)(1.0 - (double)beta2);
-    h.bc2_sqrt = (float)sqrt(bc2);
-    h.eps = eps;
-    h.neg_step = (float)(-((double)lr / bc1));
-    h.grad_scale = grad_scale;
+    const AdamHyper h = gd_adam_hyper(lr, beta1, beta2, eps, weight_decay, step, grad_scale);
     {
         GdProfScope prof(6, 28.0 * ADAM_BLOCK_ELEMS * (double)total_blocks, (hipStream_t)stream);
         hipLaunchKernelGGL(adamw_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, table, n_tensors, h);
@@ -694,6 +665,22 @@ int gdmcf_scale_f32(const float* acc, int64_t n, float scale, float* out, void* 
 }
 
 }  // extern "C"
+
+GdAdamHyper gd_adam_hyper(float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale) {
+    // scalars formed in double exactly as torch/optim/adamw.py does, then narrowed to f32
+    GdAdamHyper h;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    h.decay = (float)(1.0 - (double)lr * (double)weight_decay);
+    h.one_m_b1 = (float)(1.0 - (double)beta1);
+    h.beta2 = beta2;
+    h.one_m_b2 = (float)(1.0 - (double)beta2);
+    h.bc2_sqrt = (float)sqrt(bc2);
+    h.eps = eps;
+    h.neg_step = (float)(-((double)lr / bc1));
+    h.grad_scale = grad_scale;
+    return h;
+}
 
 // ---- internal helpers used by linear.hip ---------------------------------------------------------
 int gd_splitk_reduce(const float* slabs, int64_t slab_stride, int splits, int64_t ld_slab, int M, int N, int mode,

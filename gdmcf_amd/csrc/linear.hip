@@ -149,4 +149,23 @@ int gdmcf_linear_bwd_weight_f32(const float* dZ, int64_t lddz, const float* A, i
     return GDMCF_OK;
 }
 
+int gdmcf_linear_bwd_weight_adamw_f32(const float* dZ, int64_t lddz, const float* A, int64_t lda, const float* rowscale,
+                                      int M, int N, int K, float* W, int64_t ldw, float* exp_avg, float* exp_avg_sq,
+                                      float* db, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                      int step, float grad_scale, void* stream) {
+    GD_CHECK_SHAPE(M > 0 && N > 0 && K > 0 && lddz >= N && lda >= K && ldw >= K, "linear_bwd_weight_adamw: bad shape");
+    GD_CHECK_ARG(W && exp_avg && exp_avg_sq && step >= 1, "linear_bwd_weight_adamw: optimizer state missing");
+    hipStream_t s = (hipStream_t)stream;
+    const int cls = gd_pick_shape_class(N, K);
+    GdGemm g = {};
+    g.A = dZ; g.lda = lddz; g.B = A; g.ldb = lda; g.M = N; g.N = K; g.K = M; g.splits = 1;
+    g.m_fastest = gd_cdiv(N, gd_gemm_tile_m(cls)) <= gd_cdiv(K, gd_gemm_tile_n(cls));
+    g.C = W; g.ldc = ldw; g.aux = exp_avg; g.aux2 = exp_avg_sq; g.prof_tag = 5;
+    g.adam = gd_adam_hyper(lr, beta1, beta2, eps, weight_decay, step, grad_scale);
+    int rc = gd_gemm_launch(GD_LAY_MC, GD_LAY_MC, GD_EPI_ADAMW, cls, g, s);
+    if (rc) return rc;
+    if (db) return gd_colsum(dZ, lddz, rowscale, M, N, db, s);
+    return GDMCF_OK;
+}
+
 }  // extern "C"

@@ -42,6 +42,9 @@ class DenoiserEngine:
         # all-reduce of the big weight gradients overlaps the rest of the backward (gdmcf_amd/parallel.py).
         # When set, the engine assigns .grad itself and hands autograd None for that parameter.
         self.grad_sink = None
+        # single-GPU optimiser-in-backward (FusedAdamW.fuse_into_backward): big weights are updated inside the
+        # weight-gradient GEMM's epilogue; their gradient is never materialised.
+        self.fused_opt = None
 
     def manual_seed(self, seed):
         self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
@@ -219,36 +222,23 @@ class DenoiserEngine:
     # ------------------------------------------------------------------------------------------
     def _backward(self, sv, dz_last, ld_last, rowscale):
         """Gradients in model.parameters() order: emb_layer (w, b), in_layers..., out_layers...
-        dz_last is d(loss)/d(last layer output) up to the per-row factor `rowscale`."""
+        dz_last is d(loss)/d(last layer output) up to the per-row factor `rowscale`.
+
+        Order inside a layer: data parallel wants the weight gradient first (its all-reduce then overlaps the
+        input-gradient GEMM); the fused optimiser needs the input gradient first (it reads W, which the
+        weight-gradient epilogue then overwrites)."""
         lib, st = self.lib, _lib.stream_ptr()
         bufs, layers, B = sv["bufs"], sv["layers"], sv["B"]
-        dev = dz_last.device
+        m = self.model
         L = len(layers)
         grads_w = [None] * L
         grads_b = [None] * L
+        dWe = dbe = None
+        fused = self.fused_opt if self.grad_sink is None else None
         dz, lddz, rs = dz_last, ld_last, rowscale
-        for li in range(L - 1, -1, -1):
-            w, bias, _ = layers[li]
-            N, K = w.shape
-            if li > 0:
-                A_prev, lda_prev = bufs.acts[li - 1], bufs.acts[li - 1].stride(0)
-            else:
-                A_prev, lda_prev = bufs.xin, bufs.ldk
-            dW = torch.empty_like(w)
-            db = torch.empty_like(bias)
-            A_use, lda_use = A_prev, lda_prev
-            if rs is not None:
-                # (rs . dZ)^T A == dZ^T (rs . A): scale the small activation instead of the big dZ
-                _lib.check(lib.gdmcf_rowscale_f32(A_prev.data_ptr(), lda_prev, rs.data_ptr(), B, K, bufs.hs.data_ptr(),
-                                                  bufs.hs.stride(0), st))
-                A_use, lda_use = bufs.hs, bufs.hs.stride(0)
-            _lib.check(lib.gdmcf_linear_bwd_weight_f32(dz.data_ptr(), lddz, A_use.data_ptr(), lda_use, _lib.ptr(rs), B,
-                                                       N, K, dW.data_ptr(), dW.stride(0), db.data_ptr(), 0, st))
-            grads_w[li], grads_b[li] = dW, db
-            if self.grad_sink is not None:
-                self.grad_sink(w, dW)
-                self.grad_sink(bias, db)
-                grads_w[li] = grads_b[li] = None
+
+        def input_grad(li, w, A_prev, lda_prev, N, K):
+            nonlocal dWe, dbe
             if li > 0:
                 dprev = bufs.dzs[li - 1]
                 act_prev = layers[li - 1][2]
@@ -256,14 +246,53 @@ class DenoiserEngine:
                                                           A_prev.data_ptr(), lda_prev, act_prev, B, N, K,
                                                           dprev.data_ptr(), dprev.stride(0), bufs.ws.data_ptr(),
                                                           bufs.ws_bytes, st))
-                dz, lddz, rs = dprev, dprev.stride(0), None
-        m = self.model
-        dWe = torch.empty_like(m.emb_layer.weight)
-        dbe = torch.empty_like(m.emb_layer.bias)
-        w0 = layers[0][0]
-        _lib.check(lib.gdmcf_emb_bwd_f32(dz.data_ptr(), lddz, w0.data_ptr(), w0.stride(0), self.I, self.E,
-                                         bufs.temb.data_ptr(), B, w0.shape[0], bufs.demb.data_ptr(), dWe.data_ptr(),
-                                         dbe.data_ptr(), st))
+                return dprev, dprev.stride(0), None
+            dWe = torch.empty_like(m.emb_layer.weight)
+            dbe = torch.empty_like(m.emb_layer.bias)
+            _lib.check(lib.gdmcf_emb_bwd_f32(dz.data_ptr(), lddz, w.data_ptr(), w.stride(0), self.I, self.E,
+                                             bufs.temb.data_ptr(), B, w.shape[0], bufs.demb.data_ptr(), dWe.data_ptr(),
+                                             dbe.data_ptr(), st))
+            return None, 0, None
+
+        def weight_grad(li, w, bias, A_prev, lda_prev, N, K):
+            db = torch.empty_like(bias)
+            A_use, lda_use = A_prev, lda_prev
+            if rs is not None:
+                # (rs . dZ)^T A == dZ^T (rs . A): scale the small activation instead of the big dZ
+                _lib.check(lib.gdmcf_rowscale_f32(A_prev.data_ptr(), lda_prev, rs.data_ptr(), B, K, bufs.hs.data_ptr(),
+                                                  bufs.hs.stride(0), st))
+                A_use, lda_use = bufs.hs, bufs.hs.stride(0)
+            fs = fused.fused_state(w) if fused is not None else None
+            if fs is not None:
+                _lib.check(lib.gdmcf_linear_bwd_weight_adamw_f32(
+                    dz.data_ptr(), lddz, A_use.data_ptr(), lda_use, _lib.ptr(rs), B, N, K, w.data_ptr(), w.stride(0),
+                    fs["exp_avg"].data_ptr(), fs["exp_avg_sq"].data_ptr(), db.data_ptr(), fs["lr"], fs["beta1"],
+                    fs["beta2"], fs["eps"], fs["weight_decay"], fs["step"], fs["grad_scale"], st))
+                dW = None
+            else:
+                dW = torch.empty_like(w)
+                _lib.check(lib.gdmcf_linear_bwd_weight_f32(dz.data_ptr(), lddz, A_use.data_ptr(), lda_use, _lib.ptr(rs),
+                                                           B, N, K, dW.data_ptr(), dW.stride(0), db.data_ptr(), 0, st))
+            grads_w[li], grads_b[li] = dW, db
+            if self.grad_sink is not None:
+                self.grad_sink(w, dW)
+                self.grad_sink(bias, db)
+                grads_w[li] = grads_b[li] = None
+
+        for li in range(L - 1, -1, -1):
+            w, bias, _ = layers[li]
+            N, K = w.shape
+            if li > 0:
+                A_prev, lda_prev = bufs.acts[li - 1], bufs.acts[li - 1].stride(0)
+            else:
+                A_prev, lda_prev = bufs.xin, bufs.ldk
+            if fused is not None:
+                nxt = input_grad(li, w, A_prev, lda_prev, N, K)
+                weight_grad(li, w, bias, A_prev, lda_prev, N, K)
+            else:
+                weight_grad(li, w, bias, A_prev, lda_prev, N, K)
+                nxt = input_grad(li, w, A_prev, lda_prev, N, K)
+            dz, lddz, rs = nxt
         if self.grad_sink is not None:
             self.grad_sink(m.emb_layer.weight, dWe)
             self.grad_sink(m.emb_layer.bias, dbe)

@@ -99,6 +99,9 @@ class DataParallelStep:
             diffusion.update_history = False  # replayed below on the gathered global batch
             optimizer.grad_scale = 1.0 / self.world
             broadcast_parameters(model, group)
+            model.engine.fused_opt = None  # gradients must be all-reduced before the update
+            if hasattr(optimizer, "_fused_ids"):
+                optimizer._fused_ids = set()
             if overlap:
                 model.engine.grad_sink = self._sink
 

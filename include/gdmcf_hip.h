@@ -142,6 +142,16 @@ int gdmcf_linear_bwd_input_f32(const float* dZ, int64_t lddz, const float* W, in
 int gdmcf_linear_bwd_weight_f32(const float* dZ, int64_t lddz, const float* A, int64_t lda,
                                 const float* rowscale, int M, int N, int K, float* dW,
                                 int64_t lddw, float* db, int accumulate, void* stream);
+/* Weight gradient fused with the AdamW update of that weight (single-GPU optimiser-in-backward, opt-in):
+ * G = dZ^T @ A stays in the MFMA accumulators and W, exp_avg, exp_avg_sq ([N,K], row stride ldw, all three) are
+ * updated in the epilogue with torch.optim.AdamW's single-tensor math for step number `step`
+ * (32 -> 24 B/param of HBM traffic; the gradient is never materialised).  W must not be read by later
+ * kernels of the same backward pass (the caller computes the input gradient first).              */
+int gdmcf_linear_bwd_weight_adamw_f32(const float* dZ, int64_t lddz, const float* A, int64_t lda,
+                                      const float* rowscale, int M, int N, int K, float* W, int64_t ldw,
+                                      float* exp_avg, float* exp_avg_sq, float* db, float lr, float beta1,
+                                      float beta2, float eps, float weight_decay, int step,
+                                      float grad_scale, void* stream);
 int gdmcf_rowscale_f32(const float* A, int64_t lda, const float* rowscale, int M, int K, float* out,
                        int64_t ldo, void* stream);
 /* Gradients of the timestep-embedding branch (models/DNN.py:73-74,78):

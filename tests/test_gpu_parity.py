@@ -621,3 +621,43 @@ def test_linear_entry_points_random_shapes():
     ws = torch.empty(4096, dtype=torch.uint8, device=DEV)
     with pytest.raises(NotImplementedError):
         _lib.check(lib.gdmcf_linear_fwd_f32(A.data_ptr(), 3, W.data_ptr(), 3, None, 0, 4, 5, 3, C.data_ptr(), 5, ws.data_ptr(), 4096, st))
+
+
+def test_fused_optimizer_in_backward_equals_step():
+    """FusedAdamW.fuse_into_backward: same weights, moments, biases and losses as the unfused optimiser (the update
+    runs in the weight-gradient GEMM's epilogue on the very same accumulators), over several steps incl. weight decay."""
+    fx = H.load("train_ragged_x0")
+    meta = H.train_meta(fx)
+
+    def run(fuse):
+        model, diff = gpu_model(meta, fx), gpu_diffusion(meta)
+        opt = gdmcf_amd.FusedAdamW(model.parameters(), lr=1e-3, weight_decay=0.01)
+        if fuse:
+            opt.fuse_into_backward(model, min_numel=1024)
+            assert model.engine.fused_opt is opt and len(opt._fused_ids) == 2
+        model.train()
+        losses = []
+        for s_ in range(meta["n_steps"]):
+            inp = H.step_inputs(fx, s_)
+            opt.zero_grad()
+            l = diff.training_losses(model, cu(inp["x"]), True, ts=cu(inp["ts"]), pt=cu(inp["pt"]), noise=cu(inp["noise"]),
+                                     drop_mask=cu(inp["drop_mask"]))["loss"].mean()
+            l.backward()
+            if fuse:
+                assert model.in_layers[0].weight.grad is None and model.in_layers[0].bias.grad is not None
+            opt.step()
+            losses.append(float(l.detach()))
+        return model, opt, losses
+
+    m0, o0, l0 = run(False)
+    m1, o1, l1 = run(True)
+    np.testing.assert_allclose(l1, l0, rtol=1e-6)
+    for (k, a), (_, b) in zip(m0.named_parameters(), m1.named_parameters()):
+        # same math, compiled in two contexts (FMA contraction may differ): bound on the lr scale (3 steps of 1e-3)
+        assert float((a - b).abs().max()) <= 2e-3 * 1e-3 * meta["n_steps"], k
+        assert int(o0.state[a]["step"]) == int(o1.state[b]["step"]) == meta["n_steps"]
+        assert H.relerr(o1.state[b]["exp_avg"].cpu().numpy(), o0.state[a]["exp_avg"].cpu().numpy()) < 1e-6, k
+        assert H.relerr(o1.state[b]["exp_avg_sq"].cpu().numpy(), o0.state[a]["exp_avg_sq"].cpu().numpy()) < 1e-6, k
+    # and the reference's weights after these steps (golden) within the usual lr-scale bound
+    for k, v in m1.named_parameters():
+        assert np.abs(v.detach().cpu().numpy() - fx["pN." + k]).max() < 0.05 * 1e-3 * meta["n_steps"], k
