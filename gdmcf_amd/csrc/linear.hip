@@ -1,5 +1,7 @@
 // C-ABI entry points for the denoiser's dense layers: forward (plain / fused row-loss / fused
 // posterior mean) and backward (input grad, weight grad).  All of them drive gemm_f32.hip.
+#include <stdlib.h>
+
 #include "common.h"
 
 int gd_splitk_reduce(const float* slabs, int64_t slab_stride, int splits, int64_t ld_slab, int M, int N, int mode,
@@ -10,7 +12,9 @@ int gd_rowpart_reduce(const float* rowpart, int ld, int M, int nt, float* rowsum
 
 namespace {
 
-constexpr int TARGET_WGS = 512;  // 256 CUs x 2 resident workgroups
+// workgroups aimed at by the split-K heuristic: 256 CUs x 2 resident, times ~1.5 so the second wave of
+// workgroups evens out the tail (measured sweet spot on the batch-400 products; GDMCF_TARGET_WGS overrides)
+static const int TARGET_WGS = getenv("GDMCF_TARGET_WGS") ? atoi(getenv("GDMCF_TARGET_WGS")) : 760;
 
 // number of K splits for an [M,N,K] product whose output is small (batch x hidden)
 int pick_splits(int M, int N, int K, int cls, int bk) {

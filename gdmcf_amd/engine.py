@@ -12,7 +12,6 @@ HBM layout (all float32 row-major, leading dims padded to 64 elements = 256 B):
   diff  [B, ldi]  alpha*out - target (the last layer's output is never stored in training)
   slabs           split-K partial sums (forward of layer 0, input-gradient of the last layer)
 """
-import ctypes
 
 import torch
 

@@ -10,7 +10,6 @@ the CPU oracle on identical inputs.  Without them noise and dropout come from an
 Philox stream and are never materialised in HBM.
 """
 import enum
-import math
 
 import numpy as np
 import torch

@@ -257,7 +257,6 @@ def gen_sample(name, B, I, dims, T, mean_type, seed=0, density=0.08, scale=0.01,
 
 # ----------------------------------------------------------------------------------------
 def gen_lightgcn(name, U, It, d, L, nnz, seed=0):
-    import __main__
     rng = np.random.default_rng(seed)
     users = rng.integers(0, U, nnz)
     items = np.minimum((rng.pareto(1.2, nnz) * It / 20).astype(np.int64), It - 1)  # skewed popularity

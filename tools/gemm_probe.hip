@@ -40,7 +40,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&h, (size_t)B * ldh * 4));
     CK(hipMalloc(&diff, (size_t)B * ldi * 4));
     CK(hipMalloc(&tgt, (size_t)B * I * 4));
-    CK(hipMalloc(&slab, (size_t)16 * B * 1024 * 4));
+    CK(hipMalloc(&slab, (size_t)64 * B * 1024 * 4));  // up to 64 splits
     CK(hipMalloc(&dW1, (size_t)H * (I + E) * 4));
     CK(hipMalloc(&dW2, (size_t)I * H * 4));
     CK(hipMalloc(&rowpart, (size_t)B * 1024 * 4));

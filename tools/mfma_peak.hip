@@ -33,6 +33,36 @@ __global__ __launch_bounds__(256) void k32(float* out, int iters, float a0, floa
     for (int i = 0; i < NACC; ++i) for (int e = 0; e < 16; ++e) r += acc[i][e];
     out[blockIdx.x * 256 + threadIdx.x] = r;
 }
+// the GEMM kernel's pattern: TM x TN accumulators, distinct A/B operand registers per k-step, optional fences
+template <int TM, int TN, bool FENCE, bool VARY>
+__global__ __launch_bounds__(256) void kpat(float* out, int iters, float a0, float b0) {
+    f32x4 acc[TM][TN];
+    for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+    float fa[2][TM][4], fb[2][TN][4];
+    for (int p = 0; p < 2; ++p) {
+        for (int i = 0; i < TM; ++i) for (int s = 0; s < 4; ++s) fa[p][i][s] = a0 + threadIdx.x + i + s + p;
+        for (int j = 0; j < TN; ++j) for (int s = 0; s < 4; ++s) fb[p][j][s] = b0 + j - s + p;
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int gi = 0; gi < 8; ++gi) {
+            const int par = VARY ? ((gi >> 2) & 1) : 0, sg = VARY ? (gi & 3) : 0;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[par][VARY ? i : 0][sg], fb[par][VARY ? j : 0][sg], acc[i][j], 0, 0, 0);
+            if (FENCE) __builtin_amdgcn_sched_barrier(0);
+        }
+        if (VARY) {  // keep the operands opaque like freshly loaded fragments
+            for (int i = 0; i < TM; ++i) for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(fa[0][i][s]), "+v"(fa[1][i][s]));
+            for (int j = 0; j < TN; ++j) for (int s = 0; s < 4; ++s) asm volatile("" : "+v"(fb[0][j][s]), "+v"(fb[1][j][s]));
+        }
+    }
+    f32x4 r = {0, 0, 0, 0};
+    for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) r += acc[i][j];
+    out[blockIdx.x * 256 + threadIdx.x] = r.x + r.y + r.z + r.w;
+}
 template <class K>
 void run(const char* name, K kern, int blocks, int iters, double flop_per_mfma, int mfma_per_iter, size_t lds) {
     float* out;
@@ -63,5 +93,10 @@ int main() {
     run("16x16x4 2acc  1 WG/CU", k16<2>, 256, it, 2048, 16, 100 * 1024);
     run("32x32x2 4acc  1 WG/CU", k32<4>, 256, it, 4096, 32, 100 * 1024);
     run("32x32x2 4acc  2 WG/CU", k32<4>, 512, it, 4096, 32, 60 * 1024);
+    run("pattern 5x2 same operands, no fence 2WG", kpat<5, 2, false, false>, 512, it, 2048, 80, 60 * 1024);
+    run("pattern 5x2 varied operands, no fence 2WG", kpat<5, 2, false, true>, 512, it, 2048, 80, 60 * 1024);
+    run("pattern 5x2 varied operands, fences  2WG", kpat<5, 2, true, true>, 512, it, 2048, 80, 60 * 1024);
+    run("pattern 5x2 varied operands, fences  1WG", kpat<5, 2, true, true>, 256, it, 2048, 80, 100 * 1024);
+    run("pattern 4x4 varied operands, fences  2WG", kpat<4, 4, true, true>, 512, it, 2048, 128, 60 * 1024);
     return 0;
 }
