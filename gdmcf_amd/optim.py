@@ -73,43 +73,68 @@ class FusedAdamW(torch.optim.Optimizer):
             cache[key] = hit
         return hit
 
+    def _launch(self, gi, group, plist, step):
+        lib = _lib.load()
+        for p in plist:
+            _lib.require_gpu(p, "FusedAdamW parameter")
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise RuntimeError("FusedAdamW: parameters must be contiguous float32")
+            if p.grad.is_sparse:
+                raise RuntimeError("FusedAdamW does not support sparse gradients")
+            if not p.grad.is_contiguous() or p.grad.dtype != torch.float32:
+                p.grad = p.grad.float().contiguous()
+        table, nblk = self._table(gi, plist)
+        b1, b2 = group["betas"]
+        _lib.check(lib.gdmcf_adamw_f32(table.data_ptr(), len(plist), nblk, group["lr"], b1, b2, group["eps"],
+                                       group["weight_decay"], step, float(self.grad_scale), _lib.stream_ptr()))
+
+    def _init_state(self, p):
+        st = self.state[p]
+        if len(st) == 0:
+            st["step"] = 0
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        return st
+
+    @torch.no_grad()
+    def step_subset(self, params):
+        """Apply this step's update to `params` now; the following step() handles the remaining tensors and skips
+        these.  Lets a data-parallel driver update a tensor as soon as its all-reduce has finished while other
+        gradients are still on the wire."""
+        params = [p for p in params if p.grad is not None]
+        for gi, group in enumerate(self.param_groups):
+            plist = [p for p in group["params"] if any(p is q for q in params)]
+            if not plist:
+                continue
+            sts = [self._init_state(p) for p in plist]
+            if any(st.get("_fused_pending") for st in sts):
+                raise RuntimeError("FusedAdamW.step_subset: tensor already updated in this step")
+            self._launch(gi, group, plist, int(sts[0]["step"]) + 1)
+            for st in sts:
+                st["_fused_pending"] = True
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        lib = _lib.load()
         for gi, group in enumerate(self.param_groups):
-            for p in group["params"]:  # weights already updated inside the backward pass
+            done = set()
+            for p in group["params"]:  # tensors already updated (inside the backward pass or by step_subset)
                 st = self.state.get(p)
                 if st and st.get("_fused_pending"):
                     st["step"] = int(st["step"]) + 1
                     st["_fused_pending"] = False
-            plist = [p for p in group["params"] if p.grad is not None]
+                    done.add(id(p))
+            plist = [p for p in group["params"] if p.grad is not None and id(p) not in done]
             if not plist:
                 continue
-            for p in plist:
-                _lib.require_gpu(p, "FusedAdamW parameter")
-                if p.dtype != torch.float32 or not p.is_contiguous():
-                    raise RuntimeError("FusedAdamW: parameters must be contiguous float32")
-                if p.grad.is_sparse:
-                    raise RuntimeError("FusedAdamW does not support sparse gradients")
-                if not p.grad.is_contiguous() or p.grad.dtype != torch.float32:
-                    p.grad = p.grad.float().contiguous()
-                st = self.state[p]
-                if len(st) == 0:
-                    st["step"] = 0
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-            steps = {int(self.state[p]["step"]) for p in plist}
+            steps = {int(self._init_state(p)["step"]) for p in plist}
             if len(steps) != 1:
                 raise RuntimeError("FusedAdamW: parameters of one group must share the step count")
             step = steps.pop() + 1
-            table, nblk = self._table(gi, plist)
-            b1, b2 = group["betas"]
-            _lib.check(lib.gdmcf_adamw_f32(table.data_ptr(), len(plist), nblk, group["lr"], b1, b2, group["eps"],
-                                           group["weight_decay"], step, float(self.grad_scale), _lib.stream_ptr()))
+            self._launch(gi, group, plist, step)
             for p in plist:
                 self.state[p]["step"] = step
         return loss

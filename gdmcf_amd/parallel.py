@@ -109,7 +109,7 @@ class DataParallelStep:
         param.grad = grad if param.grad is None else param.grad.add_(grad)
         g = param.grad
         if g.numel() * g.element_size() >= (1 << 20):
-            self._handles.append(_all_reduce(g, self.group, async_op=True))
+            self._handles.append((param, _all_reduce(g, self.group, async_op=True)))
         else:
             self._small.append(g)
 
@@ -130,14 +130,19 @@ class DataParallelStep:
         rank = dist.get_rank(self.group)
         hist[rank, :, 0] = ts.to(torch.float64)  # exact for any realistic number of diffusion steps
         hist[rank, :, 1] = lu
+        # the large all-reduces complete in launch order; every tensor but the last is updated the moment its
+        # own reduction is done, so that AdamW pass overlaps the reductions still on the wire
+        early = hasattr(self.optimizer, "step_subset")
+        for k, (param, h) in enumerate(self._handles):
+            if h is not None:
+                h.wait()
+            if early and k + 1 < len(self._handles):
+                self.optimizer.step_subset([param])
         _all_reduce(flat, self.group)
         off = 0
         for g in self._small:
             g.copy_(flat[off:off + g.numel()].view_as(g))
             off += g.numel()
-        for h in self._handles:
-            if h is not None:
-                h.wait()
         self._handles, self._small = [], []
         return hist[:, :, 0].reshape(-1).to(torch.int64).contiguous(), hist[:, :, 1].reshape(-1).contiguous()
 
