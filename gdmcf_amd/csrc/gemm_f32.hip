@@ -238,6 +238,171 @@ __device__ __forceinline__ void load_frag(const float* __restrict__ lds, int row
 
 __device__ __forceinline__ float gd_tanh(float x) { return tanhf(x); }
 
+// ---- epilogue (shared by the plain and the wave-specialised kernel) ---------------------------------------
+template <int BM, int TM, int TN, int WAVES_N, int EPI>
+__device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GdGemm& g, int m0, int n0, int wm0, int wn0,
+                                              int r, int q, int split, int tile_n, int wave, int tid, float* smem) {
+    // ---- epilogue.  acc[i][j][e] = C[m0+wm0+16i+4q+e][n0+wn0+16j+r] ----
+    // Branch-free on the load side: every read (bias, target, x_t, z, per-row coefficients) uses indices
+    // clamped into the matrix and is issued before any of them is consumed, so the ~40 loads per lane are
+    // in flight together; only the stores are predicated.
+    float rowacc[TM][4];
+    int ncl[TN];
+    bool nok[TN];
+    float biasv[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn0 + 16 * j + r;
+        nok[j] = n < g.N;
+        ncl[j] = min(n, g.N - 1);
+        biasv[j] = 0.f;
+        if ((EPI == GD_EPI_BIAS_ACT || EPI == GD_EPI_LOSS || EPI == GD_EPI_POST) && g.bias) biasv[j] = g.bias[ncl[j]];
+    }
+    if (EPI == GD_EPI_ADAMW) {
+        // Fused optimiser: the tile of the weight gradient never leaves the accumulators.  Per 16-row block:
+        // load p, exp_avg, exp_avg_sq (clamped indices, all in flight), update, predicated stores.
+        float* __restrict__ P = g.C;
+        float* __restrict__ Mo = const_cast<float*>(g.aux);
+        float* __restrict__ Vo = const_cast<float*>(g.aux2);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float pv[4][TN], mv[4][TN], vv[4][TN];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int mc = min(m0 + wm0 + 16 * i + 4 * q + e, g.M - 1);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int64_t o = (int64_t)mc * g.ldc + ncl[j];
+                    pv[e][j] = P[o];
+                    mv[e][j] = Mo[o];
+                    vv[e][j] = Vo[o];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = m0 + wm0 + 16 * i + 4 * q + e;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    gd_adam_elem(pv[e][j], acc[i][j][e], mv[e][j], vv[e][j], g.adam);
+                    if (m < g.M && nok[j]) {
+                        const int64_t o = (int64_t)m * g.ldc + ncl[j];
+                        P[o] = pv[e][j];
+                        Mo[o] = mv[e][j];
+                        Vo[o] = vv[e][j];
+                    }
+                }
+            }
+        }
+    } else if (EPI == GD_EPI_SLAB || EPI == GD_EPI_STORE || EPI == GD_EPI_BIAS_ACT) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = m0 + wm0 + 16 * i + 4 * q + e;
+                if (m < g.M) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        if (!nok[j]) continue;
+                        float v = acc[i][j][e];
+                        if (EPI == GD_EPI_SLAB) {
+                            g.C[(int64_t)split * g.slab_stride + (int64_t)m * g.ldc + ncl[j]] = v;
+                        } else if (EPI == GD_EPI_STORE) {
+                            float* p = &g.C[(int64_t)m * g.ldc + ncl[j]];
+                            *p = g.accumulate ? (*p + v) : v;
+                        } else {
+                            v += biasv[j];
+                            if (g.act == 1) v = gd_tanh(v);
+                            g.C[(int64_t)m * g.ldc + ncl[j]] = v;
+                        }
+                    }
+                }
+            }
+    } else {
+        // LOSS / POST, one 16-row block at a time: phase 1 -- all auxiliary loads of the block (4*TN per
+        // array, in flight together); phase 2 -- arithmetic + predicated stores.
+        const bool has_z = (EPI == GD_EPI_POST) && (g.aux2 != nullptr);
+        const bool has_r = (EPI == GD_EPI_POST) && (g.r2 != nullptr);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float av[4][TN];  // target (LOSS) or x_t (POST)
+            float zv[4][TN];  // z noise (POST with sampling noise)
+            float c1v[4], c2v[4], p1v[4], p2v[4], sgv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int mc = min(m0 + wm0 + 16 * i + 4 * q + e, g.M - 1);
+                c1v[e] = 1.f; c2v[e] = 0.f; p1v[e] = 0.f; p2v[e] = 0.f; sgv[e] = 0.f;
+                if (EPI == GD_EPI_LOSS) {
+                    if (g.r0) c1v[e] = g.r0[mc];  // alpha
+                } else {
+                    c1v[e] = g.r0[mc];
+                    c2v[e] = g.r1[mc];
+                    if (has_r) {
+                        p1v[e] = g.r2[mc];
+                        p2v[e] = g.r3[mc];
+                    }
+                    if (has_z) sgv[e] = g.r4[mc];
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    av[e][j] = g.aux[(int64_t)mc * g.ldaux + ncl[j]];
+                    zv[e][j] = has_z ? g.aux2[(int64_t)mc * g.ldaux2 + ncl[j]] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = m0 + wm0 + 16 * i + 4 * q + e;
+                const bool mok = m < g.M;
+                float racc = 0.f;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const bool ok = mok && nok[j];
+                    const float v = acc[i][j][e] + biasv[j];
+                    if (EPI == GD_EPI_LOSS) {
+                        const float d = c1v[e] * v - av[e][j];
+                        if (ok) {
+                            if (g.out2) g.out2[(int64_t)m * g.ldout2 + ncl[j]] = v;
+                            g.C[(int64_t)m * g.ldc + ncl[j]] = d;
+                            racc += d * d;
+                        }
+                    } else {
+                        const float xt = av[e][j];
+                        const float pred = has_r ? (p1v[e] * xt - p2v[e] * v) : v;
+                        float mean = c1v[e] * pred + c2v[e] * xt;
+                        if (has_z) mean += sgv[e] * zv[e][j];
+                        if (ok) {
+                            if (g.out2) g.out2[(int64_t)m * g.ldout2 + ncl[j]] = pred;
+                            g.C[(int64_t)m * g.ldc + ncl[j]] = mean;
+                        }
+                    }
+                }
+                rowacc[i][e] = racc;
+            }
+        }
+    }
+    if (EPI == GD_EPI_LOSS) {
+        // per-row sum of squares: 16 lanes (r) of each q-group hold one row's columns
+        float* rs = smem;  // [BM][WAVES_N]; the tile buffers are dead after the final barrier
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = rowacc[i][e];
+                v += __shfl_xor(v, 1);
+                v += __shfl_xor(v, 2);
+                v += __shfl_xor(v, 4);
+                v += __shfl_xor(v, 8);
+                if (r == 0) rs[(wm0 + 16 * i + 4 * q + e) * WAVES_N + (wave % WAVES_N)] = v;
+            }
+        __syncthreads();
+        if (tid < BM && m0 + tid < g.M) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES_N; ++w) s += rs[tid * WAVES_N + w];
+            g.rowpart[(int64_t)(m0 + tid) * g.ld_rowpart + tile_n] = s;
+        }
+    }
+}
+
 template <int LAYA, int LAYB, int BM, int BN, int BK, int WAVES_M, int WAVES_N, int EPI>
 __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GdGemm g) {
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
@@ -483,165 +648,127 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GdGemm g) {
 #undef __syncthreads
 #endif
 
-    // ---- epilogue.  acc[i][j][e] = C[m0+wm0+16i+4q+e][n0+wn0+16j+r] ----
-    // Branch-free on the load side: every read (bias, target, x_t, z, per-row coefficients) uses indices
-    // clamped into the matrix and is issued before any of them is consumed, so the ~40 loads per lane are
-    // in flight together; only the stores are predicated.
-    float rowacc[TM][4];
-    int ncl[TN];
-    bool nok[TN];
-    float biasv[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn0 + 16 * j + r;
-        nok[j] = n < g.N;
-        ncl[j] = min(n, g.N - 1);
-        biasv[j] = 0.f;
-        if ((EPI == GD_EPI_BIAS_ACT || EPI == GD_EPI_LOSS || EPI == GD_EPI_POST) && g.bias) biasv[j] = g.bias[ncl[j]];
-    }
-    if (EPI == GD_EPI_ADAMW) {
-        // Fused optimiser: the tile of the weight gradient never leaves the accumulators.  Per 16-row block:
-        // load p, exp_avg, exp_avg_sq (clamped indices, all in flight), update, predicated stores.
-        float* __restrict__ P = g.C;
-        float* __restrict__ Mo = const_cast<float*>(g.aux);
-        float* __restrict__ Vo = const_cast<float*>(g.aux2);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            float pv[4][TN], mv[4][TN], vv[4][TN];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int mc = min(m0 + wm0 + 16 * i + 4 * q + e, g.M - 1);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int64_t o = (int64_t)mc * g.ldc + ncl[j];
-                    pv[e][j] = P[o];
-                    mv[e][j] = Mo[o];
-                    vv[e][j] = Vo[o];
-                }
+    gemm_epilogue<BM, TM, TN, WAVES_N, EPI>(acc, g, m0, n0, wm0, wn0, r, q, split, tile_n, wave, tid, smem);
+}
+
+// ---- wave-specialised variant ------------------------------------------------------------------------------
+// 512 threads: waves 0-3 issue nothing but LDS fragment reads and MFMAs, waves 4-7 do all global loads and LDS
+// writes (same two-tile-ahead register staging, same LDS images, same edge handling).  Motivation (measured):
+// a global_load_dwordx4 costs the issuing wave ~60 cycles of issue time, 7 per tile = the ~415-cycle per-tile
+// overhead of the all-in-one kernel; in a loader wave that time is off the MFMA waves' critical path.
+// One s_barrier per tile for all eight waves: after it tile t+1 is complete in LDS and tile t's stage is free.
+template <int LAYA, int LAYB, int BM, int BN, int BK, int WAVES_M, int WAVES_N, int EPI>
+__global__ __launch_bounds__(2 * NTHREADS, 4) void gemm_f32_spec_kernel(const GdGemm g) {
+    constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    using GA = TileGeom<LAYA, BM, BK>;
+    using GB = TileGeom<LAYB, BN, BK>;
+    constexpr int STAGE_FLOATS = GA::FLOATS + GB::FLOATS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const bool loader = threadIdx.x >= NTHREADS;
+    const int tid = threadIdx.x & (NTHREADS - 1);
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave / WAVES_N) * WTM, wn0 = (wave % WAVES_N) * WTN;
+    const int r = lane & 15, q = lane >> 4;
+
+    const int nwg = gridDim.x, id = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = id & 7;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
+    const int tiles = g.tiles_m * g.tiles_n;
+    const int split = logical / tiles;
+    const int t = logical - split * tiles;
+    const int tile_m = g.m_fastest ? (t % g.tiles_m) : (t / g.tiles_n);
+    const int tile_n = g.m_fastest ? (t / g.tiles_m) : (t % g.tiles_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int kbeg = split * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
+    const int nt = (kend - kbeg + BK - 1) / BK;
+    float* const L0 = smem;
+    float* const L1 = smem + STAGE_FLOATS;
+    constexpr int LOADS_PER_TILE = GA::NL + GB::NL;
+#define GD_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+
+    if (loader) {
+        TileStage<LAYA, BM, BK> sa0, sa1;
+        TileStage<LAYB, BN, BK> sb0, sb1;
+        const bool a_full = (m0 + BM <= g.M), b_full = (n0 + BN <= g.N);
+        if (nt > 0) {
+            sa0.load(g.A, g.lda, m0, g.M, kbeg, kend, kbeg, a_full, tid);
+            sb0.load(g.B, g.ldb, n0, g.N, kbeg, kend, kbeg, b_full, tid);
+            if (nt > 1) {
+                sa1.load(g.A, g.lda, m0, g.M, kbeg + BK, kend, kbeg, a_full, tid);
+                sb1.load(g.B, g.ldb, n0, g.N, kbeg + BK, kend, kbeg, b_full, tid);
+                GD_WAIT_VM(LOADS_PER_TILE);
+            } else {
+                GD_WAIT_VM(0);
             }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int m = m0 + wm0 + 16 * i + 4 * q + e;
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    gd_adam_elem(pv[e][j], acc[i][j][e], mv[e][j], vv[e][j], g.adam);
-                    if (m < g.M && nok[j]) {
-                        const int64_t o = (int64_t)m * g.ldc + ncl[j];
-                        P[o] = pv[e][j];
-                        Mo[o] = mv[e][j];
-                        Vo[o] = vv[e][j];
-                    }
-                }
-            }
+            sa0.pin();
+            sb0.pin();
+            sa0.store(L0, tid);
+            sb0.store(L0 + GA::FLOATS, tid);
         }
-    } else if (EPI == GD_EPI_SLAB || EPI == GD_EPI_STORE || EPI == GD_EPI_BIAS_ACT) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int m = m0 + wm0 + 16 * i + 4 * q + e;
-                if (m < g.M) {
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        if (!nok[j]) continue;
-                        float v = acc[i][j][e];
-                        if (EPI == GD_EPI_SLAB) {
-                            g.C[(int64_t)split * g.slab_stride + (int64_t)m * g.ldc + ncl[j]] = v;
-                        } else if (EPI == GD_EPI_STORE) {
-                            float* p = &g.C[(int64_t)m * g.ldc + ncl[j]];
-                            *p = g.accumulate ? (*p + v) : v;
-                        } else {
-                            v += biasv[j];
-                            if (g.act == 1) v = gd_tanh(v);
-                            g.C[(int64_t)m * g.ldc + ncl[j]] = v;
-                        }
-                    }
-                }
-            }
-    } else {
-        // LOSS / POST, one 16-row block at a time: phase 1 -- all auxiliary loads of the block (4*TN per
-        // array, in flight together); phase 2 -- arithmetic + predicated stores.
-        const bool has_z = (EPI == GD_EPI_POST) && (g.aux2 != nullptr);
-        const bool has_r = (EPI == GD_EPI_POST) && (g.r2 != nullptr);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            float av[4][TN];  // target (LOSS) or x_t (POST)
-            float zv[4][TN];  // z noise (POST with sampling noise)
-            float c1v[4], c2v[4], p1v[4], p2v[4], sgv[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int mc = min(m0 + wm0 + 16 * i + 4 * q + e, g.M - 1);
-                c1v[e] = 1.f; c2v[e] = 0.f; p1v[e] = 0.f; p2v[e] = 0.f; sgv[e] = 0.f;
-                if (EPI == GD_EPI_LOSS) {
-                    if (g.r0) c1v[e] = g.r0[mc];  // alpha
-                } else {
-                    c1v[e] = g.r0[mc];
-                    c2v[e] = g.r1[mc];
-                    if (has_r) {
-                        p1v[e] = g.r2[mc];
-                        p2v[e] = g.r3[mc];
-                    }
-                    if (has_z) sgv[e] = g.r4[mc];
-                }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    av[e][j] = g.aux[(int64_t)mc * g.ldaux + ncl[j]];
-                    zv[e][j] = has_z ? g.aux2[(int64_t)mc * g.ldaux2 + ncl[j]] : 0.f;
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int m = m0 + wm0 + 16 * i + 4 * q + e;
-                const bool mok = m < g.M;
-                float racc = 0.f;
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const bool ok = mok && nok[j];
-                    const float v = acc[i][j][e] + biasv[j];
-                    if (EPI == GD_EPI_LOSS) {
-                        const float d = c1v[e] * v - av[e][j];
-                        if (ok) {
-                            if (g.out2) g.out2[(int64_t)m * g.ldout2 + ncl[j]] = v;
-                            g.C[(int64_t)m * g.ldc + ncl[j]] = d;
-                            racc += d * d;
-                        }
-                    } else {
-                        const float xt = av[e][j];
-                        const float pred = has_r ? (p1v[e] * xt - p2v[e] * v) : v;
-                        float mean = c1v[e] * pred + c2v[e] * xt;
-                        if (has_z) mean += sgv[e] * zv[e][j];
-                        if (ok) {
-                            if (g.out2) g.out2[(int64_t)m * g.ldout2 + ncl[j]] = pred;
-                            g.C[(int64_t)m * g.ldc + ncl[j]] = mean;
-                        }
-                    }
-                }
-                rowacc[i][e] = racc;
-            }
-        }
-    }
-    if (EPI == GD_EPI_LOSS) {
-        // per-row sum of squares: 16 lanes (r) of each q-group hold one row's columns
-        float* rs = smem;  // [BM][WAVES_N]; the tile buffers are dead after the final barrier
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float v = rowacc[i][e];
-                v += __shfl_xor(v, 1);
-                v += __shfl_xor(v, 2);
-                v += __shfl_xor(v, 4);
-                v += __shfl_xor(v, 8);
-                if (r == 0) rs[(wm0 + 16 * i + 4 * q + e) * WAVES_N + (wave % WAVES_N)] = v;
-            }
         __syncthreads();
-        if (tid < BM && m0 + tid < g.M) {
-            float s = 0.f;
-#pragma unroll
-            for (int w = 0; w < WAVES_N; ++w) s += rs[tid * WAVES_N + w];
-            g.rowpart[(int64_t)(m0 + tid) * g.ld_rowpart + tile_n] = s;
+        for (int it = 0; it < nt; it += 2) {
+            const bool ld2 = (it + 2 < nt);
+            if (ld2) {
+                sa0.load(g.A, g.lda, m0, g.M, kbeg + (it + 2) * BK, kend, kbeg, a_full, tid);
+                sb0.load(g.B, g.ldb, n0, g.N, kbeg + (it + 2) * BK, kend, kbeg, b_full, tid);
+            }
+            if (it + 1 < nt) {
+                if (ld2) GD_WAIT_VM(LOADS_PER_TILE); else GD_WAIT_VM(0);
+                sa1.pin();
+                sb1.pin();
+                sa1.store(L1, tid);
+                sb1.store(L1 + GA::FLOATS, tid);
+            }
+            __syncthreads();
+            if (it + 1 < nt) {
+                const bool ld3 = (it + 3 < nt);
+                if (ld3) {
+                    sa1.load(g.A, g.lda, m0, g.M, kbeg + (it + 3) * BK, kend, kbeg, a_full, tid);
+                    sb1.load(g.B, g.ldb, n0, g.N, kbeg + (it + 3) * BK, kend, kbeg, b_full, tid);
+                }
+                if (ld2) {
+                    if (ld3) GD_WAIT_VM(LOADS_PER_TILE); else GD_WAIT_VM(0);
+                    sa0.pin();
+                    sb0.pin();
+                    sa0.store(L0, tid);
+                    sb0.store(L0 + GA::FLOATS, tid);
+                }
+                __syncthreads();
+            }
         }
+        GD_WAIT_VM(0);
+        return;  // loader waves take no part in the epilogue (a finished wave leaves the barrier count)
     }
+#undef GD_WAIT_VM
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    for (int it = 0; it < nt; ++it) {
+        const float* As = (it & 1) ? L1 : L0;
+        const float* Bs = As + GA::FLOATS;
+#pragma unroll
+        for (int c = 0; c < BK / 16; ++c) {
+            float fa[TM][4], fb[TN][4];
+            load_frag<LAYA, BM, BK, TM>(As, wm0, c, r, q, fa);
+            load_frag<LAYB, BN, BK, TN>(Bs, wn0, c, r, q, fb);
+#pragma unroll
+            for (int sg = 0; sg < 4; ++sg)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][sg], fb[j][sg], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    gemm_epilogue<BM, TM, TN, WAVES_N, EPI>(acc, g, m0, n0, wm0, wn0, r, q, split, tile_n, wave, tid, smem);
 }
 
 template <int LAYA, int LAYB, int BM, int BN, int BK, int WM, int WN, int EPI>
@@ -650,7 +777,16 @@ int launch_one(GdGemm& g, hipStream_t s) {
     using GB = TileGeom<LAYB, BN, BK>;
     static const size_t lds_pad = getenv("GD_LDS_PAD") ? (size_t)atoi(getenv("GD_LDS_PAD")) : 0;  // occupancy experiments
     const size_t lds = (size_t)2 * (GA::FLOATS + GB::FLOATS) * sizeof(float) + lds_pad;
-    auto kern = gemm_f32_kernel<LAYA, LAYB, BM, BN, BK, WM, WN, EPI>;
+    // Row-contiguous x row-contiguous products (the weight gradients) run the wave-specialised kernel: measured
+    // +6-7 % at 128x128 tiles on the Yelp shape, no gain or a loss for the K-contiguous products
+    // (profiles/r01_spec_ab.txt).  GDMCF_GEMM_SPEC=0 switches it off for A/B runs.
+    static const bool spec_on = !(getenv("GDMCF_GEMM_SPEC") && atoi(getenv("GDMCF_GEMM_SPEC")) == 0);
+    constexpr bool SPEC_OK = (LAYA == 1 && LAYB == 1 && BM == 128 && BN == 128);
+    const bool spec = SPEC_OK && spec_on;
+    void (*kern)(const GdGemm) = gemm_f32_kernel<LAYA, LAYB, BM, BN, BK, WM, WN, EPI>;
+    if constexpr (SPEC_OK) {
+        if (spec) kern = gemm_f32_spec_kernel<LAYA, LAYB, BM, BN, BK, WM, WN, EPI>;
+    }
     static bool attr_set = false;
     if (!attr_set && lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -672,7 +808,7 @@ int launch_one(GdGemm& g, hipStream_t s) {
     }
     {
         GdProfScope prof(g.prof_tag, 2.0 * g.M * g.N * g.K, s);
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTHREADS), lds, s, g);
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(spec ? 2 * NTHREADS : NTHREADS), lds, s, g);
     }
     return gd_launch_status("gemm_f32");
 }
