@@ -29,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_* = 64 FLOP/clk/SIMD
+PEAK_BF16_MATRIX_TFLOPS = 2516.6  # dense bf16 MFMA = 16 x the f32 matrix rate (same guide)
 PEAK_HBM_GBPS = 8000.0
 TAGS = {1: "linear_fwd_gemm", 2: "loss_fwd_gemm", 3: "posterior_gemm", 4: "bwd_input_gemm", 5: "bwd_weight_gemm",
         6: "adamw", 7: "prep_input", 8: "spmm_csr", 9: "topk"}
@@ -42,11 +43,11 @@ TRAFFIC_KERNEL = {"bwd_weight_gemm": "gemm_f32_kernel<1, 1, 128, 128, 16, 2, 2, 
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_final_hbm_traffic.json")
 
 
-def measured_traffic(kernel_tag, workload):
+def measured_traffic(kernel_tag, workload, gemm_dtype="f32"):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE and
     WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950 note; profiles/summarize.py).  PMC counters
     cannot be collected from inside the process, so this is a lookup; None when no profile matches."""
-    if workload != "yelp" or kernel_tag not in TRAFFIC_KERNEL or not os.path.exists(TRAFFIC_FILE):
+    if workload != "yelp" or gemm_dtype != "f32" or kernel_tag not in TRAFFIC_KERNEL or not os.path.exists(TRAFFIC_FILE):
         return None
     for row in json.load(open(TRAFFIC_FILE)):
         if row["kernel"] == TRAFFIC_KERNEL[kernel_tag]:
@@ -63,6 +64,8 @@ def parse():
     ap.add_argument("--T", type=int, default=5, help="diffusion steps")
     ap.add_argument("--batch", type=int, default=400)
     ap.add_argument("--hidden", type=int, default=1000)
+    ap.add_argument("--gemm-dtype", default="f32", choices=["f32", "bf16"],
+                    help="input precision of the denoiser GEMMs (bf16 = BASELINE configs[2]; f32 is the parity path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
@@ -145,7 +148,7 @@ def main():
     x_dev = torch.from_numpy(x_host[:1]).to(dev)
 
     torch.manual_seed(0)
-    model = gdmcf_amd.DNN([I, hid], [hid, I], 10, time_type="cat", norm=False).to(dev)
+    model = gdmcf_amd.DNN([I, hid], [hid, I], 10, time_type="cat", norm=False, gemm_dtype=args.gemm_dtype).to(dev)
     diffusion = gdmcf_amd.GaussianDiffusion(gdmcf_amd.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, T, dev)
     opt = gdmcf_amd.FusedAdamW(model.parameters(), lr=1e-5, weight_decay=0.0)
     if args.fuse_optimizer and world == 1:
@@ -184,22 +187,35 @@ def main():
     roofline, klist = None, []
     for tag, d in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"]):
         sec = d["ms"] * 1e-3
-        if tag in GEMM_TAGS:
+        extra = {}
+        if tag in GEMM_TAGS and args.gemm_dtype == "bf16":
+            # bf16 products of f32 tensors at batch 400 are bound by bringing the f32 operands in, not by the
+            # matrix pipe: report the HBM fraction on the compulsory bytes (each operand and the result once),
+            # and the bf16-MFMA fraction beside it.
+            E_ = 10
+            per_launch = {1: B * (I + E_) + hid * (I + E_) + B * hid, 2: B * hid + I * hid + 2 * B * I,
+                          3: B * hid + I * hid + 2 * B * I, 4: B * I + I * hid + B * hid,
+                          5: (2 * B * I + 2 * B * hid + 2 * I * hid + E_ * (B + hid)) / 2.0}[tag] * 4.0
+            ach, peak, unit, bound = per_launch * d["n"] / sec / 1e9, PEAK_HBM_GBPS, "GB/s", "hbm"
+            extra = dict(mfma_tflops=round(d["work"] / sec / 1e12, 1),
+                         mfma_frac=round(d["work"] / sec / 1e12 / PEAK_BF16_MATRIX_TFLOPS, 4))
+        elif tag in GEMM_TAGS:
             ach, peak, unit, bound = d["work"] / sec / 1e12, PEAK_F32_MATRIX_TFLOPS, "TFLOP/s", "mfma"
         else:
             ach, peak, unit, bound = d["work"] / sec / 1e9, PEAK_HBM_GBPS, "GB/s", "hbm"
         e = dict(kernel=TAGS.get(tag, str(tag)), bound=bound, achieved=round(ach, 2), peak=peak, unit=unit,
                  frac=round(ach / peak, 4), avg_ms=round(d["ms"] / d["n"], 4), launches=d["n"],
-                 share_of_step=round(d["ms"] / (el * 1e3), 4))
+                 share_of_step=round(d["ms"] / (el * 1e3), 4), **extra)
         klist.append(e)
     if klist:
         k0 = klist[0]
         roofline = dict(bound=k0["bound"], achieved=k0["achieved"], peak=k0["peak"], unit=k0["unit"], frac=k0["frac"],
-                        traffic=measured_traffic(k0["kernel"], args.workload), kernel=k0["kernel"], avg_ms=k0["avg_ms"],
+                        traffic=measured_traffic(k0["kernel"], args.workload, args.gemm_dtype), kernel=k0["kernel"], avg_ms=k0["avg_ms"],
                         launches_per_step=k0["launches"] // max(args.steps, 1),
                         traffic_unit="HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE passes of this "
                                      "command (profiles/r01_final_hbm_traffic.json)",
-                        algorithmic_unit="2*M*N*K FLOP per launch")
+                        algorithmic_unit=("2*M*N*K FLOP per launch" if k0["bound"] == "mfma" else
+                                          "compulsory bytes per launch (operands and results once; AdamW 28 B/param)"))
 
     spmm = None
     if args.spmm and rank == 0:
@@ -218,10 +234,13 @@ def main():
         out = {
             "metric": "training users/sec", "value": round(users / el, 1), "unit": "users/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.gemm_dtype, "data": "synthetic",
             "config": {"workload": f"{args.workload}-shape synthetic rows, batch={B}/GPU, dims=[{hid}], T={T}, "
                                    f"noise_scale=0.01, linear-var, mean_type=x0, reweight, AdamW lr=1e-5"
-                                   + (" (BASELINE configs[1])" if args.workload == "yelp" and T == 5 and hid == 1000 else ""),
+                                   + (" (BASELINE configs[1])" if args.workload == "yelp" and T == 5 and hid == 1000
+                                      and args.gemm_dtype == "f32" else "")
+                                   + (" (BASELINE configs[2]: bf16 denoiser GEMM inputs, f32 accumulate/state)"
+                                      if args.workload == "amazon-book" and args.gemm_dtype == "bf16" else ""),
                        "n_items": I, "global_batch": world * B, "parallelism": f"dp{world}"},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": klist, "final_loss": final_loss,
             "optimizer": "FusedAdamW" + (" fused into the dW GEMM epilogues" if (args.fuse_optimizer and world == 1) else " (separate pass)"),

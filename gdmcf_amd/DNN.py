@@ -51,8 +51,11 @@ class _DNNForward(torch.autograd.Function):
 class DNN(nn.Module):
     """A deep neural network for the reverse diffusion process (drop-in for the reference DNN)."""
 
-    def __init__(self, in_dims, out_dims, emb_size, time_type="cat", norm=False, dropout=0.5):
+    def __init__(self, in_dims, out_dims, emb_size, time_type="cat", norm=False, dropout=0.5, gemm_dtype="f32"):
         super().__init__()
+        if gemm_dtype not in ("f32", "bf16"):
+            raise ValueError("Unimplemented GEMM input precision %s" % gemm_dtype)
+        self.gemm_dtype = gemm_dtype
         self.in_dims = list(in_dims)
         self.out_dims = list(out_dims)
         assert out_dims[0] == in_dims[-1], "In and out dimensions must equal to each other."

@@ -31,6 +31,7 @@ _SIGNATURES = {
     "gdmcf_dnn_prep_input_f32": (c_int, [P, c_int64, P, P, P, c_int, P, c_int64, c_int, P, c_int64, c_float, c_uint64,
                                          c_uint64, c_int, P, P, c_int, c_int, c_int, P, c_int64, P, c_int64, P, P, P]),
     "gdmcf_dnn_emb_cols_f32": (c_int, [P, P, P, c_int, c_int, c_int, P, c_int64, P, P]),
+    "gdmcf_gemm_precision": (c_int, [c_int]),
     "gdmcf_linear_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gdmcf_linear_fwd_f32": (c_int, [P, c_int64, P, c_int64, P, c_int, c_int, c_int, c_int, P, c_int64, P, c_size_t, P]),
     "gdmcf_loss_tiles": (c_int, [c_int]),

@@ -111,11 +111,13 @@ struct GdGemm {
     int accumulate;
     int prof_tag;
     GdAdamHyper adam;  // GD_EPI_ADAMW: C = parameter, aux = exp_avg, aux2 = exp_avg_sq (all [M,N], ldc)
+    int bf16;  // 1: operands rounded to bfloat16 on the way to LDS, bf16 MFMA, f32 accumulate (gemm_bf16.hip)
     int stagger;  // startup delay (x512 clocks) for workgroups in odd wave slots; de-phases co-resident workgroups
 };
 
 // shape classes: 0 = "batch-M" (BM=80, BN=128), 1 = square 128x128, 2 = small 64x64
 int gd_gemm_launch(int layA, int layB, int epi, int shape_class, GdGemm& g, hipStream_t s);
+int gd_gemm_bf16_launch(int layA, int layB, int epi, int shape_class, GdGemm& g, hipStream_t s);  // g.bf16 != 0
 int gd_gemm_tile_m(int shape_class);
 int gd_gemm_tile_n(int shape_class);
 int gd_gemm_bk(int layA, int layB);

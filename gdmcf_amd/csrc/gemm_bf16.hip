@@ -1,0 +1,323 @@
+// bf16-input GEMM core on v_mfma_f32_16x16x32_bf16 (BASELINE config "bf16 denoiser GEMM on MFMA").
+//
+// Same products, operand descriptions, tile classes, split-K scheme and epilogues as gemm_f32.hip; only the
+// arithmetic of the inner product changes: both operands are rounded to bfloat16 (round-to-nearest-even,
+// v_cvt_pk_bf16_f32) on their way from global memory to LDS and multiplied on the bf16 matrix pipe with f32
+// accumulation.  Sources stay float32 in HBM (master weights, activations, gradients): nothing else in the
+// library changes layout, and the optimiser keeps working on f32 state.
+//
+// LDS image (both operands, whatever their global layout): rows of 64 bf16 = 128 bytes, eight 16-byte slots,
+// slot s of row r stored at s ^ ((r >> 1) & 7) -- byte-for-byte the access pattern of gemm_f32.hip's
+// K-contiguous image, so its bank analysis (MI355X_MICROARCH.md, LDS) carries over: the ds_read_b128 of MFMA
+// block t, k-chunk c by lane (r = lane & 15, q = lane >> 4) takes slot 4c+q of row 16t+r = that lane's eight
+// consecutive k values, exactly one 16x16x32 operand.
+//  * K-contiguous source: 16 lanes x 16 B cover one row's 64 floats; each lane converts 4 values and writes
+//    8 bytes (ds_write_b64, 16 contiguous lanes = one full 128-byte row, conflict-free).
+//  * row-contiguous source ([k][rows]): a lane loads a 8(k) x 4(rows) patch with eight 16-byte loads (lanes
+//    along the rows: coalesced), transposes it in registers and writes four 16-byte slots; eight consecutive
+//    lanes hold the eight k-groups of the same rows, i.e. write one full 128-byte row per ds_write_b128 group.
+// With bf16 MFMA time per tile 8x smaller than f32, the kernel is bound by bringing the f32 sources in
+// (HBM / L2), so the structure is the plain one: register-staged double buffering, one barrier per k-tile,
+// three workgroups per CU to cover latency.
+#include <stdlib.h>
+
+#include "common.h"
+#include "gemm_epilogue.h"
+
+namespace {
+
+constexpr int NTHREADS = 256;
+constexpr int BK = 64;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef f32x4 f32x4_u __attribute__((aligned(4)));
+
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    bf16x2 v;
+    v[0] = (__bf16)lo;  // v_cvt_pk_bf16_f32: round to nearest even
+    v[1] = (__bf16)hi;
+    return __builtin_bit_cast(unsigned, v);
+}
+
+// byte offset of 16-byte slot `slot` of row r
+__device__ __forceinline__ int img_off(int r, int slot) { return r * 128 + ((slot ^ ((r >> 1) & 7)) << 4); }
+
+// ---- staging: global f32 -> registers -> bf16 LDS image ---------------------------------------------------
+template <int LAY, int R>
+struct Stage;
+
+// Loads come in two flavours chosen per tile by a workgroup-uniform test, so that the common one is a run of
+// back-to-back 16-byte loads without a branch, predicate or select between them (a select right after a load
+// makes hipcc wait for that load before issuing the next):
+//   fast()  true  -> load_fast: whole tile inside the matrix in the vectorised direction
+//   fast()  false -> load_safe: element-wise predicated loads (edge tiles only)
+
+// K-contiguous source [rows][K]
+template <int R>
+struct Stage<GD_LAY_KC, R> {
+    static constexpr int UNITS = R * 16;  // (row, 16-byte segment)
+    static constexpr int NL = (UNITS + NTHREADS - 1) / NTHREADS;
+    f32x4 reg[NL];
+
+    __device__ static __forceinline__ bool fast(int row0, int rows_total, int k0, int kend) { return k0 + BK <= kend; }
+    // rows are clamped into the matrix (results of out-of-range rows are never stored)
+    __device__ __forceinline__ void load_fast(const float* __restrict__ src, int64_t ld, int row0, int rows_total,
+                                              int k0, int kend, int tid) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int u = tid + i * NTHREADS;
+            const int row = min(row0 + (u >> 4), rows_total - 1);
+            reg[i] = *reinterpret_cast<const f32x4_u*>(src + (int64_t)row * ld + k0 + ((u & 15) << 2));
+        }
+    }
+    // k-tail tile: nothing is read beyond kend and the tail contributes zeros
+    __device__ __forceinline__ void load_safe(const float* __restrict__ src, int64_t ld, int row0, int rows_total,
+                                              int k0, int kend, int tid) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int u = tid + i * NTHREADS;
+            const int row = min(row0 + (u >> 4), rows_total - 1);
+            const int k = k0 + ((u & 15) << 2);
+            const float* p = src + (int64_t)row * ld + k;
+            f32x4 v;
+            v.x = (k + 0 < kend) ? p[0] : 0.f;
+            v.y = (k + 1 < kend) ? p[1] : 0.f;
+            v.z = (k + 2 < kend) ? p[2] : 0.f;
+            v.w = (k + 3 < kend) ? p[3] : 0.f;
+            reg[i] = v;
+        }
+    }
+    __device__ __forceinline__ void store(char* img, int k0, int kend, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int u = tid + i * NTHREADS;
+            if (UNITS % NTHREADS != 0 && u >= UNITS) continue;
+            const int row = u >> 4, seg = u & 15;
+            u32x2 w;
+            w.x = pack_bf16(reg[i].x, reg[i].y);
+            w.y = pack_bf16(reg[i].z, reg[i].w);
+            *reinterpret_cast<u32x2*>(img + img_off(row, seg >> 1) + ((seg & 1) << 3)) = w;
+        }
+    }
+};
+
+// row-contiguous source [K][rows]
+template <int R>
+struct Stage<GD_LAY_MC, R> {
+    static constexpr int UNITS = (R / 4) * 8;  // (4-row group, 8-deep k group)
+    static constexpr int NL = (UNITS + NTHREADS - 1) / NTHREADS;
+    f32x4 reg[NL][8];
+
+    __device__ static __forceinline__ bool fast(int row0, int rows_total, int k0, int kend) { return row0 + R <= rows_total; }
+    // k rows beyond kend are read from the last valid row here and zeroed at store time
+    __device__ __forceinline__ void load_fast(const float* __restrict__ src, int64_t ld, int row0, int rows_total,
+                                              int k0, int kend, int tid) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int u = tid + i * NTHREADS;
+            const int kg = u & 7, rg = min(u >> 3, R / 4 - 1);
+            const float* p = src + row0 + (rg << 2);
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
+                reg[i][kk] = *reinterpret_cast<const f32x4_u*>(p + (int64_t)min(k0 + (kg << 3) + kk, kend - 1) * ld);
+        }
+    }
+    // tile crossing the last row of the matrix: a 16-byte load could run past the row, go element-wise
+    __device__ __forceinline__ void load_safe(const float* __restrict__ src, int64_t ld, int row0, int rows_total,
+                                              int k0, int kend, int tid) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int u = tid + i * NTHREADS;
+            const int kg = u & 7, rg = min(u >> 3, R / 4 - 1);
+            const int row = row0 + (rg << 2);
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const float* p = src + (int64_t)min(k0 + (kg << 3) + kk, kend - 1) * ld + row;
+                f32x4 v;
+                v.x = (row + 0 < rows_total) ? p[0] : 0.f;
+                v.y = (row + 1 < rows_total) ? p[1] : 0.f;
+                v.z = (row + 2 < rows_total) ? p[2] : 0.f;
+                v.w = (row + 3 < rows_total) ? p[3] : 0.f;
+                reg[i][kk] = v;
+            }
+        }
+    }
+    __device__ __forceinline__ void store(char* img, int k0, int kend, int tid) const {
+        const bool ktail = k0 + BK > kend;  // workgroup-uniform
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int u = tid + i * NTHREADS;
+            if (UNITS % NTHREADS != 0 && u >= UNITS) continue;
+            const int kg = u & 7, rg = u >> 3;
+            const int nvalid = ktail ? kend - (k0 + (kg << 3)) : 8;  // k values of this group inside [k0, kend)
+#pragma unroll
+            for (int mm = 0; mm < 4; ++mm) {
+                float e[8];
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) e[kk] = reg[i][kk][mm];
+                if (ktail) {
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) e[kk] = (kk < nvalid) ? e[kk] : 0.f;
+                }
+                u32x4 w;
+                w.x = pack_bf16(e[0], e[1]);
+                w.y = pack_bf16(e[2], e[3]);
+                w.z = pack_bf16(e[4], e[5]);
+                w.w = pack_bf16(e[6], e[7]);
+                *reinterpret_cast<u32x4*>(img + img_off((rg << 2) + mm, kg)) = w;
+            }
+        }
+    }
+};
+
+template <int LAY, int R>
+__device__ __forceinline__ void stage_load(Stage<LAY, R>& st, const float* __restrict__ src, int64_t ld, int row0,
+                                           int rows_total, int k0, int kend, int tid) {
+    if (Stage<LAY, R>::fast(row0, rows_total, k0, kend))
+        st.load_fast(src, ld, row0, rows_total, k0, kend, tid);
+    else
+        st.load_safe(src, ld, row0, rows_total, k0, kend, tid);
+}
+
+template <int LAYA, int LAYB, int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+__global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const GdGemm g) {
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+    constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+    constexpr int TM = WTM / 16, TN = WTN / 16;
+    static_assert(TM * 16 * WAVES_M == BM && TN * 16 * WAVES_N == BN, "tile must split into 16x16 blocks");
+    constexpr int A_BYTES = BM * 128, STAGE_BYTES = (BM + BN) * 128;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* const lds = reinterpret_cast<char*>(smem);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave / WAVES_N) * WTM, wn0 = (wave % WAVES_N) * WTN;
+    const int r = lane & 15, q = lane >> 4;
+
+    // XCD-aware bijective remap (as gemm_f32.hip): consecutive logical tiles share an XCD's L2
+    const int nwg = gridDim.x, id = blockIdx.x;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = id & 7;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
+    const int tiles = g.tiles_m * g.tiles_n;
+    const int split = logical / tiles;
+    const int t = logical - split * tiles;
+    const int tile_m = g.m_fastest ? (t % g.tiles_m) : (t / g.tiles_n);
+    const int tile_n = g.m_fastest ? (t / g.tiles_m) : (t % g.tiles_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int kbeg = split * g.kchunk;
+    const int kend = min(g.K, kbeg + g.kchunk);
+    const int nt = (kend - kbeg + BK - 1) / BK;
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    Stage<LAYA, BM> sa;
+    Stage<LAYB, BN> sb;
+    if (nt > 0) {
+        stage_load(sa, g.A, g.lda, m0, g.M, kbeg, kend, tid);
+        stage_load(sb, g.B, g.ldb, n0, g.N, kbeg, kend, tid);
+        sa.store(lds, kbeg, kend, tid);
+        sb.store(lds + A_BYTES, kbeg, kend, tid);
+    }
+    __syncthreads();
+    for (int it = 0; it < nt; ++it) {
+        const char* cur = lds + (it & 1) * STAGE_BYTES;
+        char* nxt = lds + ((it + 1) & 1) * STAGE_BYTES;
+        const bool more = it + 1 < nt;
+        if (more) {
+            stage_load(sa, g.A, g.lda, m0, g.M, kbeg + (it + 1) * BK, kend, tid);
+            stage_load(sb, g.B, g.ldb, n0, g.N, kbeg + (it + 1) * BK, kend, tid);
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            bf16x8 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                fa[i] = *reinterpret_cast<const bf16x8*>(cur + img_off(wm0 + 16 * i + r, 4 * c + q));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                fb[j] = *reinterpret_cast<const bf16x8*>(cur + A_BYTES + img_off(wn0 + 16 * j + r, 4 * c + q));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            sa.store(nxt, kbeg + (it + 1) * BK, kend, tid);
+            sb.store(nxt + A_BYTES, kbeg + (it + 1) * BK, kend, tid);
+        }
+        __syncthreads();
+    }
+    gemm_epilogue<BM, TM, TN, WAVES_N, EPI>(acc, g, m0, n0, wm0, wn0, r, q, split, tile_n, wave, tid, smem);
+}
+
+template <int LAYA, int LAYB, int BM, int BN, int WM, int WN, int EPI>
+int launch_one(GdGemm& g, hipStream_t s) {
+    constexpr size_t lds = 2 * (size_t)(BM + BN) * 128;
+    auto kern = gemm_bf16_kernel<LAYA, LAYB, BM, BN, WM, WN, EPI>;
+    static bool attr_set = false;
+    if (!attr_set && lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            gdmcf_set_error("hipFuncSetAttribute(LDS=%zu): %s", lds, hipGetErrorString(e));
+            return GDMCF_E_HIP;
+        }
+        attr_set = true;
+    }
+    g.tiles_m = gd_cdiv(g.M, BM);
+    g.tiles_n = gd_cdiv(g.N, BN);
+    if (g.splits < 1) g.splits = 1;
+    if (g.kchunk <= 0) g.kchunk = gd_cdiv(gd_cdiv(g.K, g.splits), BK) * BK;
+    const long grid = (long)g.tiles_m * g.tiles_n * g.splits;
+    if (grid <= 0 || grid > 0x7fffffffL) {
+        gdmcf_set_error("gemm grid out of range: %ld", grid);
+        return GDMCF_E_SHAPE;
+    }
+    {
+        GdProfScope prof(g.prof_tag, 2.0 * g.M * g.N * g.K, s);
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTHREADS), lds, s, g);
+    }
+    return gd_launch_status("gemm_bf16");
+}
+
+template <int LAYA, int LAYB, int EPI>
+int launch_class(int cls, GdGemm& g, hipStream_t s) {
+    switch (cls) {
+        case 0: return launch_one<LAYA, LAYB, 80, 128, 1, 4, EPI>(g, s);
+        case 1: return launch_one<LAYA, LAYB, 128, 128, 2, 2, EPI>(g, s);
+        case 2: return launch_one<LAYA, LAYB, 64, 64, 2, 2, EPI>(g, s);
+    }
+    gdmcf_set_error("bad gemm shape class %d", cls);
+    return GDMCF_E_ARG;
+}
+
+}  // namespace
+
+int gd_gemm_bf16_launch(int layA, int layB, int epi, int cls, GdGemm& g, hipStream_t s) {
+    if (g.kchunk > 0 && g.kchunk % BK != 0) {
+        gdmcf_set_error("gemm_bf16: kchunk %d is not a multiple of %d", g.kchunk, BK);
+        return GDMCF_E_ARG;
+    }
+    if (layA == GD_LAY_KC && layB == GD_LAY_KC) {
+        switch (epi) {
+            case GD_EPI_SLAB: return launch_class<GD_LAY_KC, GD_LAY_KC, GD_EPI_SLAB>(cls, g, s);
+            case GD_EPI_BIAS_ACT: return launch_class<GD_LAY_KC, GD_LAY_KC, GD_EPI_BIAS_ACT>(cls, g, s);
+            case GD_EPI_LOSS: return launch_class<GD_LAY_KC, GD_LAY_KC, GD_EPI_LOSS>(cls, g, s);
+            case GD_EPI_POST: return launch_class<GD_LAY_KC, GD_LAY_KC, GD_EPI_POST>(cls, g, s);
+        }
+    } else if (layA == GD_LAY_KC && layB == GD_LAY_MC) {
+        if (epi == GD_EPI_SLAB) return launch_class<GD_LAY_KC, GD_LAY_MC, GD_EPI_SLAB>(cls, g, s);
+    } else if (layA == GD_LAY_MC && layB == GD_LAY_MC) {
+        if (epi == GD_EPI_STORE) return launch_class<GD_LAY_MC, GD_LAY_MC, GD_EPI_STORE>(cls, g, s);
+        if (epi == GD_EPI_ADAMW) return launch_class<GD_LAY_MC, GD_LAY_MC, GD_EPI_ADAMW>(cls, g, s);
+    }
+    gdmcf_set_error("unsupported bf16 gemm variant (layA=%d layB=%d epi=%d)", layA, layB, epi);
+    return GDMCF_E_UNSUPPORTED;
+}

@@ -1,0 +1,176 @@
+// Epilogue shared by every MFMA GEMM kernel of the library (f32 kernels in gemm_f32.hip, bf16-input kernel in
+// gemm_bf16.hip).  All of them produce 16x16 accumulator blocks in the same register layout:
+//   acc[i][j][e] = C[m0 + wm0 + 16 i + 4 q + e][n0 + wn0 + 16 j + r],   r = lane & 15, q = lane >> 4.
+#pragma once
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float gd_tanh(float x) { return tanhf(x); }
+
+// ---- epilogue (shared by the plain and the wave-specialised kernel) ---------------------------------------
+template <int BM, int TM, int TN, int WAVES_N, int EPI>
+__device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GdGemm& g, int m0, int n0, int wm0, int wn0,
+                                              int r, int q, int split, int tile_n, int wave, int tid, float* smem) {
+    // ---- epilogue.  acc[i][j][e] = C[m0+wm0+16i+4q+e][n0+wn0+16j+r] ----
+    // Branch-free on the load side: every read (bias, target, x_t, z, per-row coefficients) uses indices
+    // clamped into the matrix and is issued before any of them is consumed, so the ~40 loads per lane are
+    // in flight together; only the stores are predicated.
+    float rowacc[TM][4];
+    int ncl[TN];
+    bool nok[TN];
+    float biasv[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn0 + 16 * j + r;
+        nok[j] = n < g.N;
+        ncl[j] = min(n, g.N - 1);
+        biasv[j] = 0.f;
+        if ((EPI == GD_EPI_BIAS_ACT || EPI == GD_EPI_LOSS || EPI == GD_EPI_POST) && g.bias) biasv[j] = g.bias[ncl[j]];
+    }
+    if (EPI == GD_EPI_ADAMW) {
+        // Fused optimiser: the tile of the weight gradient never leaves the accumulators.  Per 16-row block:
+        // load p, exp_avg, exp_avg_sq (clamped indices, all in flight), update, predicated stores.
+        float* __restrict__ P = g.C;
+        float* __restrict__ Mo = const_cast<float*>(g.aux);
+        float* __restrict__ Vo = const_cast<float*>(g.aux2);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float pv[4][TN], mv[4][TN], vv[4][TN];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int mc = min(m0 + wm0 + 16 * i + 4 * q + e, g.M - 1);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int64_t o = (int64_t)mc * g.ldc + ncl[j];
+                    pv[e][j] = P[o];
+                    mv[e][j] = Mo[o];
+                    vv[e][j] = Vo[o];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = m0 + wm0 + 16 * i + 4 * q + e;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    gd_adam_elem(pv[e][j], acc[i][j][e], mv[e][j], vv[e][j], g.adam);
+                    if (m < g.M && nok[j]) {
+                        const int64_t o = (int64_t)m * g.ldc + ncl[j];
+                        P[o] = pv[e][j];
+                        Mo[o] = mv[e][j];
+                        Vo[o] = vv[e][j];
+                    }
+                }
+            }
+        }
+    } else if (EPI == GD_EPI_SLAB || EPI == GD_EPI_STORE || EPI == GD_EPI_BIAS_ACT) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = m0 + wm0 + 16 * i + 4 * q + e;
+                if (m < g.M) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        if (!nok[j]) continue;
+                        float v = acc[i][j][e];
+                        if (EPI == GD_EPI_SLAB) {
+                            g.C[(int64_t)split * g.slab_stride + (int64_t)m * g.ldc + ncl[j]] = v;
+                        } else if (EPI == GD_EPI_STORE) {
+                            float* p = &g.C[(int64_t)m * g.ldc + ncl[j]];
+                            *p = g.accumulate ? (*p + v) : v;
+                        } else {
+                            v += biasv[j];
+                            if (g.act == 1) v = gd_tanh(v);
+                            g.C[(int64_t)m * g.ldc + ncl[j]] = v;
+                        }
+                    }
+                }
+            }
+    } else {
+        // LOSS / POST, one 16-row block at a time: phase 1 -- all auxiliary loads of the block (4*TN per
+        // array, in flight together); phase 2 -- arithmetic + predicated stores.
+        const bool has_z = (EPI == GD_EPI_POST) && (g.aux2 != nullptr);
+        const bool has_r = (EPI == GD_EPI_POST) && (g.r2 != nullptr);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float av[4][TN];  // target (LOSS) or x_t (POST)
+            float zv[4][TN];  // z noise (POST with sampling noise)
+            float c1v[4], c2v[4], p1v[4], p2v[4], sgv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int mc = min(m0 + wm0 + 16 * i + 4 * q + e, g.M - 1);
+                c1v[e] = 1.f; c2v[e] = 0.f; p1v[e] = 0.f; p2v[e] = 0.f; sgv[e] = 0.f;
+                if (EPI == GD_EPI_LOSS) {
+                    if (g.r0) c1v[e] = g.r0[mc];  // alpha
+                } else {
+                    c1v[e] = g.r0[mc];
+                    c2v[e] = g.r1[mc];
+                    if (has_r) {
+                        p1v[e] = g.r2[mc];
+                        p2v[e] = g.r3[mc];
+                    }
+                    if (has_z) sgv[e] = g.r4[mc];
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    av[e][j] = g.aux[(int64_t)mc * g.ldaux + ncl[j]];
+                    zv[e][j] = has_z ? g.aux2[(int64_t)mc * g.ldaux2 + ncl[j]] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = m0 + wm0 + 16 * i + 4 * q + e;
+                const bool mok = m < g.M;
+                float racc = 0.f;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const bool ok = mok && nok[j];
+                    const float v = acc[i][j][e] + biasv[j];
+                    if (EPI == GD_EPI_LOSS) {
+                        const float d = c1v[e] * v - av[e][j];
+                        if (ok) {
+                            if (g.out2) g.out2[(int64_t)m * g.ldout2 + ncl[j]] = v;
+                            g.C[(int64_t)m * g.ldc + ncl[j]] = d;
+                            racc += d * d;
+                        }
+                    } else {
+                        const float xt = av[e][j];
+                        const float pred = has_r ? (p1v[e] * xt - p2v[e] * v) : v;
+                        float mean = c1v[e] * pred + c2v[e] * xt;
+                        if (has_z) mean += sgv[e] * zv[e][j];
+                        if (ok) {
+                            if (g.out2) g.out2[(int64_t)m * g.ldout2 + ncl[j]] = pred;
+                            g.C[(int64_t)m * g.ldc + ncl[j]] = mean;
+                        }
+                    }
+                }
+                rowacc[i][e] = racc;
+            }
+        }
+    }
+    if (EPI == GD_EPI_LOSS) {
+        // per-row sum of squares: 16 lanes (r) of each q-group hold one row's columns
+        float* rs = smem;  // [BM][WAVES_N]; the tile buffers are dead after the final barrier
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = rowacc[i][e];
+                v += __shfl_xor(v, 1);
+                v += __shfl_xor(v, 2);
+                v += __shfl_xor(v, 4);
+                v += __shfl_xor(v, 8);
+                if (r == 0) rs[(wm0 + 16 * i + 4 * q + e) * WAVES_N + (wave % WAVES_N)] = v;
+            }
+        __syncthreads();
+        if (tid < BM && m0 + tid < g.M) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES_N; ++w) s += rs[tid * WAVES_N + w];
+            g.rowpart[(int64_t)(m0 + tid) * g.ld_rowpart + tile_n] = s;
+        }
+    }
+}
+
+}  // namespace

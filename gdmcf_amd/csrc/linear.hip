@@ -29,9 +29,19 @@ int pick_splits(int M, int N, int K, int cls, int bk) {
 
 inline int64_t round4(int64_t x) { return (x + 3) & ~(int64_t)3; }
 
+// input precision of the dense products issued by the calling thread (gdmcf_gemm_precision)
+thread_local int t_gemm_prec = GDMCF_GEMM_F32;
+inline int cur_bk() { return t_gemm_prec == GDMCF_GEMM_BF16 ? 64 : 32; }
+
 }  // namespace
 
 extern "C" {
+
+int gdmcf_gemm_precision(int mode) {
+    const int prev = t_gemm_prec;
+    if (mode == GDMCF_GEMM_F32 || mode == GDMCF_GEMM_BF16) t_gemm_prec = mode;
+    return prev;
+}
 
 size_t gdmcf_linear_ws_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
@@ -50,8 +60,9 @@ int gdmcf_linear_fwd_f32(const float* A, int64_t lda, const float* W, int64_t ld
     GD_CHECK_ARG(act == 0 || act == 1, "linear_fwd: bad activation");
     hipStream_t s = (hipStream_t)stream;
     const int cls = gd_pick_shape_class(M, N);
-    const int splits = pick_splits(M, N, K, cls, 32);
+    const int splits = pick_splits(M, N, K, cls, cur_bk());
     GdGemm g = {};
+    g.bf16 = (t_gemm_prec == GDMCF_GEMM_BF16);
     g.A = A; g.lda = lda; g.B = W; g.ldb = ldw; g.M = M; g.N = N; g.K = K;
     g.m_fastest = gd_cdiv(M, gd_gemm_tile_m(cls)) <= gd_cdiv(N, gd_gemm_tile_n(cls));
     g.bias = bias; g.act = act; g.prof_tag = 1;
@@ -81,6 +92,7 @@ int gdmcf_linear_loss_fwd_f32(const float* A, int64_t lda, const float* W, int64
     hipStream_t s = (hipStream_t)stream;
     const int cls = gd_pick_shape_class(M, N);
     GdGemm g = {};
+    g.bf16 = (t_gemm_prec == GDMCF_GEMM_BF16);
     g.A = A; g.lda = lda; g.B = W; g.ldb = ldw; g.M = M; g.N = N; g.K = K; g.splits = 1;
     g.m_fastest = gd_cdiv(M, gd_gemm_tile_m(cls)) <= gd_cdiv(N, gd_gemm_tile_n(cls));
     g.bias = bias; g.aux = target; g.ldaux = ldt; g.r0 = alpha; g.out2 = out; g.ldout2 = ldo;
@@ -102,6 +114,7 @@ int gdmcf_linear_posterior_fwd_f32(const float* A, int64_t lda, const float* W, 
     hipStream_t s = (hipStream_t)stream;
     const int cls = gd_pick_shape_class(M, N);
     GdGemm g = {};
+    g.bf16 = (t_gemm_prec == GDMCF_GEMM_BF16);
     g.A = A; g.lda = lda; g.B = W; g.ldb = ldw; g.M = M; g.N = N; g.K = K; g.splits = 1;
     g.m_fastest = gd_cdiv(M, gd_gemm_tile_m(cls)) <= gd_cdiv(N, gd_gemm_tile_n(cls));
     g.bias = bias; g.aux = x_t; g.ldaux = ldxt; g.aux2 = z; g.ldaux2 = ldz;
@@ -118,7 +131,7 @@ int gdmcf_linear_bwd_input_f32(const float* dZ, int64_t lddz, const float* W, in
     hipStream_t s = (hipStream_t)stream;
     // product dims: [M x K_in] = dZ[M x N] * W[N x K_in]  -> gemm (M, K, reduction N)
     const int cls = gd_pick_shape_class(M, K);
-    const int splits = pick_splits(M, K, N, cls, 32);
+    const int splits = pick_splits(M, K, N, cls, cur_bk());
     const int64_t lds_ = round4(K);
     const size_t need = (size_t)splits * M * lds_ * sizeof(float);
     if (ws == nullptr || ws_bytes < need) {
@@ -126,6 +139,7 @@ int gdmcf_linear_bwd_input_f32(const float* dZ, int64_t lddz, const float* W, in
         return GDMCF_E_WORKSPACE;
     }
     GdGemm g = {};
+    g.bf16 = (t_gemm_prec == GDMCF_GEMM_BF16);
     g.A = dZ; g.lda = lddz; g.B = W; g.ldb = ldw; g.M = M; g.N = K; g.K = N;
     g.m_fastest = gd_cdiv(M, gd_gemm_tile_m(cls)) <= gd_cdiv(K, gd_gemm_tile_n(cls));
     g.splits = splits; g.C = (float*)ws; g.ldc = lds_; g.slab_stride = (int64_t)M * lds_; g.prof_tag = 4;
@@ -144,6 +158,7 @@ int gdmcf_linear_bwd_weight_f32(const float* dZ, int64_t lddz, const float* A, i
     // dW[N x K_in] = dZ[M x N]^T * A[M x K_in]  -> gemm (N, K, reduction M), both operands row-contiguous
     const int cls = gd_pick_shape_class(N, K);
     GdGemm g = {};
+    g.bf16 = (t_gemm_prec == GDMCF_GEMM_BF16);
     g.A = dZ; g.lda = lddz; g.B = A; g.ldb = lda; g.M = N; g.N = K; g.K = M; g.splits = 1;
     g.m_fastest = gd_cdiv(N, gd_gemm_tile_m(cls)) <= gd_cdiv(K, gd_gemm_tile_n(cls));
     g.C = dW; g.ldc = lddw; g.accumulate = accumulate; g.prof_tag = 5;
@@ -162,6 +177,7 @@ int gdmcf_linear_bwd_weight_adamw_f32(const float* dZ, int64_t lddz, const float
     hipStream_t s = (hipStream_t)stream;
     const int cls = gd_pick_shape_class(N, K);
     GdGemm g = {};
+    g.bf16 = (t_gemm_prec == GDMCF_GEMM_BF16);
     g.A = dZ; g.lda = lddz; g.B = A; g.ldb = lda; g.M = N; g.N = K; g.K = M; g.splits = 1;
     g.m_fastest = gd_cdiv(N, gd_gemm_tile_m(cls)) <= gd_cdiv(K, gd_gemm_tile_n(cls));
     g.C = W; g.ldc = ldw; g.aux = exp_avg; g.aux2 = exp_avg_sq; g.prof_tag = 5;

@@ -13,6 +13,8 @@ HBM layout (all float32 row-major, leading dims padded to 64 elements = 256 B):
   slabs           split-K partial sums (forward of layer 0, input-gradient of the last layer)
 """
 
+import functools
+
 import torch
 
 from . import _lib
@@ -24,6 +26,21 @@ def _ceil64(n):
 
 class _Bufs:
     pass
+
+
+_GEMM_MODES = {"f32": 0, "bf16": 1}  # include/gdmcf_hip.h GDMCF_GEMM_F32 / GDMCF_GEMM_BF16
+
+
+def _with_precision(fn):
+    """Runs an engine entry point with the library's per-thread GEMM input precision set to this engine's."""
+    @functools.wraps(fn)
+    def wrapped(self, *a, **kw):
+        prev = self.lib.gdmcf_gemm_precision(_GEMM_MODES[self.gemm_dtype])
+        try:
+            return fn(self, *a, **kw)
+        finally:
+            self.lib.gdmcf_gemm_precision(prev)
+    return wrapped
 
 
 class DenoiserEngine:
@@ -44,6 +61,11 @@ class DenoiserEngine:
         # single-GPU optimiser-in-backward (FusedAdamW.fuse_into_backward): big weights are updated inside the
         # weight-gradient GEMM's epilogue; their gradient is never materialised.
         self.fused_opt = None
+
+    @property
+    def gemm_dtype(self):
+        """"f32": exact-f32 MFMA products (parity path);  "bf16": operands rounded to bf16 on chip, f32 accumulate."""
+        return getattr(self.model, "gemm_dtype", "f32")
 
     def manual_seed(self, seed):
         self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
@@ -140,6 +162,7 @@ class DenoiserEngine:
     # ------------------------------------------------------------------------------------------
     # fused training forward / backward
     # ------------------------------------------------------------------------------------------
+    @_with_precision
     def train_forward(self, spec):
         x0, ts = spec["x_start"], spec["ts"]
         B, dev = x0.shape[0], x0.device
@@ -185,6 +208,7 @@ class DenoiserEngine:
         self._saved = dict(kind="train", B=B, bufs=bufs, layers=layers, keepalive=(keepalive, target, alpha, rowdiv, pt))
         return loss
 
+    @_with_precision
     def train_backward(self, gloss):
         sv = self._saved
         bufs = sv["bufs"]
@@ -194,6 +218,7 @@ class DenoiserEngine:
     # ------------------------------------------------------------------------------------------
     # plain forward / backward (model(x, t))
     # ------------------------------------------------------------------------------------------
+    @_with_precision
     def forward_plain(self, x, timesteps, training, drop_mask=None):
         B, dev = x.shape[0], x.device
         layers = self._layers()
@@ -211,6 +236,7 @@ class DenoiserEngine:
         self._saved = dict(kind="plain", B=B, bufs=bufs, layers=layers, keepalive=(keepalive, ts))
         return out
 
+    @_with_precision
     def backward_plain(self, gout):
         sv = self._saved
         g = gout.to(torch.float32)
@@ -304,6 +330,7 @@ class DenoiserEngine:
     # ------------------------------------------------------------------------------------------
     # reverse diffusion loop (reference gaussian_diffusion.py:161-220)
     # ------------------------------------------------------------------------------------------
+    @_with_precision
     def p_sample_loop(self, x_start, steps, T, tabs32, eps_mode, sampling_noise, noise0=None, step_noise=None,
                       capture=None):
         """tabs32: dict of float32 device tables [T] (sqrt_ab, sqrt_1mab, c1, c2, r1, r2, sigma)."""

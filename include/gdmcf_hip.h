@@ -104,6 +104,14 @@ int gdmcf_dnn_emb_cols_f32(const int64_t* ts, const float* emb_w, const float* e
 /* ---- dense layers on the f32 MFMA (v_mfma_f32_16x16x4_f32) -------------------------------
  * replaces nn.Linear (+tanh) in DNN.forward (models/DNN.py:79-86) and their autograd backward
  * (main.py:350).  W is nn.Linear layout [N,K].  act: 0 none, 1 tanh.                        */
+/* Input precision of the dense products (BASELINE configs[2] "bf16 denoiser GEMM on MFMA").  The setting is
+ * per calling thread and applies to every gdmcf_linear_* call that follows; returns the previous mode (a mode
+ * outside the enum only queries).  GDMCF_GEMM_BF16: both operands of each product are rounded to bfloat16
+ * (nearest-even) on chip and multiplied on the bf16 matrix pipe with float32 accumulation; all tensors in HBM
+ * (weights, activations, gradients, optimiser state) stay float32.  Replaces what the reference would obtain
+ * with torch.autocast(dtype=torch.bfloat16) around models/DNN.py:79-86 -- the reference itself runs fp32.    */
+enum { GDMCF_GEMM_F32 = 0, GDMCF_GEMM_BF16 = 1 };
+int gdmcf_gemm_precision(int mode);
 size_t gdmcf_linear_ws_bytes(int M, int N, int K);
 /* C[M,N] = act(A[M,K] @ W[N,K]^T + bias) */
 int gdmcf_linear_fwd_f32(const float* A, int64_t lda, const float* W, int64_t ldw,

@@ -3,6 +3,7 @@
 
   python profiles/summarize.py stats  <kernel_stats.csv>                    -> per-kernel time table
   python profiles/summarize.py traffic <fetch counter csv> <write counter csv> -> HBM bytes per launch
+  python profiles/summarize.py counters <counter csv>                       -> per-launch average of each counter
 
 HBM traffic follows MI355X_MICROARCH.md (HBM / rocprofv3): FETCH_SIZE and WRITE_SIZE come from separate
 --pmc passes and are in KiB; on gfx950 FETCH_SIZE reports exactly half of the bytes of a wide coalesced
@@ -55,8 +56,22 @@ def traffic(fetch_csv, write_csv):
     return out
 
 
+def counters(path):
+    """per-kernel per-launch average of every counter in a --pmc csv"""
+    names = sorted({r["Counter_Name"] for r in csv.DictReader(open(path))})
+    table = collections.defaultdict(dict)
+    for c in names:
+        avg, n = per_kernel(path, c)
+        for k, v in avg.items():
+            table[k][c] = round(v, 1)
+            table[k]["launches"] = n[k]
+    return [dict(kernel=k, **v) for k, v in table.items()]
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "stats":
+    if sys.argv[1] == "counters":
+        print(json.dumps(counters(sys.argv[2]), indent=1))
+    elif sys.argv[1] == "stats":
         print(json.dumps(stats(sys.argv[2]), indent=1))
     else:
         print(json.dumps(traffic(sys.argv[2], sys.argv[3]), indent=1))

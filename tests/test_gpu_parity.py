@@ -558,12 +558,24 @@ def test_lightgcn_bpr_step_gradients_match_oracle():
     assert np.mean(losses[-5:]) < np.mean(losses[:5])
 
 
-def test_linear_entry_points_random_shapes():
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_linear_entry_points_random_shapes(prec):
     """Adversarial shapes for the branch-free edge loaders (clamped addresses, in-register shifts, K tails,
-    odd leading dimensions, split-K on/off): every dense entry point of the C ABI vs float64 matmul."""
-    import ctypes
+    odd leading dimensions, split-K on/off): every dense entry point of the C ABI vs float64 matmul.
+    bf16 mode (gdmcf_gemm_precision): the same, against float64 matmul of the bfloat16-rounded operands --
+    bf16 x bf16 products are exact in f32, so the only difference left is f32 accumulation order."""
     from gdmcf_amd import _lib
     lib = _lib.load()
+    prev = lib.gdmcf_gemm_precision(1 if prec == "bf16" else 0)
+    try:
+        _linear_entry_points_random_shapes(lib, prec)
+    finally:
+        lib.gdmcf_gemm_precision(prev)
+
+
+def _linear_entry_points_random_shapes(lib, prec):
+    from gdmcf_amd import _lib
+    D = (lambda t: t.bfloat16().double()) if prec == "bf16" else (lambda t: t.double())
     rng = np.random.default_rng(0)
     st = _lib.stream_ptr()
     shapes = [(1, 4, 4), (3, 5, 7), (16, 16, 16), (17, 33, 65), (80, 128, 32), (81, 129, 33), (100, 257, 36), (400, 130, 1000),
@@ -574,7 +586,7 @@ def test_linear_entry_points_random_shapes():
             A = torch.zeros(M, lda, device=DEV); A[:, :K] = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).to(DEV)
             W = torch.zeros(N, ldw, device=DEV); W[:, :K] = torch.from_numpy((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)).to(DEV)
             bias = torch.from_numpy(rng.standard_normal(N).astype(np.float32)).to(DEV)
-            ref = A[:, :K].double() @ W[:, :K].double().T + bias.double()
+            ref = D(A[:, :K]) @ D(W[:, :K]).T + bias.double()
             close = lambda got, want: float((got - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
             ws_bytes = int(lib.gdmcf_linear_ws_bytes(M, N, K))
             ws = torch.empty(max(ws_bytes, 256), dtype=torch.uint8, device=DEV)
@@ -602,20 +614,22 @@ def test_linear_entry_points_random_shapes():
             rs = torch.from_numpy(rng.uniform(0.5, 1.5, M).astype(np.float32)).to(DEV)
             act = torch.zeros(M, lda, device=DEV); act[:, :K] = torch.from_numpy(rng.uniform(-0.9, 0.9, (M, K)).astype(np.float32)).to(DEV)
             dA = torch.full((M, lda), float("nan"), device=DEV)
-            if N >= 4 and K >= 4:
+            if (N >= 4 and K >= 4) or prec == "bf16":
                 _lib.check(lib.gdmcf_linear_bwd_input_f32(dZ.data_ptr(), ldc, W.data_ptr(), ldw, rs.data_ptr(), act.data_ptr(), lda, 1,
                                                           M, N, K, dA.data_ptr(), lda, ws.data_ptr(), ws_bytes, st))
-                r2 = rs.double()[:, None] * (dZ[:, :N].double() @ W[:, :K].double()) * (1 - act[:, :K].double() ** 2)
+                r2 = rs.double()[:, None] * (D(dZ[:, :N]) @ D(W[:, :K])) * (1 - act[:, :K].double() ** 2)
                 assert close(dA[:, :K].double(), r2), ("bwd_input", M, N, K, pad)
                 # backward wrt weight: dW = dZ^T @ A, db = sum_m rs*dZ
                 dW = torch.full((N, ldw), float("nan"), device=DEV)
                 db = torch.empty(N, device=DEV)
                 _lib.check(lib.gdmcf_linear_bwd_weight_f32(dZ.data_ptr(), ldc, A.data_ptr(), lda, rs.data_ptr(), M, N, K, dW.data_ptr(),
                                                            ldw, db.data_ptr(), 0, st))
-                r3 = dZ[:, :N].double().T @ A[:, :K].double()
+                r3 = D(dZ[:, :N]).T @ D(A[:, :K])
                 assert close(dW[:, :K].double(), r3), ("bwd_weight", M, N, K, pad)
                 np.testing.assert_allclose(db.cpu().numpy(), (rs.double()[:, None] * dZ[:, :N].double()).sum(0).cpu().numpy(),
                                            rtol=1e-4, atol=1e-4)
+    if prec == "bf16":  # the bf16 loaders take any K
+        return
     # degenerate shapes are refused loudly, not mis-computed
     A = torch.zeros(4, 3, device=DEV); W = torch.zeros(5, 3, device=DEV); C = torch.zeros(4, 5, device=DEV)
     ws = torch.empty(4096, dtype=torch.uint8, device=DEV)
