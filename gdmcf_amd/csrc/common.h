@@ -115,7 +115,8 @@ struct GdGemm {
     int stagger;  // startup delay (x512 clocks) for workgroups in odd wave slots; de-phases co-resident workgroups
 };
 
-// shape classes: 0 = "batch-M" (BM=80, BN=128), 1 = square 128x128, 2 = small 64x64
+// shape classes: 0 = "batch-M" (BM=80, BN=128), 1 = square 128x128, 2 = small 64x64,
+//                3 = bf16 only: 208x256 on 8 waves (batch-sized M, see gemm_bf16.hip)
 int gd_gemm_launch(int layA, int layB, int epi, int shape_class, GdGemm& g, hipStream_t s);
 int gd_gemm_bf16_launch(int layA, int layB, int epi, int shape_class, GdGemm& g, hipStream_t s);  // g.bf16 != 0
 int gd_gemm_tile_m(int shape_class);

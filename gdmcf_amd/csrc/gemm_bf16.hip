@@ -16,9 +16,11 @@
 //  * row-contiguous source ([k][rows]): a lane loads a 8(k) x 4(rows) patch with eight 16-byte loads (lanes
 //    along the rows: coalesced), transposes it in registers and writes four 16-byte slots; eight consecutive
 //    lanes hold the eight k-groups of the same rows, i.e. write one full 128-byte row per ds_write_b128 group.
-// With bf16 MFMA time per tile 8x smaller than f32, the kernel is bound by bringing the f32 sources in
-// (HBM / L2), so the structure is the plain one: register-staged double buffering, one barrier per k-tile,
-// three workgroups per CU to cover latency.
+// With bf16 MFMA time per tile 16x smaller than f32, the kernel is bound by bringing the f32 sources in: at
+// 80x128 tiles the L2 serves 14 TB/s of tile reads (rocprofv3 TCC_REQ) for 2.6 TB/s of HBM fetches.  Hence the
+// plain structure (register-staged double buffering, one barrier per k-tile, occupancy to cover latency) and
+// the extra tile class 3 = 208x256 on eight waves for the batch-sized products (M = 400 = 2 x 208 - 16): 55 %
+// fewer L2 bytes per FLOP than 80x128.
 #include <stdlib.h>
 
 #include "common.h"
@@ -26,7 +28,6 @@
 
 namespace {
 
-constexpr int NTHREADS = 256;
 constexpr int BK = 64;
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -46,7 +47,7 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
 __device__ __forceinline__ int img_off(int r, int slot) { return r * 128 + ((slot ^ ((r >> 1) & 7)) << 4); }
 
 // ---- staging: global f32 -> registers -> bf16 LDS image ---------------------------------------------------
-template <int LAY, int R>
+template <int LAY, int R, int NT>
 struct Stage;
 
 // Loads come in two flavours chosen per tile by a workgroup-uniform test, so that the common one is a run of
@@ -56,10 +57,10 @@ struct Stage;
 //   fast()  false -> load_safe: element-wise predicated loads (edge tiles only)
 
 // K-contiguous source [rows][K]
-template <int R>
-struct Stage<GD_LAY_KC, R> {
+template <int R, int NT>
+struct Stage<GD_LAY_KC, R, NT> {
     static constexpr int UNITS = R * 16;  // (row, 16-byte segment)
-    static constexpr int NL = (UNITS + NTHREADS - 1) / NTHREADS;
+    static constexpr int NL = (UNITS + NT - 1) / NT;
     f32x4 reg[NL];
 
     __device__ static __forceinline__ bool fast(int row0, int rows_total, int k0, int kend) { return k0 + BK <= kend; }
@@ -68,8 +69,8 @@ struct Stage<GD_LAY_KC, R> {
                                               int k0, int kend, int tid) {
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
-            const int u = tid + i * NTHREADS;
-            const int row = min(row0 + (u >> 4), rows_total - 1);
+            const int u = tid + i * NT;
+            const int row = min(row0 + min(u >> 4, R - 1), rows_total - 1);
             reg[i] = *reinterpret_cast<const f32x4_u*>(src + (int64_t)row * ld + k0 + ((u & 15) << 2));
         }
     }
@@ -78,8 +79,8 @@ struct Stage<GD_LAY_KC, R> {
                                               int k0, int kend, int tid) {
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
-            const int u = tid + i * NTHREADS;
-            const int row = min(row0 + (u >> 4), rows_total - 1);
+            const int u = tid + i * NT;
+            const int row = min(row0 + min(u >> 4, R - 1), rows_total - 1);
             const int k = k0 + ((u & 15) << 2);
             const float* p = src + (int64_t)row * ld + k;
             f32x4 v;
@@ -93,8 +94,8 @@ struct Stage<GD_LAY_KC, R> {
     __device__ __forceinline__ void store(char* img, int k0, int kend, int tid) const {
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
-            const int u = tid + i * NTHREADS;
-            if (UNITS % NTHREADS != 0 && u >= UNITS) continue;
+            const int u = tid + i * NT;
+            if (UNITS % NT != 0 && u >= UNITS) continue;
             const int row = u >> 4, seg = u & 15;
             u32x2 w;
             w.x = pack_bf16(reg[i].x, reg[i].y);
@@ -105,10 +106,10 @@ struct Stage<GD_LAY_KC, R> {
 };
 
 // row-contiguous source [K][rows]
-template <int R>
-struct Stage<GD_LAY_MC, R> {
+template <int R, int NT>
+struct Stage<GD_LAY_MC, R, NT> {
     static constexpr int UNITS = (R / 4) * 8;  // (4-row group, 8-deep k group)
-    static constexpr int NL = (UNITS + NTHREADS - 1) / NTHREADS;
+    static constexpr int NL = (UNITS + NT - 1) / NT;
     f32x4 reg[NL][8];
 
     __device__ static __forceinline__ bool fast(int row0, int rows_total, int k0, int kend) { return row0 + R <= rows_total; }
@@ -117,7 +118,7 @@ struct Stage<GD_LAY_MC, R> {
                                               int k0, int kend, int tid) {
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
-            const int u = tid + i * NTHREADS;
+            const int u = tid + i * NT;
             const int kg = u & 7, rg = min(u >> 3, R / 4 - 1);
             const float* p = src + row0 + (rg << 2);
 #pragma unroll
@@ -130,7 +131,7 @@ struct Stage<GD_LAY_MC, R> {
                                               int k0, int kend, int tid) {
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
-            const int u = tid + i * NTHREADS;
+            const int u = tid + i * NT;
             const int kg = u & 7, rg = min(u >> 3, R / 4 - 1);
             const int row = row0 + (rg << 2);
 #pragma unroll
@@ -149,8 +150,8 @@ struct Stage<GD_LAY_MC, R> {
         const bool ktail = k0 + BK > kend;  // workgroup-uniform
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
-            const int u = tid + i * NTHREADS;
-            if (UNITS % NTHREADS != 0 && u >= UNITS) continue;
+            const int u = tid + i * NT;
+            if (UNITS % NT != 0 && u >= UNITS) continue;
             const int kg = u & 7, rg = u >> 3;
             const int nvalid = ktail ? kend - (k0 + (kg << 3)) : 8;  // k values of this group inside [k0, kend)
 #pragma unroll
@@ -173,18 +174,18 @@ struct Stage<GD_LAY_MC, R> {
     }
 };
 
-template <int LAY, int R>
-__device__ __forceinline__ void stage_load(Stage<LAY, R>& st, const float* __restrict__ src, int64_t ld, int row0,
+template <int LAY, int R, int NT>
+__device__ __forceinline__ void stage_load(Stage<LAY, R, NT>& st, const float* __restrict__ src, int64_t ld, int row0,
                                            int rows_total, int k0, int kend, int tid) {
-    if (Stage<LAY, R>::fast(row0, rows_total, k0, kend))
+    if (Stage<LAY, R, NT>::fast(row0, rows_total, k0, kend))
         st.load_fast(src, ld, row0, rows_total, k0, kend, tid);
     else
         st.load_safe(src, ld, row0, rows_total, k0, kend, tid);
 }
 
 template <int LAYA, int LAYB, int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
-__global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const GdGemm g) {
-    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(const GdGemm g) {
+    constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int TM = WTM / 16, TN = WTN / 16;
     static_assert(TM * 16 * WAVES_M == BM && TN * 16 * WAVES_N == BN, "tile must split into 16x16 blocks");
@@ -216,8 +217,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const GdGemm g) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    Stage<LAYA, BM> sa;
-    Stage<LAYB, BN> sb;
+    Stage<LAYA, BM, NT> sa;
+    Stage<LAYB, BN, NT> sb;
     if (nt > 0) {
         stage_load(sa, g.A, g.lda, m0, g.M, kbeg, kend, tid);
         stage_load(sb, g.B, g.ldb, n0, g.N, kbeg, kend, tid);
@@ -282,7 +283,7 @@ int launch_one(GdGemm& g, hipStream_t s) {
     }
     {
         GdProfScope prof(g.prof_tag, 2.0 * g.M * g.N * g.K, s);
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTHREADS), lds, s, g);
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * WM * WN), lds, s, g);
     }
     return gd_launch_status("gemm_bf16");
 }
@@ -293,6 +294,7 @@ int launch_class(int cls, GdGemm& g, hipStream_t s) {
         case 0: return launch_one<LAYA, LAYB, 80, 128, 1, 4, EPI>(g, s);
         case 1: return launch_one<LAYA, LAYB, 128, 128, 2, 2, EPI>(g, s);
         case 2: return launch_one<LAYA, LAYB, 64, 64, 2, 2, EPI>(g, s);
+        case 3: return launch_one<LAYA, LAYB, 208, 256, 1, 8, EPI>(g, s);
     }
     gdmcf_set_error("bad gemm shape class %d", cls);
     return GDMCF_E_ARG;

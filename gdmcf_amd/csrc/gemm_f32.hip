@@ -661,8 +661,8 @@ int launch_class(int cls, GdGemm& g, hipStream_t s) {
 
 }  // namespace
 
-int gd_gemm_tile_m(int cls) { return cls == 0 ? 80 : (cls == 1 ? 128 : 64); }
-int gd_gemm_tile_n(int cls) { return cls == 2 ? 64 : 128; }
+int gd_gemm_tile_m(int cls) { return cls == 0 ? 80 : (cls == 1 ? 128 : (cls == 2 ? 64 : 208)); }
+int gd_gemm_tile_n(int cls) { return cls == 2 ? 64 : (cls == 3 ? 256 : 128); }
 int gd_gemm_bk(int layA, int layB) { return (layA == GD_LAY_MC && layB == GD_LAY_MC) ? 16 : 32; }
 
 int gd_pick_shape_class(int M, int N) {

@@ -16,10 +16,28 @@ namespace {
 // workgroups evens out the tail (measured sweet spot on the batch-400 products; GDMCF_TARGET_WGS overrides)
 static const int TARGET_WGS = getenv("GDMCF_TARGET_WGS") ? atoi(getenv("GDMCF_TARGET_WGS")) : 760;
 
+// input precision of the dense products issued by the calling thread (gdmcf_gemm_precision)
+thread_local int t_gemm_prec = GDMCF_GEMM_F32;
+
+// tile class of an [M,N] output.  bf16 products are bound by L2 reads of the f32 sources, so batch-sized M takes
+// the 208x256 class when that wastes little: <= 10 % row padding and, for products that cannot split K
+// (`fused`: the epilogue needs complete sums), a last round of workgroups that is mostly full (one 120 KB-LDS
+// workgroup per CU).
+int pick_class(int M, int N, bool fused, int prec) {
+    if (prec == GDMCF_GEMM_BF16 && M > 128) {
+        const long pad = (long)gd_cdiv(M, 208) * 208;
+        const long tiles = (pad / 208) * gd_cdiv(N, 256);
+        const long rounds = (tiles + 255) / 256;
+        if (pad * 10 <= (long)M * 11 && pad / 208 <= 2 && (!fused || tiles * 100 >= rounds * 256 * 85)) return 3;
+    }
+    return gd_pick_shape_class(M, N);
+}
+
 // number of K splits for an [M,N,K] product whose output is small (batch x hidden)
-int pick_splits(int M, int N, int K, int cls, int bk) {
+int pick_splits(int M, int N, int K, int cls, int prec) {
+    const int bk = prec == GDMCF_GEMM_BF16 ? 64 : 32;
     const int tiles = gd_cdiv(M, gd_gemm_tile_m(cls)) * gd_cdiv(N, gd_gemm_tile_n(cls));
-    int s = TARGET_WGS / tiles;
+    int s = (cls == 3 ? 256 : TARGET_WGS) / tiles;
     const int max_by_k = K / (8 * bk);  // keep >= 8 K-tiles per split
     if (s > max_by_k) s = max_by_k;
     if (s < 1) s = 1;
@@ -29,9 +47,6 @@ int pick_splits(int M, int N, int K, int cls, int bk) {
 
 inline int64_t round4(int64_t x) { return (x + 3) & ~(int64_t)3; }
 
-// input precision of the dense products issued by the calling thread (gdmcf_gemm_precision)
-thread_local int t_gemm_prec = GDMCF_GEMM_F32;
-inline int cur_bk() { return t_gemm_prec == GDMCF_GEMM_BF16 ? 64 : 32; }
 
 }  // namespace
 
@@ -46,10 +61,15 @@ int gdmcf_gemm_precision(int mode) {
 size_t gdmcf_linear_ws_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     // forward: slabs [splits][M][round4(N)];  backward-input: slabs [splits][M][round4(K)]
-    const int cf = gd_pick_shape_class(M, N), cb = gd_pick_shape_class(M, K);
-    const size_t f = (size_t)pick_splits(M, N, K, cf, 32) * M * round4(N);
-    const size_t b = (size_t)pick_splits(M, K, N, cb, 32) * M * round4(K);
-    return (f > b ? f : b) * sizeof(float) + 256;
+    size_t need = 0;
+    for (int prec = GDMCF_GEMM_F32; prec <= GDMCF_GEMM_BF16; ++prec) {  // the caller may switch precision later
+        const int cf = pick_class(M, N, false, prec), cb = pick_class(M, K, false, prec);
+        const size_t f = (size_t)pick_splits(M, N, K, cf, prec) * M * round4(N);
+        const size_t b = (size_t)pick_splits(M, K, N, cb, prec) * M * round4(K);
+        need = need > f ? need : f;
+        need = need > b ? need : b;
+    }
+    return need * sizeof(float) + 256;
 }
 
 int gdmcf_loss_tiles(int N) { return gd_cdiv(N, 64); }
@@ -59,8 +79,8 @@ int gdmcf_linear_fwd_f32(const float* A, int64_t lda, const float* W, int64_t ld
     GD_CHECK_SHAPE(M > 0 && N > 0 && K > 0 && lda >= K && ldw >= K && ldc >= N, "linear_fwd: bad shape");
     GD_CHECK_ARG(act == 0 || act == 1, "linear_fwd: bad activation");
     hipStream_t s = (hipStream_t)stream;
-    const int cls = gd_pick_shape_class(M, N);
-    const int splits = pick_splits(M, N, K, cls, cur_bk());
+    const int cls = pick_class(M, N, false, t_gemm_prec);
+    const int splits = pick_splits(M, N, K, cls, t_gemm_prec);
     GdGemm g = {};
     g.bf16 = (t_gemm_prec == GDMCF_GEMM_BF16);
     g.A = A; g.lda = lda; g.B = W; g.ldb = ldw; g.M = M; g.N = N; g.K = K;
@@ -90,7 +110,7 @@ int gdmcf_linear_loss_fwd_f32(const float* A, int64_t lda, const float* W, int64
     GD_CHECK_SHAPE(M > 0 && N > 0 && K > 0 && lda >= K && ldw >= K && ldt >= N && ldd >= N, "linear_loss_fwd: bad shape");
     GD_CHECK_SHAPE(out == nullptr || ldo >= N, "linear_loss_fwd: ldo < N");
     hipStream_t s = (hipStream_t)stream;
-    const int cls = gd_pick_shape_class(M, N);
+    const int cls = pick_class(M, N, true, t_gemm_prec);
     GdGemm g = {};
     g.bf16 = (t_gemm_prec == GDMCF_GEMM_BF16);
     g.A = A; g.lda = lda; g.B = W; g.ldb = ldw; g.M = M; g.N = N; g.K = K; g.splits = 1;
@@ -112,7 +132,7 @@ int gdmcf_linear_posterior_fwd_f32(const float* A, int64_t lda, const float* W, 
     GD_CHECK_ARG((r1 == nullptr) == (r2 == nullptr), "linear_posterior_fwd: r1/r2 must both be set or both NULL");
     GD_CHECK_ARG(z == nullptr || (sigma != nullptr && ldz >= N), "linear_posterior_fwd: sigma missing");
     hipStream_t s = (hipStream_t)stream;
-    const int cls = gd_pick_shape_class(M, N);
+    const int cls = pick_class(M, N, true, t_gemm_prec);
     GdGemm g = {};
     g.bf16 = (t_gemm_prec == GDMCF_GEMM_BF16);
     g.A = A; g.lda = lda; g.B = W; g.ldb = ldw; g.M = M; g.N = N; g.K = K; g.splits = 1;
@@ -130,8 +150,8 @@ int gdmcf_linear_bwd_input_f32(const float* dZ, int64_t lddz, const float* W, in
     GD_CHECK_ARG(act == 0 || (act == 1 && Aact && ldact >= K), "linear_bwd_input: activation output missing");
     hipStream_t s = (hipStream_t)stream;
     // product dims: [M x K_in] = dZ[M x N] * W[N x K_in]  -> gemm (M, K, reduction N)
-    const int cls = gd_pick_shape_class(M, K);
-    const int splits = pick_splits(M, K, N, cls, cur_bk());
+    const int cls = pick_class(M, K, false, t_gemm_prec);
+    const int splits = pick_splits(M, K, N, cls, t_gemm_prec);
     const int64_t lds_ = round4(K);
     const size_t need = (size_t)splits * M * lds_ * sizeof(float);
     if (ws == nullptr || ws_bytes < need) {

@@ -407,6 +407,64 @@ def test_full_size_step_matches_oracle_yelp_shape():
     np.testing.assert_allclose(gdif.Lt_history.cpu().numpy(), od.Lt_history.numpy(), rtol=1e-4)
 
 
+@pytest.mark.parametrize("shape", [(32, 515, 100), (400, 34395, 1000)])
+def test_bf16_gemm_path_tracks_oracle(shape):
+    """BASELINE configs[2] (bf16 denoiser GEMM inputs, f32 accumulate / state): the same injected-randomness
+    train step as the f32 parity tests, against the f32 CPU oracle.  Tolerances are those of bf16 operand rounding
+    (2^-9 relative per operand, averaging out over the reduction), measured with tools/bf16_check.py:
+    mean training loss 3e-5 .. 3e-4 relative (<= 1e-4 at the Yelp shape), per-row loss <= 4e-3, gradients
+    1e-3 .. 1e-2 relative L2.  Asserted with ~3x margin.  Also: p_sample + top-20 keeps >= 95 % of the f32 picks."""
+    B, I, hid = shape
+    T = 5
+    torch.manual_seed(0)
+    om = O.DNN([I, hid], [hid, I], 10)
+    model = gdmcf_amd.DNN([I, hid], [hid, I], 10, gemm_dtype="bf16")
+    model.load_state_dict(om.state_dict())
+    model = model.to(DEV)
+    od = O.GaussianDiffusion(O.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, T)
+    gdif = gdmcf_amd.GaussianDiffusion(ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, T, DEV)
+    oopt = O.make_optimizer(om, 1e-3)
+    gopt = gdmcf_amd.FusedAdamW(model.parameters(), lr=1e-3, weight_decay=0.0)
+    om.train(), model.train()
+    g = torch.Generator().manual_seed(1)
+    full = I > 10000
+    for step in range(1 if full else 3):
+        x = (torch.rand(B, I, generator=g) < (0.00075 if full else 0.02)).float()
+        ts = torch.randint(0, T, (B,), generator=g)
+        noise = torch.randn(B, I, generator=g)
+        keep = (torch.rand(B, I, generator=g) < 0.5).float()
+        pt = torch.ones(B)
+        oloss, ovec = O.train_step(od, om, oopt, x, True, ts=ts, pt=pt, noise=noise, drop_mask=keep)
+        ograds = [q.grad.clone() for q in om.parameters()]
+        gopt.zero_grad()
+        terms = gdif.training_losses(model, cu(x), True, ts=cu(ts), pt=cu(pt), noise=cu(noise), drop_mask=cu(keep))
+        gl = terms["loss"].mean()
+        gl.backward()
+        rel = abs(float(gl) - float(oloss)) / abs(float(oloss))
+        assert rel <= (1.5e-4 if full else 1e-3), (step, rel)
+        np.testing.assert_allclose(terms["loss"].detach().cpu().numpy(), ovec.numpy(), rtol=(1.5e-3 if full else 1.2e-2))
+        for p, og in zip(model.parameters(), ograds):
+            assert H.relerr(p.grad.cpu().numpy(), og.numpy()) < 3e-2
+        gopt.step()
+        # keep the two models in lock-step so that step s+1 again isolates one step of rounding
+        model.load_state_dict(om.state_dict())
+        for p, oq in zip(model.parameters(), om.parameters()):
+            gopt.state[p]["exp_avg"].copy_(oopt.state[oq]["exp_avg"])
+            gopt.state[p]["exp_avg_sq"].copy_(oopt.state[oq]["exp_avg_sq"])
+    if not full:
+        f32 = gdmcf_amd.DNN([I, hid], [hid, I], 10)
+        f32.load_state_dict(om.state_dict())
+        f32 = f32.to(DEV).eval()
+        model.eval()
+        x = (torch.rand(B, I, generator=g) < 0.02).float()
+        with torch.no_grad():
+            pa = gdif.p_sample(f32, cu(x), 0, False)
+            pb = gdif.p_sample(model, cu(x), 0, False)
+        ta, tb = torch.topk(pa, 20).indices.cpu().numpy(), torch.topk(pb, 20).indices.cpu().numpy()
+        overlap = np.mean([len(set(a) & set(b)) / 20.0 for a, b in zip(ta, tb)])
+        assert overlap >= 0.95, overlap
+
+
 def test_driver_train_and_evaluate_match_oracle_loop():
     """reference main.py:327-351 + :267-310 end to end on a small synthetic problem: the HIP driver and the
     oracle loop start from the same weights, see the same batches and the same injected randomness, and must
@@ -580,6 +638,8 @@ def _linear_entry_points_random_shapes(lib, prec):
     st = _lib.stream_ptr()
     shapes = [(1, 4, 4), (3, 5, 7), (16, 16, 16), (17, 33, 65), (80, 128, 32), (81, 129, 33), (100, 257, 36), (400, 130, 1000),
               (7, 1000, 515), (129, 70, 4099), (65, 64, 8195), (33, 300, 31), (5, 6, 20000)]
+    if prec == "bf16":  # any K works there; the last three take the 208x256 tile class (fused epilogues included)
+        shapes += [(2, 3, 3), (5, 2, 130), (200, 300, 515), (413, 1000, 700), (400, 28001, 70)]
     for (M, N, K) in shapes:
         for pad in (0, 3):
             lda, ldw, ldc = K + pad, K + (1 if pad else 0), N + pad
