@@ -638,8 +638,8 @@ def _linear_entry_points_random_shapes(lib, prec):
     st = _lib.stream_ptr()
     shapes = [(1, 4, 4), (3, 5, 7), (16, 16, 16), (17, 33, 65), (80, 128, 32), (81, 129, 33), (100, 257, 36), (400, 130, 1000),
               (7, 1000, 515), (129, 70, 4099), (65, 64, 8195), (33, 300, 31), (5, 6, 20000)]
-    if prec == "bf16":  # any K works there; the last three take the 208x256 tile class (fused epilogues included)
-        shapes += [(2, 3, 3), (5, 2, 130), (200, 300, 515), (413, 1000, 700), (400, 28001, 70)]
+    if prec == "bf16":  # any K works there; the last four take the 208x256 tile class (fused epilogues and weight gradients included)
+        shapes += [(2, 3, 3), (5, 2, 130), (200, 300, 515), (413, 1000, 700), (400, 28001, 70), (64, 1100, 28000)]
     for (M, N, K) in shapes:
         for pad in (0, 3):
             lda, ldw, ldc = K + pad, K + (1 if pad else 0), N + pad
