@@ -61,6 +61,9 @@ class DenoiserEngine:
         # single-GPU optimiser-in-backward (FusedAdamW.fuse_into_backward): big weights are updated inside the
         # weight-gradient GEMM's epilogue; their gradient is never materialised.
         self.fused_opt = None
+        # compute a layer's input gradient before its weight gradient (needed when the weight may be updated as
+        # soon as its gradient exists: fused optimiser, single-process early update in parallel.DataParallelStep)
+        self.input_grad_first = False
 
     @property
     def gemm_dtype(self):
@@ -311,7 +314,7 @@ class DenoiserEngine:
                 A_prev, lda_prev = bufs.acts[li - 1], bufs.acts[li - 1].stride(0)
             else:
                 A_prev, lda_prev = bufs.xin, bufs.ldk
-            if fused is not None:
+            if fused is not None or self.input_grad_first:
                 nxt = input_grad(li, w, A_prev, lda_prev, N, K)
                 weight_grad(li, w, bias, A_prev, lda_prev, N, K)
             else:

@@ -89,9 +89,16 @@ class DataParallelStep:
     Overlap: the denoiser engine hands every gradient to `_sink` as soon as its kernels are enqueued.
     Large tensors (the two 137.6 MB weight gradients at Yelp shape) start their all-reduce immediately on
     RCCL's stream, so out_layers' gradient travels over xGMI while the dh / dW1 GEMMs still run; the few
-    small tensors are reduced in one flat bucket at the end.  Everything is waited for before AdamW."""
+    small tensors are reduced in one flat bucket at the end.  Everything is waited for before AdamW.
 
-    def __init__(self, diffusion, model, optimizer, group=None, overlap=True):
+    Single process (world == 1): no exchange.  `early_update=True` issues the AdamW update of a large tensor on a
+    side stream the moment its gradient GEMM is enqueued (the engine then computes a layer's input gradient BEFORE
+    its weight gradient, so nothing reads the old weight any more); same kernels, same values as the sequential
+    order, streams joined before `optimizer.step()` finishes the remaining tensors.  Off by default: measured on
+    MI355X at the Yelp shape it LOSES 3-4 % (1.76 -> 1.83 ms/step) -- the HBM-bound update and the MFMA-bound dW1
+    GEMM slow each other down by more than the 0.17 ms that is hidden."""
+
+    def __init__(self, diffusion, model, optimizer, group=None, overlap=True, early_update=False):
         self.diffusion, self.model, self.optimizer, self.group = diffusion, model, optimizer, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._handles, self._small = [], []
@@ -104,6 +111,12 @@ class DataParallelStep:
                 optimizer._fused_ids = set()
             if overlap:
                 model.engine.grad_sink = self._sink
+        elif (early_update and hasattr(optimizer, "step_subset") and getattr(model.engine, "fused_opt", None) is None
+              and next(model.parameters()).is_cuda):
+            self._side = torch.cuda.Stream()
+            self._side_busy = False
+            model.engine.grad_sink = self._sink_local
+            model.engine.input_grad_first = True
 
     def _sink(self, param, grad):
         param.grad = grad if param.grad is None else param.grad.add_(grad)
@@ -112,6 +125,18 @@ class DataParallelStep:
             self._handles.append((param, _all_reduce(g, self.group, async_op=True)))
         else:
             self._small.append(g)
+
+    def _sink_local(self, param, grad):
+        param.grad = grad if param.grad is None else param.grad.add_(grad)
+        if param.grad.numel() * param.grad.element_size() < (1 << 20):
+            return
+        self.optimizer._init_state(param)  # allocate the moments on the main stream
+        done = torch.cuda.Event()
+        done.record()  # everything enqueued so far: this gradient and every reader of the old weight
+        self._side.wait_event(done)
+        with torch.cuda.stream(self._side):
+            self.optimizer.step_subset([param])
+        self._side_busy = True
 
     def _finish_exchange(self):
         """One small float64 all-reduce carries (a) every small gradient and (b) the (ts, unscaled loss) pairs of
@@ -162,5 +187,8 @@ class DataParallelStep:
             _lib.check(_lib.load().gdmcf_lt_history_update(ts_all.data_ptr(), lu_all.data_ptr(), ts_all.numel(),
                                                            d.steps, d.history_num_per_term, d.Lt_history.data_ptr(),
                                                            d.Lt_count.data_ptr(), _lib.stream_ptr()))
+        if getattr(self, "_side_busy", False):
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._side_busy = False
         self.optimizer.step()
         return loss.detach()

@@ -76,3 +76,47 @@ def test_two_ranks_equal_one_process_on_the_global_batch(tmp_path):
     for r in (r0, r1):
         np.testing.assert_array_equal(r["cnt"].numpy(), diff.Lt_count.cpu().numpy())
         np.testing.assert_allclose(r["hist"].numpy(), diff.Lt_history.cpu().numpy(), rtol=1e-5)
+
+
+def test_single_process_early_update_equals_sequential_step():
+    """world == 1, early_update=True: DataParallelStep issues the AdamW update of each large weight on a side stream as soon as its
+    gradient GEMM is enqueued (input gradient first).  Same kernels on the same data -> bit-identical to the plain
+    zero_grad / training_losses / backward / step loop."""
+    import gdmcf_amd
+    from gdmcf_amd.parallel import DataParallelStep
+    dev, I2, H2, B2 = "cuda:0", 3000, 128, 48
+
+    def build():
+        torch.manual_seed(3)
+        m = gdmcf_amd.DNN([I2, H2], [H2, I2], 10).to(dev).train()
+        d = gdmcf_amd.GaussianDiffusion(gdmcf_amd.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, T, dev)
+        o = gdmcf_amd.FusedAdamW(m.parameters(), lr=1e-3, weight_decay=0.01)
+        return m, d, o
+
+    def inputs(s):
+        g = torch.Generator().manual_seed(7 + s)
+        return dict(x=(torch.rand(B2, I2, generator=g) < 0.03).float().to(dev), ts=torch.randint(0, T, (B2,), generator=g).to(dev),
+                    noise=torch.randn(B2, I2, generator=g).to(dev), keep=(torch.rand(B2, I2, generator=g) < 0.5).float().to(dev))
+
+    m0, d0, o0 = build()
+    l0 = []
+    for s in range(4):
+        i = inputs(s)
+        o0.zero_grad()
+        l = d0.training_losses(m0, i["x"], True, ts=i["ts"], pt=torch.ones(B2, device=dev), noise=i["noise"], drop_mask=i["keep"])["loss"].mean()
+        l.backward()
+        o0.step()
+        l0.append(float(l.detach()))
+    m1, d1, o1 = build()
+    step = DataParallelStep(d1, m1, o1, early_update=True)
+    assert m1.engine.grad_sink is not None and m1.engine.input_grad_first  # the overlapped path is the one under test
+    l1 = []
+    for s in range(4):
+        i = inputs(s)
+        l1.append(float(step(i["x"], True, ts=i["ts"], pt=torch.ones(B2, device=dev), noise=i["noise"], drop_mask=i["keep"])))
+    torch.cuda.synchronize()
+    assert l0 == l1
+    for a, b in zip(m0.parameters(), m1.parameters()):
+        assert torch.equal(a, b)
+        assert torch.equal(o0.state[a]["exp_avg_sq"], o1.state[b]["exp_avg_sq"]) and o0.state[a]["step"] == o1.state[b]["step"]
+    assert torch.equal(d0.Lt_history, d1.Lt_history)
