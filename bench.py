@@ -69,6 +69,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--prof-every", type=int, default=4,
+                    help="bracket the tagged launches of every Nth timed step with HIP events (an event pair keeps the next "
+                         "kernel from starting under the tail of the previous one: every step costs +3 %%, every 4th <1 %%)")
     ap.add_argument("--spmm", action="store_true", help="also time the LightGCN SpMM (reported under 'spmm')")
     ap.add_argument("--fuse-optimizer", action="store_true",
                     help="single GPU: update the two large weights inside the weight-gradient GEMM epilogue "
@@ -168,10 +171,12 @@ def main():
         loss = step(dcsr.rows(row_ids[i % n_pool], out=x_buf), True)
     sync()
     prof = not args.no_prof
-    if prof:
-        lib.gdmcf_prof_enable(1)
+    every = max(1, args.prof_every)
+    n_profiled = len(range(0, args.steps, every)) if prof else 0
     t0 = time.perf_counter()
     for i in range(args.steps):
+        if prof:
+            lib.gdmcf_prof_enable(1 if i % every == 0 else 2)  # 2 = pause, records kept
         loss = step(dcsr.rows(row_ids[i % n_pool], out=x_buf), True)
     sync()
     el = time.perf_counter() - t0
@@ -205,13 +210,13 @@ def main():
             ach, peak, unit, bound = d["work"] / sec / 1e9, PEAK_HBM_GBPS, "GB/s", "hbm"
         e = dict(kernel=TAGS.get(tag, str(tag)), bound=bound, achieved=round(ach, 2), peak=peak, unit=unit,
                  frac=round(ach / peak, 4), avg_ms=round(d["ms"] / d["n"], 4), launches=d["n"],
-                 share_of_step=round(d["ms"] / (el * 1e3), 4), **extra)
+                 share_of_step=round(d["ms"] * args.steps / max(n_profiled, 1) / (el * 1e3), 4), **extra)
         klist.append(e)
     if klist:
         k0 = klist[0]
         roofline = dict(bound=k0["bound"], achieved=k0["achieved"], peak=k0["peak"], unit=k0["unit"], frac=k0["frac"],
                         traffic=measured_traffic(k0["kernel"], args.workload, args.gemm_dtype), kernel=k0["kernel"], avg_ms=k0["avg_ms"],
-                        launches_per_step=k0["launches"] // max(args.steps, 1),
+                        launches_per_step=k0["launches"] // max(n_profiled, 1), profiled_steps=n_profiled,
                         traffic_unit="HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE passes of this "
                                      "command (profiles/r01_final_hbm_traffic.json)",
                         algorithmic_unit=("2*M*N*K FLOP per launch" if k0["bound"] == "mfma" else

@@ -50,8 +50,8 @@ void gd_prof_end(hipStream_t s) {
 extern "C" {
 
 int gdmcf_prof_enable(int on) {
-    g_gd_prof_on = (on != 0);
-    if (!on) g_prof_used = 0;
+    g_gd_prof_on = (on == 1);
+    if (on == 0) g_prof_used = 0;  // 2 = pause: stop recording, keep what was recorded
     return GDMCF_OK;
 }
 

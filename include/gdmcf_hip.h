@@ -45,7 +45,8 @@ int gdmcf_device_info(int* n_cu, int* wave_size, char* arch_host, int arch_len);
  * calls; gdmcf_prof_collect synchronises them and returns (tag, milliseconds, work) triples,
  * where work = algorithmic FLOPs (GEMM tags) or bytes (HBM-bound tags) of that launch.
  * Tags: 1 linear_fwd gemm, 2 loss_fwd gemm, 3 posterior gemm, 4 bwd_input gemm, 5 bwd_weight gemm,
- * 6 adamw, 7 prep_input, 8 spmm, 9 topk.                                                     */
+ * 6 adamw, 7 prep_input, 8 spmm, 9 topk.
+ * on: 1 = record, 2 = pause (stop recording, keep the records), 0 = off and discard.           */
 int gdmcf_prof_enable(int on);
 int gdmcf_prof_collect(int cap, int* tags_host, float* ms_host, double* work_host);
 
