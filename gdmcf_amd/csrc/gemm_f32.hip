@@ -492,7 +492,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GdGemm g) {
 // a global_load_dwordx4 costs the issuing wave ~60 cycles of issue time, 7 per tile = the ~415-cycle per-tile
 // overhead of the all-in-one kernel; in a loader wave that time is off the MFMA waves' critical path.
 // One s_barrier per tile for all eight waves: after it tile t+1 is complete in LDS and tile t's stage is free.
-template <int LAYA, int LAYB, int BM, int BN, int BK, int WAVES_M, int WAVES_N, int EPI>
+template <int LAYA, int LAYB, int BM, int BN, int BK, int WAVES_M, int WAVES_N, int EPI, int NSTG>
 __global__ __launch_bounds__(2 * NTHREADS, 4) void gemm_f32_spec_kernel(const GdGemm g) {
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int TM = WTM / 16, TN = WTN / 16;
@@ -525,51 +525,57 @@ __global__ __launch_bounds__(2 * NTHREADS, 4) void gemm_f32_spec_kernel(const Gd
 #define GD_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 
     if (loader) {
-        TileStage<LAYA, BM, BK> sa0, sa1;
-        TileStage<LAYB, BN, BK> sb0, sb1;
+        // NSTG register stages: the loads of tiles it+1 .. it+NSTG-1 are in flight while tile `it` is computed
+        // (LDS stays double buffered).  Loader waves hold no accumulators, so depth costs only idle VGPRs.
+        TileStage<LAYA, BM, BK> sa[NSTG];
+        TileStage<LAYB, BN, BK> sb[NSTG];
         const bool a_full = (m0 + BM <= g.M), b_full = (n0 + BN <= g.N);
-        if (nt > 0) {
-            sa0.load(g.A, g.lda, m0, g.M, kbeg, kend, kbeg, a_full, tid);
-            sb0.load(g.B, g.ldb, n0, g.N, kbeg, kend, kbeg, b_full, tid);
-            if (nt > 1) {
-                sa1.load(g.A, g.lda, m0, g.M, kbeg + BK, kend, kbeg, a_full, tid);
-                sb1.load(g.B, g.ldb, n0, g.N, kbeg + BK, kend, kbeg, b_full, tid);
-                GD_WAIT_VM(LOADS_PER_TILE);
-            } else {
-                GD_WAIT_VM(0);
+        // wait until every load but those of the `after` youngest tiles has landed (workgroup-uniform switch)
+        auto wait_tiles = [](int after) {
+            constexpr int LPT = GA::NL + GB::NL;
+            switch (after) {
+                case 0: GD_WAIT_VM(0); break;
+                case 1: GD_WAIT_VM(LPT); break;
+                case 2: GD_WAIT_VM(2 * LPT); break;
+                case 3: GD_WAIT_VM(3 * LPT); break;
+                case 4: GD_WAIT_VM(4 * LPT); break;
+                case 5: GD_WAIT_VM(5 * LPT); break;
+                default: GD_WAIT_VM(6 * LPT); break;
             }
-            sa0.pin();
-            sb0.pin();
-            sa0.store(L0, tid);
-            sb0.store(L0 + GA::FLOATS, tid);
+        };
+        static_assert(NSTG >= 2 && NSTG <= 8 && (NSTG - 2) * LOADS_PER_TILE <= 63, "vmcnt is a 6-bit counter");
+#pragma unroll
+        for (int u = 0; u < NSTG - 1; ++u) {
+            if (u < nt) {
+                sa[u].load(g.A, g.lda, m0, g.M, kbeg + u * BK, kend, kbeg, a_full, tid);
+                sb[u].load(g.B, g.ldb, n0, g.N, kbeg + u * BK, kend, kbeg, b_full, tid);
+            }
+        }
+        if (nt > 0) {
+            wait_tiles(min(NSTG - 2, nt - 1));
+            sa[0].pin();
+            sb[0].pin();
+            sa[0].store(L0, tid);
+            sb[0].store(L0 + GA::FLOATS, tid);
         }
         __syncthreads();
-        for (int it = 0; it < nt; it += 2) {
-            const bool ld2 = (it + 2 < nt);
-            if (ld2) {
-                sa0.load(g.A, g.lda, m0, g.M, kbeg + (it + 2) * BK, kend, kbeg, a_full, tid);
-                sb0.load(g.B, g.ldb, n0, g.N, kbeg + (it + 2) * BK, kend, kbeg, b_full, tid);
-            }
-            if (it + 1 < nt) {
-                if (ld2) GD_WAIT_VM(LOADS_PER_TILE); else GD_WAIT_VM(0);
-                sa1.pin();
-                sb1.pin();
-                sa1.store(L1, tid);
-                sb1.store(L1 + GA::FLOATS, tid);
-            }
-            __syncthreads();
-            if (it + 1 < nt) {
-                const bool ld3 = (it + 3 < nt);
-                if (ld3) {
-                    sa1.load(g.A, g.lda, m0, g.M, kbeg + (it + 3) * BK, kend, kbeg, a_full, tid);
-                    sb1.load(g.B, g.ldb, n0, g.N, kbeg + (it + 3) * BK, kend, kbeg, b_full, tid);
+        for (int base = 0; base < nt; base += NSTG) {
+#pragma unroll
+            for (int u = 0; u < NSTG; ++u) {
+                const int it = base + u;  // MFMA waves compute tile `it`; this step makes tile it+1 visible in LDS
+                if (it >= nt) break;
+                const int s_new = (u + NSTG - 1) % NSTG, s_nxt = (u + 1) % NSTG;
+                if (it + NSTG - 1 < nt) {
+                    sa[s_new].load(g.A, g.lda, m0, g.M, kbeg + (it + NSTG - 1) * BK, kend, kbeg, a_full, tid);
+                    sb[s_new].load(g.B, g.ldb, n0, g.N, kbeg + (it + NSTG - 1) * BK, kend, kbeg, b_full, tid);
                 }
-                if (ld2) {
-                    if (ld3) GD_WAIT_VM(LOADS_PER_TILE); else GD_WAIT_VM(0);
-                    sa0.pin();
-                    sb0.pin();
-                    sa0.store(L0, tid);
-                    sb0.store(L0 + GA::FLOATS, tid);
+                if (it + 1 < nt) {
+                    wait_tiles(min(it + NSTG - 1, nt - 1) - (it + 1));
+                    float* Ln = ((it + 1) & 1) ? L1 : L0;
+                    sa[s_nxt].pin();
+                    sb[s_nxt].pin();
+                    sa[s_nxt].store(Ln, tid);
+                    sb[s_nxt].store(Ln + GA::FLOATS, tid);
                 }
                 __syncthreads();
             }
@@ -620,7 +626,13 @@ int launch_one(GdGemm& g, hipStream_t s) {
     const bool spec = SPEC_OK && spec_on;
     void (*kern)(const GdGemm) = gemm_f32_kernel<LAYA, LAYB, BM, BN, BK, WM, WN, EPI>;
     if constexpr (SPEC_OK) {
-        if (spec) kern = gemm_f32_spec_kernel<LAYA, LAYB, BM, BN, BK, WM, WN, EPI>;
+        // register stages of the loader waves: 2 (default) or 4 via GDMCF_SPEC_STAGES; measured 0.260 / 0.262 / 0.257
+        // / 0.272 ms for 2 / 3 / 4 / 6 stages on the Yelp dW products -- the kernel is not load-latency bound
+        static const int nstg = getenv("GDMCF_SPEC_STAGES") ? atoi(getenv("GDMCF_SPEC_STAGES")) : 2;
+        if (spec) {
+            kern = nstg == 4 ? gemm_f32_spec_kernel<LAYA, LAYB, BM, BN, BK, WM, WN, EPI, 4>
+                             : gemm_f32_spec_kernel<LAYA, LAYB, BM, BN, BK, WM, WN, EPI, 2>;
+        }
     }
     static bool attr_set = false;
     if (!attr_set && lds > 48 * 1024) {
