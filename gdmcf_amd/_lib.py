@@ -32,6 +32,10 @@ _SIGNATURES = {
                                          c_uint64, c_int, P, P, c_int, c_int, c_int, P, c_int64, P, c_int64, P, P, P]),
     "gdmcf_dnn_emb_cols_f32": (c_int, [P, P, P, c_int, c_int, c_int, P, c_int64, P, P]),
     "gdmcf_gemm_precision": (c_int, [c_int]),
+    "gdmcf_bf16_shadow_set": (c_int, [P, P, c_int64, c_int64, c_int64]),
+    "gdmcf_bf16_shadow_clear": (c_int, [P]),
+    "gdmcf_bf16_shadow_get": (P, [P]),
+    "gdmcf_bf16_shadow_sync": (c_int, [P, c_int64, P]),
     "gdmcf_linear_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gdmcf_linear_fwd_f32": (c_int, [P, c_int64, P, c_int64, P, c_int, c_int, c_int, c_int, P, c_int64, P, c_size_t, P]),
     "gdmcf_loss_tiles": (c_int, [c_int]),
@@ -114,3 +118,34 @@ def schedule_tables(kind, noise_scale, noise_min, noise_max, steps, beta_fixed=T
                                      int(bool(beta_fixed)), out.ctypes.data_as(c_void_p))
     check(rc)
     return out
+
+
+class Bf16Shadow:
+    """A registered bf16 shadow of a 2-D float32 device tensor (include/gdmcf_hip.h, gdmcf_bf16_shadow_set):
+    zero-padded [round_up(rows, 64)][round_up(cols, 64)] bfloat16 buffer, unregistered when dropped."""
+
+    def __init__(self, t, sync=True):
+        import weakref
+
+        import torch
+        require_gpu(t, "bf16 shadow source")
+        if t.dim() != 2 or t.dtype != torch.float32 or t.stride(1) != 1:
+            raise RuntimeError("gdmcf_amd: a bf16 shadow needs a 2-D float32 tensor with unit column stride")
+        rows, cols = t.shape
+        self.ptr = t.data_ptr()
+        self.ld = t.stride(0)
+        self.buf = torch.zeros((rows + 63) // 64 * 64, (cols + 63) // 64 * 64, dtype=torch.bfloat16, device=t.device)
+        lib = load()
+        check(lib.gdmcf_bf16_shadow_set(self.ptr, self.buf.data_ptr(), rows, cols, self.buf.stride(0)))
+        self._fin = weakref.finalize(self, lib.gdmcf_bf16_shadow_clear, self.ptr)
+        if sync:
+            self.sync()
+
+    def sync(self):
+        check(load().gdmcf_bf16_shadow_sync(self.ptr, self.ld, stream_ptr()))
+
+    def view(self, rows, cols):
+        return self.buf[:rows, :cols]
+
+    def close(self):
+        self._fin()

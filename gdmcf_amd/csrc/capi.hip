@@ -5,6 +5,9 @@
 
 #include <vector>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "common.h"
 
 static thread_local char g_err[512] = "";
@@ -47,7 +50,57 @@ void gd_prof_end(hipStream_t s) {
     ++g_prof_used;
 }
 
+// ---- bf16 shadows ---------------------------------------------------------------------------------------------
+namespace {
+std::mutex g_shadow_mu;
+std::unordered_map<const void*, GdShadow> g_shadows;
+}  // namespace
+
+bool gd_shadow_lookup(const void* f32, GdShadow* out) {
+    if (f32 == nullptr) return false;
+    std::lock_guard<std::mutex> lk(g_shadow_mu);
+    if (g_shadows.empty()) return false;
+    auto it = g_shadows.find(f32);
+    if (it == g_shadows.end()) return false;
+    if (out) *out = it->second;
+    return true;
+}
+
 extern "C" {
+
+int gdmcf_bf16_shadow_set(const float* f32, void* bf16, int64_t rows, int64_t cols, int64_t ld_bf16) {
+    GD_CHECK_ARG(f32 != nullptr && bf16 != nullptr, "bf16_shadow_set: null pointer");
+    GD_CHECK_SHAPE(rows > 0 && cols > 0, "bf16_shadow_set: empty matrix");
+    GD_CHECK_SHAPE(ld_bf16 % 64 == 0 && ld_bf16 >= cols, "bf16_shadow_set: ld_bf16 must be a multiple of 64 and >= cols");
+    GD_CHECK_ARG((reinterpret_cast<uintptr_t>(bf16) & 15u) == 0, "bf16_shadow_set: shadow must be 16-byte aligned");
+    std::lock_guard<std::mutex> lk(g_shadow_mu);
+    g_shadows[f32] = GdShadow{bf16, ld_bf16, rows, cols};
+    return GDMCF_OK;
+}
+
+int gdmcf_bf16_shadow_clear(const float* f32) {
+    std::lock_guard<std::mutex> lk(g_shadow_mu);
+    if (f32 == nullptr)
+        g_shadows.clear();
+    else
+        g_shadows.erase(f32);
+    return GDMCF_OK;
+}
+
+void* gdmcf_bf16_shadow_get(const float* f32) {
+    GdShadow sh;
+    return gd_shadow_lookup(f32, &sh) ? sh.p16 : nullptr;
+}
+
+int gdmcf_bf16_shadow_sync(const float* f32, int64_t ld, void* stream) {
+    GdShadow sh;
+    if (!gd_shadow_lookup(f32, &sh)) {
+        gdmcf_set_error("bf16_shadow_sync: no shadow registered for %p", (const void*)f32);
+        return GDMCF_E_ARG;
+    }
+    GD_CHECK_SHAPE(ld >= sh.cols, "bf16_shadow_sync: ld < cols");
+    return gd_cast_bf16(f32, ld, sh.p16, sh.ld16, sh.rows, sh.cols, (hipStream_t)stream);
+}
 
 int gdmcf_prof_enable(int on) {
     g_gd_prof_on = (on == 1);

@@ -53,6 +53,15 @@ struct GdProfScope {
 static inline int gd_cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline bool gd_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// ---- bf16 shadow registry (capi.hip) ----------------------------------------------------------------------
+struct GdShadow {
+    void* p16;
+    int64_t ld16;
+    int64_t rows, cols;
+};
+bool gd_shadow_lookup(const void* f32, GdShadow* out);
+int gd_cast_bf16(const float* src, int64_t ld, void* dst, int64_t ld16, int64_t rows, int64_t cols, hipStream_t s);
+
 // ---- GEMM core (gemm_f32.hip) -----------------------------------------------------------
 enum { GD_LAY_KC = 0, GD_LAY_MC = 1 };  // operand stored [rows][K] (K contiguous) / [K][rows]
 enum { GD_EPI_SLAB = 0, GD_EPI_BIAS_ACT = 1, GD_EPI_LOSS = 2, GD_EPI_POST = 3, GD_EPI_STORE = 4, GD_EPI_ADAMW = 5 };
@@ -111,6 +120,14 @@ struct GdGemm {
     int accumulate;
     int prof_tag;
     GdAdamHyper adam;  // GD_EPI_ADAMW: C = parameter, aux = exp_avg, aux2 = exp_avg_sq (all [M,N], ldc)
+    // bf16 mode only: bf16 copies ("shadows", gdmcf_bf16_shadow_set) of the operands / of the LOSS epilogue's
+    // result.  When BOTH operand shadows are present the kernel streams them instead of the f32 matrices.
+    const void* A16;
+    int64_t lda16;
+    const void* B16;
+    int64_t ldb16;
+    void* C16;
+    int64_t ldc16;
     int bf16;  // 1: operands rounded to bfloat16 on the way to LDS, bf16 MFMA, f32 accumulate (gemm_bf16.hip)
     int stagger;  // startup delay (x512 clocks) for workgroups in odd wave slots; de-phases co-resident workgroups
 };

@@ -23,6 +23,8 @@
 // fewer L2 bytes per FLOP than 80x128.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "gemm_epilogue.h"
 
@@ -183,7 +185,76 @@ __device__ __forceinline__ void stage_load(Stage<LAY, R, NT>& st, const float* _
         st.load_safe(src, ld, row0, rows_total, k0, kend, tid);
 }
 
-template <int LAYA, int LAYB, int BM, int BN, int WAVES_M, int WAVES_N, int EPI>
+// ---- staging from bf16 shadows (gdmcf_bf16_shadow_set): no conversion, half the bytes ------------------------
+// Shadows are zero outside [rows, cols) up to ld16 (a multiple of 64 columns) and up to the next multiple of 64
+// rows, so neither K tails nor edge tiles need predicates: every load is an unconditional 16-byte load.
+template <int LAY, int R, int NT>
+struct Stage16;
+
+template <int R, int NT>
+struct Stage16<GD_LAY_KC, R, NT> {
+    static constexpr int UNITS = R * 8;  // (row, 16-byte segment = 8 bf16)
+    static constexpr int NL = (UNITS + NT - 1) / NT;
+    u32x4 reg[NL];
+    __device__ __forceinline__ void load(const unsigned short* __restrict__ src, int64_t ld, int row0, int rows_total,
+                                         int k0, int tid) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int u = tid + i * NT;
+            const int row = min(row0 + min(u >> 3, R - 1), rows_total - 1);
+            reg[i] = *reinterpret_cast<const u32x4*>(src + (int64_t)row * ld + k0 + ((u & 7) << 3));
+        }
+    }
+    __device__ __forceinline__ void store(char* img, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int u = tid + i * NT;
+            if (UNITS % NT != 0 && u >= UNITS) continue;
+            *reinterpret_cast<u32x4*>(img + img_off(u >> 3, u & 7)) = reg[i];
+        }
+    }
+};
+
+template <int R, int NT>
+struct Stage16<GD_LAY_MC, R, NT> {
+    static constexpr int UNITS = R;  // (8-row group, 8-deep k group): R/8 * 8
+    static constexpr int NL = (UNITS + NT - 1) / NT;
+    u32x4 reg[NL][8];
+    __device__ __forceinline__ void load(const unsigned short* __restrict__ src, int64_t ld, int row0, int rows_total,
+                                         int k0, int tid) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int u = tid + i * NT;
+            const int kg = u & 7, rg = min(u >> 3, R / 8 - 1);
+            const int col = min(row0 + (rg << 3), (int)ld - 8);  // groups beyond the matrix read padding of this row
+            const unsigned short* p = src + (int64_t)(k0 + (kg << 3)) * ld + col;
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) reg[i][kk] = *reinterpret_cast<const u32x4*>(p + (int64_t)kk * ld);
+        }
+    }
+    // 8x8 transpose of 16-bit values: image row (rg*8 + mm) slot kg holds k = kg*8 .. kg*8+7 of source row mm
+    __device__ __forceinline__ void store(char* img, int tid) const {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int u = tid + i * NT;
+            if (UNITS % NT != 0 && u >= UNITS) continue;
+            const int kg = u & 7, rg = u >> 3;
+#pragma unroll
+            for (int mm = 0; mm < 8; ++mm) {
+                const int d = mm >> 1;
+                const unsigned sel = (mm & 1) ? 0x07060302u : 0x05040100u;
+                u32x4 w;
+                w.x = __builtin_amdgcn_perm(reg[i][1][d], reg[i][0][d], sel);
+                w.y = __builtin_amdgcn_perm(reg[i][3][d], reg[i][2][d], sel);
+                w.z = __builtin_amdgcn_perm(reg[i][5][d], reg[i][4][d], sel);
+                w.w = __builtin_amdgcn_perm(reg[i][7][d], reg[i][6][d], sel);
+                *reinterpret_cast<u32x4*>(img + img_off((rg << 3) + mm, kg)) = w;
+            }
+        }
+    }
+};
+
+template <int LAYA, int LAYB, int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool S16>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(const GdGemm g) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
@@ -217,23 +288,36 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(const
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    Stage<LAYA, BM, NT> sa;
-    Stage<LAYB, BN, NT> sb;
+    typename std::conditional<S16, Stage16<LAYA, BM, NT>, Stage<LAYA, BM, NT>>::type sa;
+    typename std::conditional<S16, Stage16<LAYB, BN, NT>, Stage<LAYB, BN, NT>>::type sb;
+    auto load_tile = [&](int k0) {
+        if constexpr (S16) {
+            sa.load(static_cast<const unsigned short*>(g.A16), g.lda16, m0, g.M, k0, tid);
+            sb.load(static_cast<const unsigned short*>(g.B16), g.ldb16, n0, g.N, k0, tid);
+        } else {
+            stage_load(sa, g.A, g.lda, m0, g.M, k0, kend, tid);
+            stage_load(sb, g.B, g.ldb, n0, g.N, k0, kend, tid);
+        }
+    };
+    auto store_tile = [&](char* img, int k0) {
+        if constexpr (S16) {
+            sa.store(img, tid);
+            sb.store(img + A_BYTES, tid);
+        } else {
+            sa.store(img, k0, kend, tid);
+            sb.store(img + A_BYTES, k0, kend, tid);
+        }
+    };
     if (nt > 0) {
-        stage_load(sa, g.A, g.lda, m0, g.M, kbeg, kend, tid);
-        stage_load(sb, g.B, g.ldb, n0, g.N, kbeg, kend, tid);
-        sa.store(lds, kbeg, kend, tid);
-        sb.store(lds + A_BYTES, kbeg, kend, tid);
+        load_tile(kbeg);
+        store_tile(lds, kbeg);
     }
     __syncthreads();
     for (int it = 0; it < nt; ++it) {
         const char* cur = lds + (it & 1) * STAGE_BYTES;
         char* nxt = lds + ((it + 1) & 1) * STAGE_BYTES;
         const bool more = it + 1 < nt;
-        if (more) {
-            stage_load(sa, g.A, g.lda, m0, g.M, kbeg + (it + 1) * BK, kend, tid);
-            stage_load(sb, g.B, g.ldb, n0, g.N, kbeg + (it + 1) * BK, kend, tid);
-        }
+        if (more) load_tile(kbeg + (it + 1) * BK);
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             bf16x8 fa[TM], fb[TN];
@@ -249,19 +333,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(const
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
-        if (more) {
-            sa.store(nxt, kbeg + (it + 1) * BK, kend, tid);
-            sb.store(nxt + A_BYTES, kbeg + (it + 1) * BK, kend, tid);
-        }
+        if (more) store_tile(nxt, kbeg + (it + 1) * BK);
         __syncthreads();
     }
     gemm_epilogue<BM, TM, TN, WAVES_N, EPI>(acc, g, m0, n0, wm0, wn0, r, q, split, tile_n, wave, tid, smem);
 }
 
-template <int LAYA, int LAYB, int BM, int BN, int WM, int WN, int EPI>
+template <int LAYA, int LAYB, int BM, int BN, int WM, int WN, int EPI, bool S16>
 int launch_one(GdGemm& g, hipStream_t s) {
     constexpr size_t lds = 2 * (size_t)(BM + BN) * 128;
-    auto kern = gemm_bf16_kernel<LAYA, LAYB, BM, BN, WM, WN, EPI>;
+    auto kern = gemm_bf16_kernel<LAYA, LAYB, BM, BN, WM, WN, EPI, S16>;
     static bool attr_set = false;
     if (!attr_set && lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -290,11 +371,15 @@ int launch_one(GdGemm& g, hipStream_t s) {
 
 template <int LAYA, int LAYB, int EPI>
 int launch_class(int cls, GdGemm& g, hipStream_t s) {
+    // operands come from their bf16 shadows when both have one (classes 1 and 3: the ones the training step uses)
+    const bool s16 = g.A16 != nullptr && g.B16 != nullptr;
     switch (cls) {
-        case 0: return launch_one<LAYA, LAYB, 80, 128, 1, 4, EPI>(g, s);
-        case 1: return launch_one<LAYA, LAYB, 128, 128, 2, 2, EPI>(g, s);
-        case 2: return launch_one<LAYA, LAYB, 64, 64, 2, 2, EPI>(g, s);
-        case 3: return launch_one<LAYA, LAYB, 208, 256, 1, 8, EPI>(g, s);
+        case 0: return launch_one<LAYA, LAYB, 80, 128, 1, 4, EPI, false>(g, s);
+        case 1: return s16 ? launch_one<LAYA, LAYB, 128, 128, 2, 2, EPI, true>(g, s)
+                           : launch_one<LAYA, LAYB, 128, 128, 2, 2, EPI, false>(g, s);
+        case 2: return launch_one<LAYA, LAYB, 64, 64, 2, 2, EPI, false>(g, s);
+        case 3: return s16 ? launch_one<LAYA, LAYB, 208, 256, 1, 8, EPI, true>(g, s)
+                           : launch_one<LAYA, LAYB, 208, 256, 1, 8, EPI, false>(g, s);
     }
     gdmcf_set_error("bad gemm shape class %d", cls);
     return GDMCF_E_ARG;

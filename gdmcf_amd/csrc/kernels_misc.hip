@@ -701,3 +701,42 @@ int gd_rowpart_reduce(const float* rowpart, int ld, int M, int nt, float* rowsum
     hipLaunchKernelGGL(rowpart_reduce_kernel, dim3(gd_cdiv(M, 4)), dim3(256), 0, s, rowpart, ld, M, nt, rowsum);
     return gd_launch_status("rowpart_reduce");
 }
+
+// ---- f32 -> bf16 shadow copy (gdmcf_bf16_shadow_sync; weights whose values changed outside the library) -------
+namespace {
+typedef __bf16 gd_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned gd_pack_bf16(float lo, float hi) {
+    gd_bf16x2 v;
+    v[0] = (__bf16)lo;
+    v[1] = (__bf16)hi;
+    return __builtin_bit_cast(unsigned, v);
+}
+typedef unsigned int gd_u32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ src, int64_t ld, unsigned short* __restrict__ dst,
+                                                        int64_t ld16, int64_t rows, int64_t cols) {
+    const int64_t groups = (cols + 7) / 8;  // 8 columns = one 16-byte store
+    const int64_t total = rows * groups;
+    for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < total; u += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = u / groups, c = (u - r * groups) * 8;
+        const float* p = src + r * ld + c;
+        float e[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) e[i] = (c + i < cols) ? p[i] : 0.f;
+        gd_u32x4 w;
+        w.x = gd_pack_bf16(e[0], e[1]);
+        w.y = gd_pack_bf16(e[2], e[3]);
+        w.z = gd_pack_bf16(e[4], e[5]);
+        w.w = gd_pack_bf16(e[6], e[7]);
+        *reinterpret_cast<gd_u32x4*>(dst + r * ld16 + c) = w;
+    }
+}
+}  // namespace
+
+int gd_cast_bf16(const float* src, int64_t ld, void* dst, int64_t ld16, int64_t rows, int64_t cols, hipStream_t s) {
+    const int64_t total = rows * ((cols + 7) / 8);
+    const int64_t blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, s, src, ld,
+                       (unsigned short*)dst, ld16, rows, cols);
+    return gd_launch_status("cast_bf16");
+}

@@ -45,6 +45,19 @@ int pick_class_dw(int M, int N, int prec) {
     return gd_pick_shape_class(M, N);
 }
 
+// bf16 mode: stream the operands from their registered bf16 shadows when both have one of exactly this shape
+// (operand stored [rows][K] for GD_LAY_KC, [K][rows] for GD_LAY_MC)
+void attach_shadows(GdGemm& g, int layA, int layB) {
+    if (!g.bf16) return;
+    GdShadow a, b;
+    if (!gd_shadow_lookup(g.A, &a) || !gd_shadow_lookup(g.B, &b)) return;
+    const bool okA = layA == GD_LAY_KC ? (a.rows == g.M && a.cols == g.K) : (a.rows == g.K && a.cols == g.M);
+    const bool okB = layB == GD_LAY_KC ? (b.rows == g.N && b.cols == g.K) : (b.rows == g.K && b.cols == g.N);
+    if (!okA || !okB) return;
+    g.A16 = a.p16; g.lda16 = a.ld16;
+    g.B16 = b.p16; g.ldb16 = b.ld16;
+}
+
 // number of K splits for an [M,N,K] product whose output is small (batch x hidden)
 int pick_splits(int M, int N, int K, int cls, int prec) {
     const int bk = prec == GDMCF_GEMM_BF16 ? 64 : 32;
@@ -100,6 +113,7 @@ int gdmcf_linear_fwd_f32(const float* A, int64_t lda, const float* W, int64_t ld
     g.bias = bias; g.act = act; g.prof_tag = 1;
     if (splits == 1) {
         g.splits = 1; g.C = C; g.ldc = ldc;
+        attach_shadows(g, GD_LAY_KC, GD_LAY_KC);
         return gd_gemm_launch(GD_LAY_KC, GD_LAY_KC, GD_EPI_BIAS_ACT, cls, g, s);
     }
     const int64_t lds_ = round4(N);
@@ -109,6 +123,7 @@ int gdmcf_linear_fwd_f32(const float* A, int64_t lda, const float* W, int64_t ld
         return GDMCF_E_WORKSPACE;
     }
     g.splits = splits; g.C = (float*)ws; g.ldc = lds_; g.slab_stride = (int64_t)M * lds_;
+    attach_shadows(g, GD_LAY_KC, GD_LAY_KC);
     int rc = gd_gemm_launch(GD_LAY_KC, GD_LAY_KC, GD_EPI_SLAB, cls, g, s);
     if (rc) return rc;
     const int real_splits = gd_cdiv(K, g.kchunk);
@@ -130,6 +145,7 @@ int gdmcf_linear_loss_fwd_f32(const float* A, int64_t lda, const float* W, int64
     g.bias = bias; g.aux = target; g.ldaux = ldt; g.r0 = alpha; g.out2 = out; g.ldout2 = ldo;
     g.prof_tag = 2;
     g.C = diff; g.ldc = ldd; g.rowpart = rowpart; g.ld_rowpart = gdmcf_loss_tiles(N);
+    attach_shadows(g, GD_LAY_KC, GD_LAY_KC);
     int rc = gd_gemm_launch(GD_LAY_KC, GD_LAY_KC, GD_EPI_LOSS, cls, g, s);
     if (rc) return rc;
     return gd_rowpart_reduce(rowpart, g.ld_rowpart, M, g.tiles_n, rowsum, s);
@@ -152,6 +168,7 @@ int gdmcf_linear_posterior_fwd_f32(const float* A, int64_t lda, const float* W, 
     g.bias = bias; g.aux = x_t; g.ldaux = ldxt; g.aux2 = z; g.ldaux2 = ldz;
     g.r0 = c1; g.r1 = c2; g.r2 = r1; g.r3 = r2; g.r4 = sigma;
     g.out2 = pred_out; g.ldout2 = ldp; g.C = x_next; g.ldc = ldxn; g.prof_tag = 3;
+    attach_shadows(g, GD_LAY_KC, GD_LAY_KC);
     return gd_gemm_launch(GD_LAY_KC, GD_LAY_KC, GD_EPI_POST, cls, g, s);
 }
 
@@ -175,6 +192,7 @@ int gdmcf_linear_bwd_input_f32(const float* dZ, int64_t lddz, const float* W, in
     g.A = dZ; g.lda = lddz; g.B = W; g.ldb = ldw; g.M = M; g.N = K; g.K = N;
     g.m_fastest = gd_cdiv(M, gd_gemm_tile_m(cls)) <= gd_cdiv(K, gd_gemm_tile_n(cls));
     g.splits = splits; g.C = (float*)ws; g.ldc = lds_; g.slab_stride = (int64_t)M * lds_; g.prof_tag = 4;
+    attach_shadows(g, GD_LAY_KC, GD_LAY_MC);
     int rc = gd_gemm_launch(GD_LAY_KC, GD_LAY_MC, GD_EPI_SLAB, cls, g, s);
     if (rc) return rc;
     const int real_splits = gd_cdiv(N, g.kchunk);
@@ -194,6 +212,7 @@ int gdmcf_linear_bwd_weight_f32(const float* dZ, int64_t lddz, const float* A, i
     g.A = dZ; g.lda = lddz; g.B = A; g.ldb = lda; g.M = N; g.N = K; g.K = M; g.splits = 1;
     g.m_fastest = gd_cdiv(N, gd_gemm_tile_m(cls)) <= gd_cdiv(K, gd_gemm_tile_n(cls));
     g.C = dW; g.ldc = lddw; g.accumulate = accumulate; g.prof_tag = 5;
+    attach_shadows(g, GD_LAY_MC, GD_LAY_MC);
     int rc = gd_gemm_launch(GD_LAY_MC, GD_LAY_MC, GD_EPI_STORE, cls, g, s);
     if (rc) return rc;
     if (db) return gd_colsum(dZ, lddz, rowscale, M, N, db, s);
@@ -214,6 +233,7 @@ int gdmcf_linear_bwd_weight_adamw_f32(const float* dZ, int64_t lddz, const float
     g.m_fastest = gd_cdiv(N, gd_gemm_tile_m(cls)) <= gd_cdiv(K, gd_gemm_tile_n(cls));
     g.C = W; g.ldc = ldw; g.aux = exp_avg; g.aux2 = exp_avg_sq; g.prof_tag = 5;
     g.adam = gd_adam_hyper(lr, beta1, beta2, eps, weight_decay, step, grad_scale);
+    attach_shadows(g, GD_LAY_MC, GD_LAY_MC);
     int rc = gd_gemm_launch(GD_LAY_MC, GD_LAY_MC, GD_EPI_ADAMW, cls, g, s);
     if (rc) return rc;
     if (db) return gd_colsum(dZ, lddz, rowscale, M, N, db, s);

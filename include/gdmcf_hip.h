@@ -113,6 +113,19 @@ int gdmcf_dnn_emb_cols_f32(const int64_t* ts, const float* emb_w, const float* e
  * with torch.autocast(dtype=torch.bfloat16) around models/DNN.py:79-86 -- the reference itself runs fp32.    */
 enum { GDMCF_GEMM_F32 = 0, GDMCF_GEMM_BF16 = 1 };
 int gdmcf_gemm_precision(int mode);
+/* bf16 shadows (GDMCF_GEMM_BF16 only): a shadow is a bfloat16 copy of a float32 matrix that the library may
+ * stream INSTEAD of the float32 matrix when that matrix is an operand of a dense product (half the bytes, no
+ * conversion on chip), and that every library kernel WRITING the float32 matrix keeps up to date (the input
+ * builder, the split-K reducers, the fused-loss epilogue, gdmcf_rowscale_f32, gdmcf_adamw_f32 via its table).
+ * The float32 matrix stays authoritative; a shadow whose float32 matrix was written by anything else must be
+ * refreshed with gdmcf_bf16_shadow_sync.  Layout: [round_up(rows, 64)][ld_bf16] bfloat16, ld_bf16 a multiple of 64
+ * and >= cols, 16-byte aligned, ZERO outside [rows, cols) (the kernels rely on the zero padding instead of edge
+ * predicates).  The registry is keyed by the float32 base pointer and global to the process: clear an entry
+ * before its buffers are freed.  A product uses shadows only when BOTH operands have one of exactly its shape. */
+int gdmcf_bf16_shadow_set(const float* f32, void* bf16, int64_t rows, int64_t cols, int64_t ld_bf16);
+int gdmcf_bf16_shadow_clear(const float* f32 /* NULL: all */);
+void* gdmcf_bf16_shadow_get(const float* f32);
+int gdmcf_bf16_shadow_sync(const float* f32, int64_t ld, void* stream);
 size_t gdmcf_linear_ws_bytes(int M, int N, int K);
 /* C[M,N] = act(A[M,K] @ W[N,K]^T + bias) */
 int gdmcf_linear_fwd_f32(const float* A, int64_t lda, const float* W, int64_t ldw,

@@ -616,7 +616,7 @@ def test_lightgcn_bpr_step_gradients_match_oracle():
     assert np.mean(losses[-5:]) < np.mean(losses[:5])
 
 
-@pytest.mark.parametrize("prec", ["f32", "bf16"])
+@pytest.mark.parametrize("prec", ["f32", "bf16", "bf16-shadows"])
 def test_linear_entry_points_random_shapes(prec):
     """Adversarial shapes for the branch-free edge loaders (clamped addresses, in-register shifts, K tails,
     odd leading dimensions, split-K on/off): every dense entry point of the C ABI vs float64 matmul.
@@ -624,14 +624,17 @@ def test_linear_entry_points_random_shapes(prec):
     bf16 x bf16 products are exact in f32, so the only difference left is f32 accumulation order."""
     from gdmcf_amd import _lib
     lib = _lib.load()
-    prev = lib.gdmcf_gemm_precision(1 if prec == "bf16" else 0)
+    prev = lib.gdmcf_gemm_precision(0 if prec == "f32" else 1)
     try:
-        _linear_entry_points_random_shapes(lib, prec)
+        _linear_entry_points_random_shapes(lib, "bf16" if prec != "f32" else "f32", shadows=(prec == "bf16-shadows"))
     finally:
         lib.gdmcf_gemm_precision(prev)
+        lib.gdmcf_bf16_shadow_clear(None)
 
 
-def _linear_entry_points_random_shapes(lib, prec):
+def _linear_entry_points_random_shapes(lib, prec, shadows=False):
+    """shadows=True: every operand gets a registered bf16 shadow (the kernels then stream those, no edge predicates,
+    zero padding) -- same reference, same tolerance."""
     from gdmcf_amd import _lib
     D = (lambda t: t.bfloat16().double()) if prec == "bf16" else (lambda t: t.double())
     rng = np.random.default_rng(0)
@@ -640,12 +643,17 @@ def _linear_entry_points_random_shapes(lib, prec):
               (7, 1000, 515), (129, 70, 4099), (65, 64, 8195), (33, 300, 31), (5, 6, 20000)]
     if prec == "bf16":  # any K works there; the last four take the 208x256 tile class (fused epilogues and weight gradients included)
         shapes += [(2, 3, 3), (5, 2, 130), (200, 300, 515), (413, 1000, 700), (400, 28001, 70), (64, 1100, 28000)]
+    keep = []
     for (M, N, K) in shapes:
         for pad in (0, 3):
             lda, ldw, ldc = K + pad, K + (1 if pad else 0), N + pad
             A = torch.zeros(M, lda, device=DEV); A[:, :K] = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float32)).to(DEV)
             W = torch.zeros(N, ldw, device=DEV); W[:, :K] = torch.from_numpy((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)).to(DEV)
             bias = torch.from_numpy(rng.standard_normal(N).astype(np.float32)).to(DEV)
+            for sh in keep:  # unregister before the allocator can hand the same addresses to new tensors
+                sh.close()
+            keep = [_lib.Bf16Shadow(A[:, :K]), _lib.Bf16Shadow(W[:, :K])] if shadows else []
+            assert not shadows or lib.gdmcf_bf16_shadow_get(A.data_ptr()) == keep[0].buf.data_ptr()
             ref = D(A[:, :K]) @ D(W[:, :K]).T + bias.double()
             close = lambda got, want: float((got - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
             ws_bytes = int(lib.gdmcf_linear_ws_bytes(M, N, K))
@@ -674,6 +682,8 @@ def _linear_entry_points_random_shapes(lib, prec):
             rs = torch.from_numpy(rng.uniform(0.5, 1.5, M).astype(np.float32)).to(DEV)
             act = torch.zeros(M, lda, device=DEV); act[:, :K] = torch.from_numpy(rng.uniform(-0.9, 0.9, (M, K)).astype(np.float32)).to(DEV)
             dA = torch.full((M, lda), float("nan"), device=DEV)
+            if shadows:
+                keep.append(_lib.Bf16Shadow(dZ[:, :N]))
             if (N >= 4 and K >= 4) or prec == "bf16":
                 _lib.check(lib.gdmcf_linear_bwd_input_f32(dZ.data_ptr(), ldc, W.data_ptr(), ldw, rs.data_ptr(), act.data_ptr(), lda, 1,
                                                           M, N, K, dA.data_ptr(), lda, ws.data_ptr(), ws_bytes, st))
