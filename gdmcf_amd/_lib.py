@@ -35,6 +35,7 @@ _SIGNATURES = {
     "gdmcf_bf16_shadow_set": (c_int, [P, P, c_int64, c_int64, c_int64]),
     "gdmcf_bf16_shadow_clear": (c_int, [P]),
     "gdmcf_bf16_shadow_get": (P, [P]),
+    "gdmcf_bf16_shadow_info": (c_int, [P, P, P, P, P]),
     "gdmcf_bf16_shadow_sync": (c_int, [P, c_int64, P]),
     "gdmcf_linear_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gdmcf_linear_fwd_f32": (c_int, [P, c_int64, P, c_int64, P, c_int, c_int, c_int, c_int, P, c_int64, P, c_size_t, P]),
@@ -54,6 +55,7 @@ _SIGNATURES = {
     "gdmcf_lt_history_update": (c_int, [P, P, c_int, c_int, c_int, P, P, P]),
     "gdmcf_sample_timesteps": (c_int, [P, P, c_int, c_int, c_int, c_double, c_uint64, c_uint64, P, P, P, P]),
     "gdmcf_adamw_f32": (c_int, [P, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_int, c_float, P]),
+    "gdmcf_adamw_bf16s_f32": (c_int, [P, P, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_int, c_float, P]),
     "gdmcf_topk_masked_f32": (c_int, [P, c_int64, c_int, c_int, P, P, c_int, P, P, P]),
     "gdmcf_spmm_csr_f32": (c_int, [P, P, P, P, c_int, c_int, P, P, c_int, P, P, c_int, P, c_int64, c_int, P, c_int64, P, P, c_int,
                                    c_int64, c_float, c_double, P]),
@@ -105,6 +107,15 @@ def require_gpu(t, what):
                            "the HIP path has no CPU fallback")
 
 
+def shadow_info(data_ptr):
+    """(bf16 pointer, rows, cols, ld) of the registered bf16 shadow of a float32 base pointer, or None."""
+    p16 = ctypes.c_void_p()
+    rows, cols, ld = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+    if not load().gdmcf_bf16_shadow_info(data_ptr, ctypes.byref(p16), ctypes.byref(rows), ctypes.byref(cols), ctypes.byref(ld)):
+        return None
+    return int(p16.value), int(rows.value), int(cols.value), int(ld.value)
+
+
 def stream_ptr():
     import torch
     return torch.cuda.current_stream().cuda_stream
@@ -121,8 +132,10 @@ def schedule_tables(kind, noise_scale, noise_min, noise_max, steps, beta_fixed=T
 
 
 class Bf16Shadow:
-    """A registered bf16 shadow of a 2-D float32 device tensor (include/gdmcf_hip.h, gdmcf_bf16_shadow_set):
-    zero-padded [round_up(rows, 64)][round_up(cols, 64)] bfloat16 buffer, unregistered when dropped."""
+    """A bf16 shadow of a 2-D float32 device tensor (include/gdmcf_hip.h, gdmcf_bf16_shadow_set): zero-padded
+    [round_up(rows, 64)][round_up(cols, 64)] bfloat16 buffer.  Registered on construction; `unregister()` /
+    `register()` bracket code that writes the float32 tensor with kernels that do not maintain shadows; the
+    registration is dropped with the object."""
 
     def __init__(self, t, sync=True):
         import weakref
@@ -131,21 +144,26 @@ class Bf16Shadow:
         require_gpu(t, "bf16 shadow source")
         if t.dim() != 2 or t.dtype != torch.float32 or t.stride(1) != 1:
             raise RuntimeError("gdmcf_amd: a bf16 shadow needs a 2-D float32 tensor with unit column stride")
-        rows, cols = t.shape
+        self.rows, self.cols = t.shape
         self.ptr = t.data_ptr()
         self.ld = t.stride(0)
-        self.buf = torch.zeros((rows + 63) // 64 * 64, (cols + 63) // 64 * 64, dtype=torch.bfloat16, device=t.device)
-        lib = load()
-        check(lib.gdmcf_bf16_shadow_set(self.ptr, self.buf.data_ptr(), rows, cols, self.buf.stride(0)))
-        self._fin = weakref.finalize(self, lib.gdmcf_bf16_shadow_clear, self.ptr)
+        self.buf = torch.zeros((self.rows + 63) // 64 * 64, (self.cols + 63) // 64 * 64, dtype=torch.bfloat16,
+                               device=t.device)
+        self._lib = load()
+        self._fin = weakref.finalize(self, self._lib.gdmcf_bf16_shadow_clear, self.ptr)
+        self.register()
         if sync:
             self.sync()
 
-    def sync(self):
-        check(load().gdmcf_bf16_shadow_sync(self.ptr, self.ld, stream_ptr()))
+    def register(self):
+        check(self._lib.gdmcf_bf16_shadow_set(self.ptr, self.buf.data_ptr(), self.rows, self.cols, self.buf.stride(0)))
 
-    def view(self, rows, cols):
-        return self.buf[:rows, :cols]
+    def unregister(self):
+        self._lib.gdmcf_bf16_shadow_clear(self.ptr)
+
+    def sync(self):
+        """Refresh the shadow from the float32 tensor (needed after anything but a gdmcf kernel wrote it)."""
+        check(self._lib.gdmcf_bf16_shadow_sync(self.ptr, self.ld, stream_ptr()))
 
     def close(self):
         self._fin()

@@ -92,6 +92,16 @@ void* gdmcf_bf16_shadow_get(const float* f32) {
     return gd_shadow_lookup(f32, &sh) ? sh.p16 : nullptr;
 }
 
+int gdmcf_bf16_shadow_info(const float* f32, void** bf16, int64_t* rows, int64_t* cols, int64_t* ld_bf16) {
+    GdShadow sh;
+    if (!gd_shadow_lookup(f32, &sh)) return 0;
+    if (bf16) *bf16 = sh.p16;
+    if (rows) *rows = sh.rows;
+    if (cols) *cols = sh.cols;
+    if (ld_bf16) *ld_bf16 = sh.ld16;
+    return 1;
+}
+
 int gdmcf_bf16_shadow_sync(const float* f32, int64_t ld, void* stream) {
     GdShadow sh;
     if (!gd_shadow_lookup(f32, &sh)) {

@@ -8,6 +8,12 @@ namespace {
 
 __device__ __forceinline__ float gd_tanh(float x) { return tanhf(x); }
 
+// float -> bfloat16 bits, round to nearest even (bf16 shadow of a result, GdGemm::C16)
+__device__ __forceinline__ unsigned short gd_epi_bf16(float x) {
+    __bf16 h = (__bf16)x;
+    return __builtin_bit_cast(unsigned short, h);
+}
+
 // ---- epilogue (shared by the plain and the wave-specialised kernel) ---------------------------------------
 template <int BM, int TM, int TN, int WAVES_N, int EPI>
 __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GdGemm& g, int m0, int n0, int wm0, int wn0,
@@ -83,6 +89,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GdGemm
                             v += biasv[j];
                             if (g.act == 1) v = gd_tanh(v);
                             g.C[(int64_t)m * g.ldc + ncl[j]] = v;
+                            if (g.C16) static_cast<unsigned short*>(g.C16)[(int64_t)m * g.ldc16 + ncl[j]] = gd_epi_bf16(v);
                         }
                     }
                 }
@@ -132,6 +139,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GdGemm
                         if (ok) {
                             if (g.out2) g.out2[(int64_t)m * g.ldout2 + ncl[j]] = v;
                             g.C[(int64_t)m * g.ldc + ncl[j]] = d;
+                            if (g.C16) static_cast<unsigned short*>(g.C16)[(int64_t)m * g.ldc16 + ncl[j]] = gd_epi_bf16(d);
                             racc += d * d;
                         }
                     } else {

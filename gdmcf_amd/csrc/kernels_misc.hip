@@ -34,6 +34,12 @@ __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& z0, fl
     z1 = rad * s;
 }
 
+// round-to-nearest-even float -> bfloat16 bits (v_cvt_pk_bf16_f32), for the bf16 shadow copies
+__device__ __forceinline__ unsigned short gd_bf16_bits(float x) {
+    __bf16 h = (__bf16)x;
+    return __builtin_bit_cast(unsigned short, h);
+}
+
 struct PrepArgs {
     const float* x;
     int64_t ldx;
@@ -58,6 +64,8 @@ struct PrepArgs {
     float* xt_out;
     int64_t ldxt;
     float* temb_out;
+    unsigned short* xin16;  // bf16 shadow of xin (or NULL), row stride ldxin16 (a multiple of 64 >= I+E)
+    int64_t ldxin16;
 };
 
 __device__ __forceinline__ float temb_value(float t, int f, int E) {
@@ -174,6 +182,11 @@ __global__ __launch_bounds__(256) void prep_input_kernel(const PrepArgs a) {
         }
     }
     *reinterpret_cast<f32x4*>(a.xin + (int64_t)b * a.ldxin + col) = f32x4{v[0], v[1], v[2], v[3]};
+    if (a.xin16 && col < a.ldxin16) {
+        const uint2 w = make_uint2(gd_bf16_bits(v[0]) | ((unsigned)gd_bf16_bits(v[1]) << 16),
+                                   gd_bf16_bits(v[2]) | ((unsigned)gd_bf16_bits(v[3]) << 16));
+        *reinterpret_cast<uint2*>(a.xin16 + (int64_t)b * a.ldxin16 + col) = w;
+    }
 }
 
 __global__ void emb_cols_kernel(const int64_t* __restrict__ ts, const float* __restrict__ emb_w,
@@ -202,7 +215,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
                                                             const float* __restrict__ bias,
                                                             const float* __restrict__ rowscale,
                                                             const float* __restrict__ aact, int64_t ldact, int act,
-                                                            float* __restrict__ out, int64_t ldo) {
+                                                            float* __restrict__ out, int64_t ldo,
+                                                            unsigned short* __restrict__ out16, int64_t ldo16) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= (int64_t)M * N) return;
     const int m = (int)(e / N), n = (int)(e % N);
@@ -219,15 +233,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         }
     }
     out[(int64_t)m * ldo + n] = s;
+    if (out16) out16[(int64_t)m * ldo16 + n] = gd_bf16_bits(s);
 }
 
 __global__ __launch_bounds__(256) void rowscale_kernel(const float* __restrict__ A, int64_t lda,
                                                        const float* __restrict__ rs, int M, int K,
-                                                       float* __restrict__ out, int64_t ldo) {
+                                                       float* __restrict__ out, int64_t ldo,
+                                                       unsigned short* __restrict__ out16, int64_t ldo16) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= (int64_t)M * K) return;
     const int m = (int)(e / K), k = (int)(e % K);
-    out[(int64_t)m * ldo + k] = A[(int64_t)m * lda + k] * rs[m];
+    const float v = A[(int64_t)m * lda + k] * rs[m];
+    out[(int64_t)m * ldo + k] = v;
+    if (out16) out16[(int64_t)m * ldo16 + k] = gd_bf16_bits(v);
 }
 
 // db[n] = sum_m rs[m]*dZ[m,n].  One workgroup per 64 columns; wave w sums rows w, w+4, ... (each row read
@@ -462,8 +480,10 @@ constexpr int ADAM_BLOCK_ELEMS = 4096;
 typedef GdAdamHyper AdamHyper;
 #define adam_elem gd_adam_elem
 
+// stab (optional): [n][3] = (bf16 shadow pointer or 0, columns, shadow row stride) -- the updated parameter is also
+// stored, rounded to bfloat16, into its zero-padded 2-D shadow (gdmcf_bf16_shadow_set)
 __global__ __launch_bounds__(256) void adamw_kernel(const int64_t* __restrict__ table, int n_tensors,
-                                                    const AdamHyper h) {
+                                                    const AdamHyper h, const int64_t* __restrict__ stab) {
     int t = 0;
     for (int i = 1; i < n_tensors; ++i)
         if ((int64_t)blockIdx.x >= table[i * 6 + 5]) t = i;
@@ -475,6 +495,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(const int64_t* __restrict__ 
     const int64_t base = ((int64_t)blockIdx.x - table[t * 6 + 5]) * ADAM_BLOCK_ELEMS;
     const bool al = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
                       reinterpret_cast<uintptr_t>(v)) & 15u) == 0;
+    unsigned short* p16 = stab ? reinterpret_cast<unsigned short*>(stab[t * 3 + 0]) : nullptr;
+    const unsigned cols16 = p16 ? (unsigned)stab[t * 3 + 1] : 1u;
+    const int64_t ld16 = p16 ? stab[t * 3 + 2] : 0;
 #pragma unroll
     for (int it = 0; it < ADAM_BLOCK_ELEMS / (256 * 4); ++it) {
         const int64_t i = base + (int64_t)(it * 256 + threadIdx.x) * 4;
@@ -494,9 +517,35 @@ __global__ __launch_bounds__(256) void adamw_kernel(const int64_t* __restrict__ 
             *reinterpret_cast<f32x4*>(p + i) = pp;
             *reinterpret_cast<f32x4*>(m + i) = mm;
             *reinterpret_cast<f32x4*>(v + i) = vv;
+            if (p16) {
+                unsigned r = (unsigned)i / cols16, c = (unsigned)i - r * cols16;  // numel < 2^32 (checked on the host)
+                if (c + 3 < cols16) {
+                    // one 8-byte store; only 2-byte aligned when the row length is odd (gfx950 runs with unaligned
+                    // global access enabled, hipcc emits global_store_dwordx2 for it)
+                    typedef uint2 uint2_u __attribute__((aligned(2)));
+                    *reinterpret_cast<uint2_u*>(p16 + (int64_t)r * ld16 + c) =
+                        make_uint2(gd_bf16_bits(pp[0]) | ((unsigned)gd_bf16_bits(pp[1]) << 16),
+                                   gd_bf16_bits(pp[2]) | ((unsigned)gd_bf16_bits(pp[3]) << 16));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        p16[(int64_t)r * ld16 + c] = gd_bf16_bits(pp[j]);
+                        if (++c == cols16) {
+                            c = 0;
+                            ++r;
+                        }
+                    }
+                }
+            }
         } else {
             for (int j = 0; j < 4; ++j)
-                if (i + j < n) adam_elem(p[i + j], g[i + j], m[i + j], v[i + j], h);
+                if (i + j < n) {
+                    adam_elem(p[i + j], g[i + j], m[i + j], v[i + j], h);
+                    if (p16) {
+                        const unsigned r = (unsigned)(i + j) / cols16, c = (unsigned)(i + j) - r * cols16;
+                        p16[(int64_t)r * ld16 + c] = gd_bf16_bits(p[i + j]);
+                    }
+                }
         }
     }
 }
@@ -560,6 +609,12 @@ int gdmcf_dnn_prep_input_f32(const float* x, int64_t ldx, const int64_t* ts, con
     a.keep_thresh = th >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)th;
     a.seed = seed; a.offset = offset; a.rownorm = nullptr; a.emb_w = emb_w; a.emb_b = emb_b; a.E = E; a.B = B;
     a.I = I; a.xin = xin; a.ldxin = ldxin; a.xt_out = xt_out; a.ldxt = ldxt; a.temb_out = temb_out;
+    a.xin16 = nullptr; a.ldxin16 = 0;
+    GdShadow sh;
+    if (gd_shadow_lookup(xin, &sh) && sh.rows == B && sh.cols == I + E) {  // keep the bf16 shadow of xin in sync
+        a.xin16 = (unsigned short*)sh.p16;
+        a.ldxin16 = sh.ld16;
+    }
     hipStream_t s = (hipStream_t)stream;
     if (normalize) {
         // F.normalize (reference models/DNN.py:75-76) needs the L2 norm of the noised row first
@@ -590,8 +645,10 @@ int gdmcf_rowscale_f32(const float* A, int64_t lda, const float* rowscale, int M
                        void* stream) {
     GD_CHECK_SHAPE(M > 0 && K > 0 && lda >= K && ldo >= K, "rowscale: bad shape");
     const int64_t n = (int64_t)M * K;
+    GdShadow sh;
+    const bool has16 = gd_shadow_lookup(out, &sh) && sh.rows == M && sh.cols == K;
     hipLaunchKernelGGL(rowscale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, A, lda,
-                       rowscale, M, K, out, ldo);
+                       rowscale, M, K, out, ldo, has16 ? (unsigned short*)sh.p16 : nullptr, has16 ? sh.ld16 : 0);
     return gd_launch_status("rowscale");
 }
 
@@ -638,15 +695,31 @@ int gdmcf_sample_timesteps(const double* Lt_history, const int64_t* Lt_count, in
     return gd_launch_status("sample_timesteps");
 }
 
-int gdmcf_adamw_f32(const int64_t* table, int n_tensors, int total_blocks, float lr, float beta1, float beta2,
-                    float eps, float weight_decay, int step, float grad_scale, void* stream) {
+static int adamw_launch(const int64_t* table, const int64_t* shadow_table, int n_tensors, int total_blocks, float lr,
+                        float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                        void* stream) {
     GD_CHECK_ARG(n_tensors > 0 && total_blocks > 0 && step >= 1, "adamw: bad arguments");
     const AdamHyper h = gd_adam_hyper(lr, beta1, beta2, eps, weight_decay, step, grad_scale);
     {
         GdProfScope prof(6, 28.0 * ADAM_BLOCK_ELEMS * (double)total_blocks, (hipStream_t)stream);
-        hipLaunchKernelGGL(adamw_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, table, n_tensors, h);
+        hipLaunchKernelGGL(adamw_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, table, n_tensors, h,
+                           shadow_table);
     }
     return gd_launch_status("adamw");
+}
+
+int gdmcf_adamw_f32(const int64_t* table, int n_tensors, int total_blocks, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, int step, float grad_scale, void* stream) {
+    return adamw_launch(table, nullptr, n_tensors, total_blocks, lr, beta1, beta2, eps, weight_decay, step, grad_scale,
+                        stream);
+}
+
+int gdmcf_adamw_bf16s_f32(const int64_t* table, const int64_t* shadow_table, int n_tensors, int total_blocks, float lr,
+                          float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                          void* stream) {
+    GD_CHECK_ARG(shadow_table != nullptr, "adamw_bf16s: shadow table missing");
+    return adamw_launch(table, shadow_table, n_tensors, total_blocks, lr, beta1, beta2, eps, weight_decay, step,
+                        grad_scale, stream);
 }
 
 int gdmcf_densify_rows_f32(const int64_t* indptr, const int32_t* indices, const float* values, const int64_t* row_ids,
@@ -687,8 +760,11 @@ int gd_splitk_reduce(const float* slabs, int64_t slab_stride, int splits, int64_
                      const float* bias, const float* rowscale, const float* aact, int64_t ldact, int act, float* out,
                      int64_t ldo, hipStream_t s) {
     const int64_t n = (int64_t)M * N;
+    GdShadow sh;
+    const bool has16 = gd_shadow_lookup(out, &sh) && sh.rows == M && sh.cols == N;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, slabs, slab_stride,
-                       splits, ld_slab, M, N, mode, bias, rowscale, aact, ldact, act, out, ldo);
+                       splits, ld_slab, M, N, mode, bias, rowscale, aact, ldact, act, out, ldo,
+                       has16 ? (unsigned short*)sh.p16 : nullptr, has16 ? sh.ld16 : 0);
     return gd_launch_status("splitk_reduce");
 }
 

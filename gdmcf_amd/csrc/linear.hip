@@ -6,7 +6,7 @@
 
 int gd_splitk_reduce(const float* slabs, int64_t slab_stride, int splits, int64_t ld_slab, int M, int N, int mode,
                      const float* bias, const float* rowscale, const float* aact, int64_t ldact, int act, float* out,
-                     int64_t ldo, hipStream_t s);
+                     int64_t ldo, hipStream_t s);  // also refreshes the bf16 shadow of `out`, if one is registered
 int gd_colsum(const float* dZ, int64_t ld, const float* rs, int M, int N, float* db, hipStream_t s);
 int gd_rowpart_reduce(const float* rowpart, int ld, int M, int nt, float* rowsum, hipStream_t s);
 
@@ -47,6 +47,15 @@ int pick_class_dw(int M, int N, int prec) {
 
 // bf16 mode: stream the operands from their registered bf16 shadows when both have one of exactly this shape
 // (operand stored [rows][K] for GD_LAY_KC, [K][rows] for GD_LAY_MC)
+// result written by a fused epilogue (BIAS_ACT without split-K, LOSS): keep its bf16 shadow in sync
+void attach_result_shadow(GdGemm& g) {
+    GdShadow c;
+    if (gd_shadow_lookup(g.C, &c) && c.rows == g.M && c.cols == g.N) {
+        g.C16 = c.p16;
+        g.ldc16 = c.ld16;
+    }
+}
+
 void attach_shadows(GdGemm& g, int layA, int layB) {
     if (!g.bf16) return;
     GdShadow a, b;
@@ -113,6 +122,7 @@ int gdmcf_linear_fwd_f32(const float* A, int64_t lda, const float* W, int64_t ld
     g.bias = bias; g.act = act; g.prof_tag = 1;
     if (splits == 1) {
         g.splits = 1; g.C = C; g.ldc = ldc;
+        attach_result_shadow(g);
         attach_shadows(g, GD_LAY_KC, GD_LAY_KC);
         return gd_gemm_launch(GD_LAY_KC, GD_LAY_KC, GD_EPI_BIAS_ACT, cls, g, s);
     }
@@ -145,6 +155,7 @@ int gdmcf_linear_loss_fwd_f32(const float* A, int64_t lda, const float* W, int64
     g.bias = bias; g.aux = target; g.ldaux = ldt; g.r0 = alpha; g.out2 = out; g.ldout2 = ldo;
     g.prof_tag = 2;
     g.C = diff; g.ldc = ldd; g.rowpart = rowpart; g.ld_rowpart = gdmcf_loss_tiles(N);
+    attach_result_shadow(g);
     attach_shadows(g, GD_LAY_KC, GD_LAY_KC);
     int rc = gd_gemm_launch(GD_LAY_KC, GD_LAY_KC, GD_EPI_LOSS, cls, g, s);
     if (rc) return rc;

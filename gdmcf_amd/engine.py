@@ -53,6 +53,7 @@ class DenoiserEngine:
         self.seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
         self.offset = 0
         self._bufs = {}
+        self._wshadow = {}
         self._saved = None
         # data parallel: called as grad_sink(param, grad) the moment a gradient's kernels are enqueued, so the
         # all-reduce of the big weight gradients overlaps the rest of the backward (gdmcf_amd/parallel.py).
@@ -75,6 +76,38 @@ class DenoiserEngine:
         self.offset = 0
 
     # ------------------------------------------------------------------------------------------
+    # bf16 shadows (gemm_dtype == "bf16"): bf16 copies of every GEMM operand, streamed instead of the f32 tensors.
+    # Activation shadows are written by the kernels that produce the activations; weight shadows are refreshed
+    # here whenever the parameter's version counter moved (FusedAdamW bumps it after its raw-pointer update).
+    def _shadows_on(self, bufs, layers):
+        if self.gemm_dtype != "bf16":
+            if bufs.shadows is not None:  # precision switched back: drop the registrations
+                for sh in bufs.shadows:
+                    sh.close()
+                bufs.shadows = None
+            for sh, _ in self._wshadow.values():
+                sh.close()
+            self._wshadow = {}
+            return
+        if bufs.shadows is None:
+            I, E = self.I, self.E
+            mk = lambda t, cols: _lib.Bf16Shadow(t[:, :cols], sync=False)
+            sh = [mk(bufs.xin, I + E), mk(bufs.diff, I)]
+            for (w, _, _), a, d in zip(layers[:-1], bufs.acts, bufs.dzs):
+                sh += [mk(a, w.shape[0]), mk(d, w.shape[0])]
+            sh.append(mk(bufs.hs, layers[-1][0].shape[1]))
+            bufs.shadows = sh
+            bufs.sh_xin = sh[0]
+        for w, _, _ in layers:
+            rec = self._wshadow.get(id(w))
+            if rec is None or rec[0].ptr != w.data_ptr():
+                if rec is not None:
+                    rec[0].close()
+                self._wshadow[id(w)] = [_lib.Bf16Shadow(w.detach()), w._version]
+            elif rec[1] != w._version:
+                rec[0].sync()
+                rec[1] = w._version
+
     def _layers(self):
         layers = self.model.layer_list()
         for w, b, _ in layers:
@@ -103,6 +136,7 @@ class DenoiserEngine:
         b.ldi = _ceil64(I)
         b.diff = torch.zeros(B, b.ldi, **f32)
         b.xt = None
+        b.shadows = None  # bf16 shadows of the GEMM operands among these buffers (created on first bf16 use)
         b.rowpart = torch.zeros(B, lib.gdmcf_loss_tiles(layers[-1][0].shape[0]), **f32)
         b.rowsum = torch.zeros(B, **f32)
         b.gradcoef = torch.zeros(B, **f32)
@@ -171,6 +205,7 @@ class DenoiserEngine:
         B, dev = x0.shape[0], x0.device
         layers = self._layers()
         bufs = self.buffers(B, dev)
+        self._shadows_on(bufs, layers)
         lib, st = self.lib, _lib.stream_ptr()
         self.version += 1
         eps_mode = spec["eps_mode"]
@@ -226,6 +261,7 @@ class DenoiserEngine:
         B, dev = x.shape[0], x.device
         layers = self._layers()
         bufs = self.buffers(B, dev)
+        self._shadows_on(bufs, layers)
         lib, st = self.lib, _lib.stream_ptr()
         self.version += 1
         ts = timesteps.to(device=dev, dtype=torch.int64).contiguous()
@@ -296,6 +332,7 @@ class DenoiserEngine:
                     dz.data_ptr(), lddz, A_use.data_ptr(), lda_use, _lib.ptr(rs), B, N, K, w.data_ptr(), w.stride(0),
                     fs["exp_avg"].data_ptr(), fs["exp_avg_sq"].data_ptr(), db.data_ptr(), fs["lr"], fs["beta1"],
                     fs["beta2"], fs["eps"], fs["weight_decay"], fs["step"], fs["grad_scale"], st))
+                torch.autograd.graph.increment_version(w)  # updated in the GEMM epilogue
                 dW = None
             else:
                 dW = torch.empty_like(w)
@@ -341,6 +378,7 @@ class DenoiserEngine:
         B, dev, I = x_start.shape[0], x_start.device, self.I
         layers = self._layers()
         bufs = self.buffers(B, dev)
+        self._shadows_on(bufs, layers)
         st = _lib.stream_ptr()
         self.version += 1
         if bufs.xin2 is None:

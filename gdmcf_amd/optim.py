@@ -54,14 +54,20 @@ class FusedAdamW(torch.optim.Optimizer):
                     step=int(st["step"]) + 1, grad_scale=float(self.grad_scale))
 
     def _table(self, gi, plist):
-        """Device table [n][6] = (p, g, m, v, numel, first_block); re-uploaded only when a pointer moved."""
-        rows, blk = [], 0
+        """Device tables: [n][6] = (p, g, m, v, numel, first_block) and, when any parameter has a registered bf16
+        shadow (bf16 GEMM mode), [n][3] = (shadow, cols, shadow ld); re-uploaded only when a pointer moved."""
+        rows, srows, blk = [], [], 0
         for p in plist:
             st = self.state[p]
             rows.append((p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                          p.numel(), blk))
+            info = _lib.shadow_info(p.data_ptr()) if p.dim() == 2 else None
+            if info is not None and (info[1], info[2]) == tuple(p.shape) and p.numel() < 2 ** 32:
+                srows.append((info[0], info[2], info[3]))
+            else:
+                srows.append((0, 1, 0))
             blk += (p.numel() + _BLOCK - 1) // _BLOCK
-        key = tuple(rows)
+        key = (tuple(rows), tuple(srows))
         cache = self._tables.setdefault(gi, {})
         hit = cache.get(key)
         if hit is None:
@@ -69,7 +75,9 @@ class FusedAdamW(torch.optim.Optimizer):
             # addresses, so after a few steps every combination is resident and no H2D copy happens
             if len(cache) >= 16:
                 cache.clear()
-            hit = (torch.tensor(rows, dtype=torch.int64).to(plist[0].device), blk)
+            dev = plist[0].device
+            stab = torch.tensor(srows, dtype=torch.int64).to(dev) if any(r[0] for r in srows) else None
+            hit = (torch.tensor(rows, dtype=torch.int64).to(dev), blk, stab, [r[0] != 0 for r in srows])
             cache[key] = hit
         return hit
 
@@ -83,10 +91,21 @@ class FusedAdamW(torch.optim.Optimizer):
                 raise RuntimeError("FusedAdamW does not support sparse gradients")
             if not p.grad.is_contiguous() or p.grad.dtype != torch.float32:
                 p.grad = p.grad.float().contiguous()
-        table, nblk = self._table(gi, plist)
+        table, nblk, stab, shadowed = self._table(gi, plist)
         b1, b2 = group["betas"]
-        _lib.check(lib.gdmcf_adamw_f32(table.data_ptr(), len(plist), nblk, group["lr"], b1, b2, group["eps"],
-                                       group["weight_decay"], step, float(self.grad_scale), _lib.stream_ptr()))
+        if stab is None:
+            _lib.check(lib.gdmcf_adamw_f32(table.data_ptr(), len(plist), nblk, group["lr"], b1, b2, group["eps"],
+                                           group["weight_decay"], step, float(self.grad_scale), _lib.stream_ptr()))
+        else:
+            _lib.check(lib.gdmcf_adamw_bf16s_f32(table.data_ptr(), stab.data_ptr(), len(plist), nblk, group["lr"], b1, b2,
+                                                 group["eps"], group["weight_decay"], step, float(self.grad_scale),
+                                                 _lib.stream_ptr()))
+        # The kernel wrote through raw pointers.  Parameters whose bf16 shadow was refreshed by this very launch keep
+        # their version (the engine's version-keyed shadow check then sees nothing to redo); all others are bumped so
+        # that autograd and version-keyed caches notice the in-place update.
+        for p, sh in zip(plist, shadowed):
+            if not sh:
+                torch.autograd.graph.increment_version(p)
 
     def _init_state(self, p):
         st = self.state[p]

@@ -125,6 +125,8 @@ int gdmcf_gemm_precision(int mode);
 int gdmcf_bf16_shadow_set(const float* f32, void* bf16, int64_t rows, int64_t cols, int64_t ld_bf16);
 int gdmcf_bf16_shadow_clear(const float* f32 /* NULL: all */);
 void* gdmcf_bf16_shadow_get(const float* f32);
+/* 1 and the registered description, or 0 when `f32` has no shadow */
+int gdmcf_bf16_shadow_info(const float* f32, void** bf16, int64_t* rows, int64_t* cols, int64_t* ld_bf16);
 int gdmcf_bf16_shadow_sync(const float* f32, int64_t ld, void* stream);
 size_t gdmcf_linear_ws_bytes(int M, int N, int K);
 /* C[M,N] = act(A[M,K] @ W[N,K]^T + bias) */
@@ -216,6 +218,12 @@ int gdmcf_sample_timesteps(const double* Lt_history, const int64_t* Lt_count, in
 int gdmcf_adamw_f32(const int64_t* table, int n_tensors, int total_blocks, float lr, float beta1,
                     float beta2, float eps, float weight_decay, int step, float grad_scale,
                     void* stream);
+/* Same update, additionally storing each updated parameter rounded to bfloat16 into its registered shadow:
+ * shadow_table [n_tensors][3] int64 device array = (shadow pointer or 0, columns of the 2-D parameter, shadow row
+ * stride) as returned by gdmcf_bf16_shadow_info.  Parameters must have fewer than 2^32 elements.              */
+int gdmcf_adamw_bf16s_f32(const int64_t* table, const int64_t* shadow_table, int n_tensors, int total_blocks, float lr,
+                          float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                          void* stream);
 
 /* ---- evaluation: history mask + top-k (main.py:296-301) ----------------------------------
  * For every row: entries listed in the CSR history mask become -inf, then the k largest
