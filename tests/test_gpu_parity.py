@@ -465,6 +465,60 @@ def test_bf16_gemm_path_tracks_oracle(shape):
         assert overlap >= 0.95, overlap
 
 
+def test_bf16_shadows_stay_in_sync():
+    """bf16 mode streams bf16 shadows of every GEMM operand.  After full train steps every shadow must equal the
+    float32 tensor rounded to bfloat16 (bit for bit, zero padding intact): written by the input builder, the split-K
+    reducers, the fused-loss epilogue, rowscale and -- for the weights -- by the AdamW kernel itself; a weight changed
+    behind the library's back is picked up through its version counter."""
+    from gdmcf_amd import _lib
+    B, I, hid, T = 48, 1301, 255, 5  # odd row lengths: the AdamW shadow stores are then only 2-byte aligned
+    torch.manual_seed(0)
+    model = gdmcf_amd.DNN([I, hid], [hid, I], 10, gemm_dtype="bf16").to(DEV).train()
+    gdif = gdmcf_amd.GaussianDiffusion(ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, T, DEV)
+    opt = gdmcf_amd.FusedAdamW(model.parameters(), lr=1e-3, weight_decay=0.01)
+    g = torch.Generator().manual_seed(1)
+
+    def step():
+        x = (torch.rand(B, I, generator=g) < 0.03).float().to(DEV)
+        opt.zero_grad()
+        l = gdif.training_losses(model, x, True)["loss"].mean()
+        l.backward()
+        opt.step()
+        return x, float(l.detach())
+
+    def check(sh, t):
+        rows, cols = sh.rows, sh.cols
+        want = t[:rows, :cols].detach().bfloat16()
+        assert torch.equal(sh.buf[:rows, :cols], want)
+        assert float(sh.buf[rows:].abs().sum()) == 0.0 and float(sh.buf[:, cols:].abs().sum()) == 0.0  # padding
+
+    for _ in range(3):
+        step()
+    eng = model.engine
+    bufs = eng.buffers(B, torch.device(DEV))
+    assert bufs.shadows is not None and len(eng._wshadow) == 2
+    srcs = [bufs.xin, bufs.diff, bufs.acts[0], bufs.dzs[0], bufs.hs]
+    for sh, t in zip(bufs.shadows, srcs):
+        assert _lib.shadow_info(t.data_ptr())[0] == sh.buf.data_ptr()
+        check(sh, t)
+    for w in (model.in_layers[0].weight, model.out_layers[0].weight):
+        check(eng._wshadow[id(w)][0], w)  # maintained by gdmcf_adamw_bf16s_f32, no re-cast
+    # a weight edited by plain torch: the next step must see the new values (version-keyed refresh)
+    with torch.no_grad():
+        model.out_layers[0].weight.mul_(0.5)
+    twin = gdmcf_amd.DNN([I, hid], [hid, I], 10, gemm_dtype="bf16").to(DEV).train()
+    twin.load_state_dict(model.state_dict())
+    x = (torch.rand(B, I, generator=g) < 0.03).float().to(DEV)
+    ts = torch.randint(0, T, (B,), generator=g).to(DEV)
+    noise, keep = torch.randn(B, I, generator=g).to(DEV), (torch.rand(B, I, generator=g) < 0.5).float().to(DEV)
+    gdif.update_history = False
+    with torch.no_grad():
+        a = gdif.training_losses(model, x, True, ts=ts, pt=torch.ones(B, device=DEV), noise=noise, drop_mask=keep)["loss"]
+        b = gdif.training_losses(twin, x, True, ts=ts, pt=torch.ones(B, device=DEV), noise=noise, drop_mask=keep)["loss"]
+    assert torch.equal(a, b)
+    check(eng._wshadow[id(model.out_layers[0].weight)][0], model.out_layers[0].weight)
+
+
 def test_driver_train_and_evaluate_match_oracle_loop():
     """reference main.py:327-351 + :267-310 end to end on a small synthetic problem: the HIP driver and the
     oracle loop start from the same weights, see the same batches and the same injected randomness, and must
