@@ -194,13 +194,16 @@ def main():
         sec = d["ms"] * 1e-3
         extra = {}
         if tag in GEMM_TAGS and args.gemm_dtype == "bf16":
-            # bf16 products of f32 tensors at batch 400 are bound by bringing the f32 operands in, not by the
-            # matrix pipe: report the HBM fraction on the compulsory bytes (each operand and the result once),
-            # and the bf16-MFMA fraction beside it.
+            # bf16 products at batch 400 are bound by moving operands and results, not by the matrix pipe: report
+            # the HBM fraction on the compulsory bytes (each operand and the result once) and the bf16-MFMA
+            # fraction beside it.
             E_ = 10
-            per_launch = {1: B * (I + E_) + hid * (I + E_) + B * hid, 2: B * hid + I * hid + 2 * B * I,
-                          3: B * hid + I * hid + 2 * B * I, 4: B * I + I * hid + B * hid,
-                          5: (2 * B * I + 2 * B * hid + 2 * I * hid + E_ * (B + hid)) / 2.0}[tag] * 4.0
+            ob = 2.0  # operands are streamed from their bf16 shadows (2 B/elem); results and the loss target are f32
+            per_launch = {1: ob * (B + hid) * (I + E_) + 4.0 * B * hid,
+                          2: ob * (B * hid + I * hid) + 4.0 * 2 * B * I + 2.0 * B * I,
+                          3: ob * (B * hid + I * hid) + 4.0 * 2 * B * I,
+                          4: ob * (B * I + I * hid) + 4.0 * B * hid,
+                          5: (ob * (B * I + 2 * B * hid + B * (I + E_)) + 4.0 * (I * hid + hid * (I + E_))) / 2.0}[tag]
             ach, peak, unit, bound = per_launch * d["n"] / sec / 1e9, PEAK_HBM_GBPS, "GB/s", "hbm"
             extra = dict(mfma_tflops=round(d["work"] / sec / 1e12, 1),
                          mfma_frac=round(d["work"] / sec / 1e12 / PEAK_BF16_MATRIX_TFLOPS, 4))

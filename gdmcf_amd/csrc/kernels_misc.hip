@@ -701,7 +701,8 @@ static int adamw_launch(const int64_t* table, const int64_t* shadow_table, int n
     GD_CHECK_ARG(n_tensors > 0 && total_blocks > 0 && step >= 1, "adamw: bad arguments");
     const AdamHyper h = gd_adam_hyper(lr, beta1, beta2, eps, weight_decay, step, grad_scale);
     {
-        GdProfScope prof(6, 28.0 * ADAM_BLOCK_ELEMS * (double)total_blocks, (hipStream_t)stream);
+        // algorithmic bytes: read p, g, m, v; write p, m, v (+ the 2-byte shadow of p in bf16 mode)
+        GdProfScope prof(6, (shadow_table ? 30.0 : 28.0) * ADAM_BLOCK_ELEMS * (double)total_blocks, (hipStream_t)stream);
         hipLaunchKernelGGL(adamw_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, table, n_tensors, h,
                            shadow_table);
     }
