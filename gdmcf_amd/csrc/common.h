@@ -129,7 +129,6 @@ struct GdGemm {
     void* C16;
     int64_t ldc16;
     int bf16;  // 1: operands rounded to bfloat16 on the way to LDS, bf16 MFMA, f32 accumulate (gemm_bf16.hip)
-    int stagger;  // startup delay (x512 clocks) for workgroups in odd wave slots; de-phases co-resident workgroups
 };
 
 // shape classes: 0 = "batch-M" (BM=80, BN=128), 1 = square 128x128, 2 = small 64x64,

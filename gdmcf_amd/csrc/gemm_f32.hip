@@ -286,14 +286,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GdGemm g) {
     // its MFMA pipes busy, one tile ahead only gives half of that (measured: 40-60 % MFMA busy).
     TileStage<LAYA, BM, BK> sa0, sa1;
     TileStage<LAYB, BN, BK> sb0, sb1;
-    if (g.stagger > 0) {
-        // Two workgroups share a CU and run identical code from the same start: left alone they stay in
-        // lockstep (both in the MFMA phase, then both in the load/LDS phase, matrix pipe idle).  Delaying the
-        // workgroup that sits in the odd wave slots by part of an iteration makes the phases complementary.
-        const unsigned slot = __builtin_amdgcn_s_getreg((4) | (0 << 6) | ((4 - 1) << 11));  // HW_ID.wave_id
-        if (slot & 1u)
-            for (int i = 0; i < g.stagger; ++i) __builtin_amdgcn_s_sleep(8);
-    }
     const bool a_full = (m0 + BM <= g.M), b_full = (n0 + BN <= g.N);
     float* const L0 = smem;
     float* const L1 = smem + STAGE_FLOATS;

@@ -149,3 +149,34 @@ def test_data_load_matches_reference(tmp_path):
     ds = data_utils.DataDiffusion(torch.from_numpy(tr.toarray()))
     row, idx = ds[3]
     assert idx == 3 and len(ds) == nu and torch.equal(row, torch.from_numpy(tr.toarray())[3])
+
+
+def test_bf16_shadow_registry_and_gemm_precision_are_host_side_state():
+    """include/gdmcf_hip.h: gdmcf_gemm_precision is per calling thread and returns the previous mode; the bf16 shadow
+    registry is a host-side map keyed by the float32 base pointer (no GPU needed to exercise its contract)."""
+    import ctypes
+    import threading
+    from gdmcf_amd import _lib
+    lib = _lib.load()
+    assert lib.gdmcf_gemm_precision(1) == 0 and lib.gdmcf_gemm_precision(-1) == 1  # -1 only queries
+    seen = []
+    t = threading.Thread(target=lambda: seen.append(lib.gdmcf_gemm_precision(-1)))
+    t.start(), t.join()
+    assert seen == [0]  # another thread still has the default
+    assert lib.gdmcf_gemm_precision(0) == 1
+    f32 = (ctypes.c_float * 16)()
+    b16 = (ctypes.c_uint16 * (64 * 64 + 8))()
+    base = ctypes.addressof(b16)
+    aligned = (base + 15) & ~15
+    pf = ctypes.addressof(f32)
+    assert _lib.shadow_info(pf) is None and lib.gdmcf_bf16_shadow_get(pf) is None
+    _lib.check(lib.gdmcf_bf16_shadow_set(pf, aligned, 4, 4, 64))
+    assert _lib.shadow_info(pf) == (aligned, 4, 4, 64) and lib.gdmcf_bf16_shadow_get(pf) == aligned
+    with pytest.raises(AssertionError):  # row stride must be a multiple of 64 and >= cols
+        _lib.check(lib.gdmcf_bf16_shadow_set(pf, aligned, 4, 4, 8))
+    with pytest.raises(ValueError):  # 16-byte alignment
+        _lib.check(lib.gdmcf_bf16_shadow_set(pf, aligned + 2, 4, 4, 64))
+    with pytest.raises(ValueError):  # syncing something that was never registered
+        _lib.check(lib.gdmcf_bf16_shadow_sync(pf + 4, 4, None))
+    _lib.check(lib.gdmcf_bf16_shadow_clear(pf))
+    assert _lib.shadow_info(pf) is None

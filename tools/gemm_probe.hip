@@ -59,7 +59,6 @@ int main(int argc, char** argv) {
     CK(hipEventCreate(&e0));
     CK(hipEventCreate(&e1));
     const int splits = getenv("GD_SPLITS") ? atoi(getenv("GD_SPLITS")) : 12;
-    const int stagger = getenv("GD_STAGGER") ? atoi(getenv("GD_STAGGER")) : 0;
 
     struct Case { const char* name; int la, lb, epi, cls; GdGemm g; };
     std::vector<Case> cases;
@@ -91,7 +90,6 @@ int main(int argc, char** argv) {
         cases.push_back({"dW1 cls0  ", GD_LAY_MC, GD_LAY_MC, GD_EPI_STORE, 0, g});
     }
     for (auto& c : cases) {
-        c.g.stagger = stagger;
         for (int w = 0; w < 3; ++w) {
             GdGemm g = c.g;
             if (gd_gemm_launch(c.la, c.lb, c.epi, c.cls, g, s)) return 1;
