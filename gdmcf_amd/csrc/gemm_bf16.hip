@@ -336,7 +336,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(const
         if (more) store_tile(nxt, kbeg + (it + 1) * BK);
         __syncthreads();
     }
-    gemm_epilogue<BM, TM, TN, WAVES_N, EPI>(acc, g, m0, n0, wm0, wn0, r, q, split, tile_n, wave, tid, smem);
+    if constexpr (EPI == GD_EPI_ADAMW)  // (plain result stores measured equal with and without the LDS round trip)
+        gemm_epilogue_rows<BM, BN, TM, TN, WAVES_M, WAVES_N, EPI, 64 * (BM + BN), NT>(acc, g, m0, n0, wn0, r, q, wave, tid,
+                                                                                     smem);
+    else
+        gemm_epilogue<BM, TM, TN, WAVES_N, EPI>(acc, g, m0, n0, wm0, wn0, r, q, split, tile_n, wave, tid, smem);
 }
 
 template <int LAYA, int LAYB, int BM, int BN, int WM, int WN, int EPI, bool S16>

@@ -14,6 +14,95 @@ __device__ __forceinline__ unsigned short gd_epi_bf16(float x) {
     return __builtin_bit_cast(unsigned short, h);
 }
 
+// ---- row-contiguous epilogue for the weight-gradient products (used for GD_EPI_ADAMW; handles GD_EPI_STORE too) ----
+// The MFMA accumulator layout gives every store instruction four 64-byte row segments (dword per lane).  Here the
+// tile is handed through LDS instead (the operand buffers are dead after the final barrier) and written back as
+// 16 bytes per lane along the rows: a pass of NTH threads covers NTH/(BN/4) full tile rows of BN*4 contiguous bytes.
+// With GD_EPI_ADAMW the same pass streams W, exp_avg and exp_avg_sq exactly like the stand-alone AdamW kernel.
+// LDS image [slot][BN + 4]: (4*LD) % 32 == 16, so the four lane groups of a ds_write_b32 hit disjoint banks.
+// Rounds of IB 16-row blocks per wave row when the whole tile does not fit in LDS_FLOATS.
+typedef f32x4 f32x4_ua __attribute__((aligned(4)));
+typedef uint2 uint2_ua __attribute__((aligned(2)));
+
+template <int BM, int BN, int TM, int TN, int WAVES_M, int WAVES_N, int EPI, int LDS_FLOATS, int NTH>
+__device__ __forceinline__ void gemm_epilogue_rows(f32x4 (&acc)[TM][TN], const GdGemm& g, int m0, int n0, int wn0,
+                                                   int r, int q, int wave, int tid, float* smem) {
+    static_assert(EPI == GD_EPI_STORE || EPI == GD_EPI_ADAMW, "row epilogue: weight-gradient products only");
+    constexpr int LD = BN + 4;
+    constexpr int IBMAX = LDS_FLOATS / (WAVES_M * 16 * LD);
+    static_assert(IBMAX >= 1, "row epilogue: LDS too small for one 16-row block per wave row");
+    constexpr int IB = IBMAX < TM ? IBMAX : TM;
+    constexpr int TPR = BN / 4, RPP = NTH / TPR, SLOTS = WAVES_M * IB * 16;
+    static_assert(NTH % TPR == 0 && BN % 4 == 0, "row epilogue: thread mapping");
+    const int wr = wave / WAVES_N;
+    const int c4 = (tid % TPR) * 4;
+    const int n = n0 + c4;
+    float* __restrict__ P = g.C;
+    float* __restrict__ Mo = const_cast<float*>(g.aux);
+    float* __restrict__ Vo = const_cast<float*>(g.aux2);
+#pragma unroll
+    for (int i0 = 0; i0 < TM; i0 += IB) {
+#pragma unroll
+        for (int ib = 0; ib < IB; ++ib) {
+            if (i0 + ib < TM) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        smem[((wr * IB + ib) * 16 + 4 * q + e) * LD + wn0 + 16 * j + r] = acc[(i0 + ib) < TM ? (i0 + ib) : 0][j][e];
+            }
+        }
+        __syncthreads();
+        for (int s = tid / TPR; s < SLOTS; s += RPP) {
+            const int swr = s / (IB * 16), sib = (s >> 4) % IB;
+            const int m = m0 + swr * (BM / WAVES_M) + 16 * (i0 + sib) + (s & 15);
+            if (i0 + sib >= TM || m >= g.M || n >= g.N) continue;
+            const f32x4 gv = *reinterpret_cast<const f32x4*>(&smem[s * LD + c4]);
+            const int64_t o = (int64_t)m * g.ldc + n;
+            if (n + 3 < g.N) {
+                if (EPI == GD_EPI_STORE) {
+                    f32x4 v = gv;
+                    if (g.accumulate) v += *reinterpret_cast<const f32x4_ua*>(P + o);
+                    *reinterpret_cast<f32x4_ua*>(P + o) = v;
+                } else {
+                    f32x4 pv = *reinterpret_cast<const f32x4_ua*>(P + o);
+                    f32x4 mv = *reinterpret_cast<const f32x4_ua*>(Mo + o);
+                    f32x4 vv = *reinterpret_cast<const f32x4_ua*>(Vo + o);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float pk = pv[k], mk = mv[k], vk = vv[k];
+                        gd_adam_elem(pk, gv[k], mk, vk, g.adam);
+                        pv[k] = pk;
+                        mv[k] = mk;
+                        vv[k] = vk;
+                    }
+                    *reinterpret_cast<f32x4_ua*>(P + o) = pv;
+                    *reinterpret_cast<f32x4_ua*>(Mo + o) = mv;
+                    *reinterpret_cast<f32x4_ua*>(Vo + o) = vv;
+                    if (g.C16)
+                        *reinterpret_cast<uint2_ua*>(static_cast<unsigned short*>(g.C16) + (int64_t)m * g.ldc16 + n) =
+                            make_uint2(gd_epi_bf16(pv[0]) | ((unsigned)gd_epi_bf16(pv[1]) << 16),
+                                       gd_epi_bf16(pv[2]) | ((unsigned)gd_epi_bf16(pv[3]) << 16));
+                }
+            } else {
+                for (int k = 0; k < 4 && n + k < g.N; ++k) {
+                    if (EPI == GD_EPI_STORE) {
+                        P[o + k] = g.accumulate ? P[o + k] + gv[k] : gv[k];
+                    } else {
+                        float pk = P[o + k], mk = Mo[o + k], vk = Vo[o + k];
+                        gd_adam_elem(pk, gv[k], mk, vk, g.adam);
+                        P[o + k] = pk;
+                        Mo[o + k] = mk;
+                        Vo[o + k] = vk;
+                        if (g.C16) static_cast<unsigned short*>(g.C16)[(int64_t)m * g.ldc16 + n + k] = gd_epi_bf16(pk);
+                    }
+                }
+            }
+        }
+        if (i0 + IB < TM) __syncthreads();
+    }
+}
+
 // ---- epilogue (shared by the plain and the wave-specialised kernel) ---------------------------------------
 template <int BM, int TM, int TN, int WAVES_N, int EPI>
 __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GdGemm& g, int m0, int n0, int wm0, int wn0,

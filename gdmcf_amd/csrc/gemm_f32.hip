@@ -478,6 +478,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GdGemm g) {
     gemm_epilogue<BM, TM, TN, WAVES_N, EPI>(acc, g, m0, n0, wm0, wn0, r, q, split, tile_n, wave, tid, smem);
 }
 
+// dynamic LDS of the wave-specialised kernel in floats: the two operand stages, or -- for the fused-AdamW product,
+// whose result goes back through LDS as full rows (gemm_epilogue_rows) -- the whole result tile when that still
+// leaves room for two workgroups per CU
+template <int LAYA, int LAYB, int BM, int BN, int BK, int WAVES_M, int EPI>
+constexpr int spec_lds_floats() {
+    constexpr int main_f = 2 * (TileGeom<LAYA, BM, BK>::FLOATS + TileGeom<LAYB, BN, BK>::FLOATS);
+    constexpr int tile_f = BM * (BN + 4);
+    constexpr bool rows = (EPI == GD_EPI_ADAMW);
+    return (rows && tile_f > main_f && tile_f * 4 <= 78 * 1024) ? tile_f : main_f;
+}
+
 // ---- wave-specialised variant ------------------------------------------------------------------------------
 // 512 threads: waves 0-3 issue nothing but LDS fragment reads and MFMAs, waves 4-7 do all global loads and LDS
 // writes (same two-tile-ahead register staging, same LDS images, same edge handling).  Motivation (measured):
@@ -601,7 +612,11 @@ __global__ __launch_bounds__(2 * NTHREADS, 4) void gemm_f32_spec_kernel(const Gd
         }
         __syncthreads();
     }
-    gemm_epilogue<BM, TM, TN, WAVES_N, EPI>(acc, g, m0, n0, wm0, wn0, r, q, split, tile_n, wave, tid, smem);
+    if constexpr (EPI == GD_EPI_ADAMW)  // plain stores measured faster without the LDS round trip (0.260 vs 0.280 ms)
+        gemm_epilogue_rows<BM, BN, TM, TN, WAVES_M, WAVES_N, EPI, spec_lds_floats<LAYA, LAYB, BM, BN, BK, WAVES_M, EPI>(),
+                           NTHREADS>(acc, g, m0, n0, wn0, r, q, wave, tid, smem);
+    else
+        gemm_epilogue<BM, TM, TN, WAVES_N, EPI>(acc, g, m0, n0, wm0, wn0, r, q, split, tile_n, wave, tid, smem);
 }
 
 template <int LAYA, int LAYB, int BM, int BN, int BK, int WM, int WN, int EPI>
@@ -609,13 +624,14 @@ int launch_one(GdGemm& g, hipStream_t s) {
     using GA = TileGeom<LAYA, BM, BK>;
     using GB = TileGeom<LAYB, BN, BK>;
     static const size_t lds_pad = getenv("GD_LDS_PAD") ? (size_t)atoi(getenv("GD_LDS_PAD")) : 0;  // occupancy experiments
-    const size_t lds = (size_t)2 * (GA::FLOATS + GB::FLOATS) * sizeof(float) + lds_pad;
+    size_t lds = (size_t)2 * (GA::FLOATS + GB::FLOATS) * sizeof(float) + lds_pad;
     // Row-contiguous x row-contiguous products (the weight gradients) run the wave-specialised kernel: measured
     // +6-7 % at 128x128 tiles on the Yelp shape, no gain or a loss for the K-contiguous products
     // (profiles/r01_spec_ab.txt).  GDMCF_GEMM_SPEC=0 switches it off for A/B runs.
     static const bool spec_on = !(getenv("GDMCF_GEMM_SPEC") && atoi(getenv("GDMCF_GEMM_SPEC")) == 0);
     constexpr bool SPEC_OK = (LAYA == 1 && LAYB == 1 && BM == 128 && BN == 128);
     const bool spec = SPEC_OK && spec_on;
+    if (spec) lds = (size_t)spec_lds_floats<LAYA, LAYB, BM, BN, BK, WM, EPI>() * sizeof(float);
     void (*kern)(const GdGemm) = gemm_f32_kernel<LAYA, LAYB, BM, BN, BK, WM, WN, EPI>;
     if constexpr (SPEC_OK) {
         // register stages of the loader waves: 2 (default) or 4 via GDMCF_SPEC_STAGES; measured 0.260 / 0.262 / 0.257

@@ -244,6 +244,7 @@ int gdmcf_linear_bwd_weight_adamw_f32(const float* dZ, int64_t lddz, const float
     g.m_fastest = gd_cdiv(N, gd_gemm_tile_m(cls)) <= gd_cdiv(K, gd_gemm_tile_n(cls));
     g.C = W; g.ldc = ldw; g.aux = exp_avg; g.aux2 = exp_avg_sq; g.prof_tag = 5;
     g.adam = gd_adam_hyper(lr, beta1, beta2, eps, weight_decay, step, grad_scale);
+    if (g.bf16) attach_result_shadow(g);  // the bf16 kernels' row epilogue also refreshes W's bf16 shadow
     attach_shadows(g, GD_LAY_MC, GD_LAY_MC);
     int rc = gd_gemm_launch(GD_LAY_MC, GD_LAY_MC, GD_EPI_ADAMW, cls, g, s);
     if (rc) return rc;

@@ -332,7 +332,8 @@ class DenoiserEngine:
                     dz.data_ptr(), lddz, A_use.data_ptr(), lda_use, _lib.ptr(rs), B, N, K, w.data_ptr(), w.stride(0),
                     fs["exp_avg"].data_ptr(), fs["exp_avg_sq"].data_ptr(), db.data_ptr(), fs["lr"], fs["beta1"],
                     fs["beta2"], fs["eps"], fs["weight_decay"], fs["step"], fs["grad_scale"], st))
-                torch.autograd.graph.increment_version(w)  # updated in the GEMM epilogue
+                if not (self.gemm_dtype == "bf16" and _lib.shadow_info(w.data_ptr()) is not None):
+                    torch.autograd.graph.increment_version(w)  # updated in the GEMM epilogue (bf16: shadow too)
                 dW = None
             else:
                 dW = torch.empty_like(w)

@@ -799,3 +799,44 @@ def test_fused_optimizer_in_backward_equals_step():
     # and the reference's weights after these steps (golden) within the usual lr-scale bound
     for k, v in m1.named_parameters():
         assert np.abs(v.detach().cpu().numpy() - fx["pN." + k]).max() < 0.05 * 1e-3 * meta["n_steps"], k
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(1280, 256, 64), (1301, 255, 48)])
+def test_fused_optimizer_row_epilogue_matches_separate_pass(shape, dtype):
+    """fuse_into_backward at shapes that take the 128x128 wave-specialised f32 kernel / the bf16 kernels, whose fused
+    epilogue hands the gradient tile through LDS and streams W, exp_avg, exp_avg_sq row-wise (gemm_epilogue_rows):
+    same weights, moments and losses as the separate AdamW pass over 5 steps (Philox path, weight decay on); in bf16
+    mode the weight shadows refreshed by the epilogue must equal the rounded weights."""
+    I, hid, B = shape
+
+    def run(fuse):
+        torch.manual_seed(0)
+        m = gdmcf_amd.DNN([I, hid], [hid, I], 10, gemm_dtype=dtype).to(DEV).train()
+        d = gdmcf_amd.GaussianDiffusion(ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, 5, DEV)
+        o = gdmcf_amd.FusedAdamW(m.parameters(), lr=1e-3, weight_decay=0.01)
+        if fuse:
+            o.fuse_into_backward(m)
+        m.engine.manual_seed(99)
+        g = torch.Generator().manual_seed(1)
+        losses = []
+        for _ in range(5):
+            x = (torch.rand(B, I, generator=g) < 0.02).float().to(DEV)
+            ts = torch.randint(0, 5, (B,), generator=g).to(DEV)
+            o.zero_grad()
+            l = d.training_losses(m, x, True, ts=ts, pt=torch.ones(B, device=DEV))["loss"].mean()
+            l.backward()
+            o.step()
+            losses.append(float(l.detach()))
+        return m, o, losses
+
+    m0, o0, l0 = run(False)
+    m1, o1, l1 = run(True)
+    np.testing.assert_allclose(l1, l0, rtol=1e-6)
+    for a, b in zip(m0.parameters(), m1.parameters()):
+        assert float((a - b).abs().max()) <= 2e-3 * 1e-3 * 5  # same math in two compilation contexts (FMA contraction)
+        assert H.relerr(o1.state[b]["exp_avg_sq"].cpu().numpy(), o0.state[a]["exp_avg_sq"].cpu().numpy()) < 1e-6
+    if dtype == "bf16":
+        for w in (m1.in_layers[0].weight, m1.out_layers[0].weight):
+            sh = m1.engine._wshadow[id(w)][0]
+            assert torch.equal(sh.buf[:sh.rows, :sh.cols], w.detach().bfloat16())
