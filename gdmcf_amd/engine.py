@@ -98,6 +98,9 @@ class DenoiserEngine:
             sh.append(mk(bufs.hs, layers[-1][0].shape[1]))
             bufs.shadows = sh
             bufs.sh_xin = sh[0]
+        live = {id(w) for w, _, _ in layers}
+        for key in [k for k in self._wshadow if k not in live]:  # a parameter object was replaced: drop its registration
+            self._wshadow.pop(key)[0].close()
         for w, _, _ in layers:
             rec = self._wshadow.get(id(w))
             if rec is None or rec[0].ptr != w.data_ptr():

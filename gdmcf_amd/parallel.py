@@ -80,6 +80,8 @@ def broadcast_parameters(model, group=None, src=0):
                 p.data.copy_(h)
             else:
                 dist.broadcast(p.data, src=src, group=group)
+            # writes through .data do not move the version counter; caches keyed on it (bf16 weight shadows) must see this
+            torch.autograd.graph.increment_version(p)
 
 
 class DataParallelStep:
