@@ -93,6 +93,38 @@ def test_train_steps_match_reference(case):
         assert H.relerr(opt.state[v]["exp_avg_sq"].cpu().numpy(), fx["v." + k]) < 4e-4, k
 
 
+@pytest.mark.parametrize("case", H.TRAIN_CASES)
+def test_bf16_mode_on_every_reference_configuration(case):
+    """The bf16 GEMM mode (shadows included) on every fixture configuration of the f32 parity suite -- eps / x0 mean
+    type, weight decay, T=40 importance sampling, two hidden layers, F.normalize -- against the reference's own
+    numbers with bf16-rounding tolerances: loss 3e-3 (mean) / 2e-2 (per row), first-step gradients 5e-2 relative L2,
+    and the bookkeeping that does not depend on the GEMM precision (Lt_count) exact."""
+    fx = H.load("train_" + case)
+    meta = H.train_meta(fx)
+    model = gpu_model(meta, fx)
+    model.gemm_dtype = "bf16"
+    diff = gpu_diffusion(meta)
+    diff.Lt_history.copy_(torch.from_numpy(fx["Lt_history0"]))
+    diff.Lt_count.copy_(torch.from_numpy(fx["Lt_count0"]))
+    opt = gdmcf_amd.FusedAdamW(model.parameters(), lr=meta["lr"], weight_decay=meta["wd"])
+    model.train()
+    for s in range(meta["n_steps"]):
+        inp = H.step_inputs(fx, s)
+        opt.zero_grad()
+        terms = diff.training_losses(model, cu(inp["x"]), True, ts=cu(inp["ts"]), pt=cu(inp["pt"]),
+                                     noise=cu(inp["noise"]), drop_mask=cu(inp["drop_mask"]))
+        loss = terms["loss"].mean()
+        loss.backward()
+        np.testing.assert_allclose(terms["loss"].detach().cpu().numpy(), fx[f"s{s}.loss_vec"], rtol=2e-2, atol=0)
+        assert abs(float(loss) - float(fx[f"s{s}.loss"])) <= 3e-3 * abs(float(fx[f"s{s}.loss"]))
+        if s == 0:
+            for k, v in model.named_parameters():
+                assert H.relerr(v.grad.cpu().numpy(), fx["g0." + k]) < 5e-2, k
+        opt.step()
+        np.testing.assert_array_equal(diff.Lt_count.cpu().numpy(), fx[f"s{s}.Lt_count"])
+    assert model.engine.buffers(meta["B"], torch.device(DEV)).shadows is not None  # the shadow path is what ran
+
+
 def test_plain_forward_backward_matches_oracle():
     """model(x, t) + autograd through the HIP kernels vs the oracle's eager autograd."""
     fx = H.load("train_ragged_x0")
