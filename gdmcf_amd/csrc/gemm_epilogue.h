@@ -239,6 +239,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GdGemm
                         if (ok) {
                             if (g.out2) g.out2[(int64_t)m * g.ldout2 + ncl[j]] = pred;
                             g.C[(int64_t)m * g.ldc + ncl[j]] = mean;
+                            if (g.C16) static_cast<unsigned short*>(g.C16)[(int64_t)m * g.ldc16 + ncl[j]] = gd_epi_bf16(mean);
                         }
                     }
                 }

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void prep_input_kernel(const PrepArgs a) {
 
 __global__ void emb_cols_kernel(const int64_t* __restrict__ ts, const float* __restrict__ emb_w,
                                 const float* __restrict__ emb_b, int E, int I, float* __restrict__ xin, int64_t ldxin,
-                                float* __restrict__ temb_out) {
+                                float* __restrict__ temb_out, unsigned short* __restrict__ xin16, int64_t ldxin16) {
     const int b = blockIdx.x;
     const float t = (float)ts[b];
     for (int i = I + threadIdx.x; i < ldxin; i += blockDim.x) {
@@ -203,6 +203,7 @@ __global__ void emb_cols_kernel(const int64_t* __restrict__ ts, const float* __r
             if (temb_out) temb_out[(int64_t)b * E + eo] = temb_value(t, eo, E);
         }
         xin[(int64_t)b * ldxin + i] = e;
+        if (xin16 && i < ldxin16) xin16[(int64_t)b * ldxin16 + i] = gd_bf16_bits(e);
     }
 }
 
@@ -636,8 +637,10 @@ int gdmcf_dnn_prep_input_f32(const float* x, int64_t ldx, const int64_t* ts, con
 int gdmcf_dnn_emb_cols_f32(const int64_t* ts, const float* emb_w, const float* emb_b, int E, int B, int I, float* xin,
                            int64_t ldxin, float* temb_out, void* stream) {
     GD_CHECK_SHAPE(B > 0 && I > 0 && E > 0 && ldxin >= I + E, "emb_cols: bad shape");
+    GdShadow sh;
+    const bool has16 = gd_shadow_lookup(xin, &sh) && sh.rows == B && sh.cols == I + E;
     hipLaunchKernelGGL(emb_cols_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, ts, emb_w, emb_b, E, I, xin, ldxin,
-                       temb_out);
+                       temb_out, has16 ? (unsigned short*)sh.p16 : nullptr, has16 ? sh.ld16 : 0);
     return gd_launch_status("emb_cols");
 }
 

@@ -50,7 +50,7 @@ int pick_class_dw(int M, int N, int prec) {
 // result written by a fused epilogue (BIAS_ACT without split-K, LOSS): keep its bf16 shadow in sync
 void attach_result_shadow(GdGemm& g) {
     GdShadow c;
-    if (gd_shadow_lookup(g.C, &c) && c.rows == g.M && c.cols == g.N) {
+    if (g.bf16 && gd_shadow_lookup(g.C, &c) && c.rows == g.M && c.cols >= g.N) {  // x_next lands in a wider xin buffer
         g.C16 = c.p16;
         g.ldc16 = c.ld16;
     }
@@ -179,6 +179,7 @@ int gdmcf_linear_posterior_fwd_f32(const float* A, int64_t lda, const float* W, 
     g.bias = bias; g.aux = x_t; g.ldaux = ldxt; g.aux2 = z; g.ldaux2 = ldz;
     g.r0 = c1; g.r1 = c2; g.r2 = r1; g.r3 = r2; g.r4 = sigma;
     g.out2 = pred_out; g.ldout2 = ldp; g.C = x_next; g.ldc = ldxn; g.prof_tag = 3;
+    attach_result_shadow(g);
     attach_shadows(g, GD_LAY_KC, GD_LAY_KC);
     return gd_gemm_launch(GD_LAY_KC, GD_LAY_KC, GD_EPI_POST, cls, g, s);
 }
@@ -244,7 +245,7 @@ int gdmcf_linear_bwd_weight_adamw_f32(const float* dZ, int64_t lddz, const float
     g.m_fastest = gd_cdiv(N, gd_gemm_tile_m(cls)) <= gd_cdiv(K, gd_gemm_tile_n(cls));
     g.C = W; g.ldc = ldw; g.aux = exp_avg; g.aux2 = exp_avg_sq; g.prof_tag = 5;
     g.adam = gd_adam_hyper(lr, beta1, beta2, eps, weight_decay, step, grad_scale);
-    if (g.bf16) attach_result_shadow(g);  // the bf16 kernels' row epilogue also refreshes W's bf16 shadow
+    attach_result_shadow(g);  // the bf16 kernels' row epilogue also refreshes W's bf16 shadow
     attach_shadows(g, GD_LAY_MC, GD_LAY_MC);
     int rc = gd_gemm_launch(GD_LAY_MC, GD_LAY_MC, GD_EPI_ADAMW, cls, g, s);
     if (rc) return rc;

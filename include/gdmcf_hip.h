@@ -115,10 +115,11 @@ enum { GDMCF_GEMM_F32 = 0, GDMCF_GEMM_BF16 = 1 };
 int gdmcf_gemm_precision(int mode);
 /* bf16 shadows (GDMCF_GEMM_BF16 only): a shadow is a bfloat16 copy of a float32 matrix that the library may
  * stream INSTEAD of the float32 matrix when that matrix is an operand of a dense product (half the bytes, no
- * conversion on chip), and that every library kernel WRITING the float32 matrix keeps up to date (the input
- * builder, the split-K reducers, the fused-loss epilogue, gdmcf_rowscale_f32, gdmcf_adamw_f32 via its table).
- * The float32 matrix stays authoritative; a shadow whose float32 matrix was written by anything else must be
- * refreshed with gdmcf_bf16_shadow_sync.  Layout: [round_up(rows, 64)][ld_bf16] bfloat16, ld_bf16 a multiple of 64
+ * conversion on chip), and that these library kernels keep up to date when they write the float32 matrix:
+ * gdmcf_dnn_prep_input_f32 / gdmcf_dnn_emb_cols_f32 (xin), gdmcf_linear_fwd_f32 (C), gdmcf_linear_loss_fwd_f32
+ * (diff), gdmcf_linear_posterior_fwd_f32 (x_next), gdmcf_linear_bwd_input_f32 (dA), gdmcf_rowscale_f32 (out),
+ * gdmcf_adamw_bf16s_f32 and gdmcf_linear_bwd_weight_adamw_f32 (W).  The float32 matrix stays authoritative; a
+ * shadow whose float32 matrix was written by anything else must be refreshed with gdmcf_bf16_shadow_sync.  Layout: [round_up(rows, 64)][ld_bf16] bfloat16, ld_bf16 a multiple of 64
  * and >= cols, 16-byte aligned, ZERO outside [rows, cols) (the kernels rely on the zero padding instead of edge
  * predicates).  The registry is keyed by the float32 base pointer and global to the process: clear an entry
  * before its buffers are freed.  A product uses shadows only when BOTH operands have one of exactly its shape. */
