@@ -22,7 +22,8 @@ __device__ __forceinline__ unsigned short gd_epi_bf16(float x) {
 // LDS image [slot][BN + 4]: (4*LD) % 32 == 16, so the four lane groups of a ds_write_b32 hit disjoint banks.
 // Rounds of IB 16-row blocks per wave row when the whole tile does not fit in LDS_FLOATS.
 typedef f32x4 f32x4_ua __attribute__((aligned(4)));
-typedef uint2 uint2_ua __attribute__((aligned(2)));
+typedef unsigned int gd_u32x2 __attribute__((ext_vector_type(2)));
+typedef gd_u32x2 gd_u32x2_ua __attribute__((aligned(2)));
 
 template <int BM, int BN, int TM, int TN, int WAVES_M, int WAVES_N, int EPI, int LDS_FLOATS, int NTH>
 __device__ __forceinline__ void gemm_epilogue_rows(f32x4 (&acc)[TM][TN], const GdGemm& g, int m0, int n0, int wn0,
@@ -79,10 +80,11 @@ __device__ __forceinline__ void gemm_epilogue_rows(f32x4 (&acc)[TM][TN], const G
                     *reinterpret_cast<f32x4_ua*>(P + o) = pv;
                     *reinterpret_cast<f32x4_ua*>(Mo + o) = mv;
                     *reinterpret_cast<f32x4_ua*>(Vo + o) = vv;
-                    if (g.C16)
-                        *reinterpret_cast<uint2_ua*>(static_cast<unsigned short*>(g.C16) + (int64_t)m * g.ldc16 + n) =
-                            make_uint2(gd_epi_bf16(pv[0]) | ((unsigned)gd_epi_bf16(pv[1]) << 16),
-                                       gd_epi_bf16(pv[2]) | ((unsigned)gd_epi_bf16(pv[3]) << 16));
+                    if (g.C16) {
+                        const gd_u32x2 w16 = {gd_epi_bf16(pv[0]) | ((unsigned)gd_epi_bf16(pv[1]) << 16),
+                                              gd_epi_bf16(pv[2]) | ((unsigned)gd_epi_bf16(pv[3]) << 16)};
+                        *reinterpret_cast<gd_u32x2_ua*>(static_cast<unsigned short*>(g.C16) + (int64_t)m * g.ldc16 + n) = w16;
+                    }
                 }
             } else {
                 for (int k = 0; k < 4 && n + k < g.N; ++k) {

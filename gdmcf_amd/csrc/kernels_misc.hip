@@ -523,10 +523,11 @@ __global__ __launch_bounds__(256) void adamw_kernel(const int64_t* __restrict__ 
                 if (c + 3 < cols16) {
                     // one 8-byte store; only 2-byte aligned when the row length is odd (gfx950 runs with unaligned
                     // global access enabled, hipcc emits global_store_dwordx2 for it)
-                    typedef uint2 uint2_u __attribute__((aligned(2)));
-                    *reinterpret_cast<uint2_u*>(p16 + (int64_t)r * ld16 + c) =
-                        make_uint2(gd_bf16_bits(pp[0]) | ((unsigned)gd_bf16_bits(pp[1]) << 16),
-                                   gd_bf16_bits(pp[2]) | ((unsigned)gd_bf16_bits(pp[3]) << 16));
+                    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                    typedef u32x2 u32x2_u __attribute__((aligned(2)));
+                    const u32x2 w = {gd_bf16_bits(pp[0]) | ((unsigned)gd_bf16_bits(pp[1]) << 16),
+                                     gd_bf16_bits(pp[2]) | ((unsigned)gd_bf16_bits(pp[3]) << 16)};
+                    *reinterpret_cast<u32x2_u*>(p16 + (int64_t)r * ld16 + c) = w;
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
