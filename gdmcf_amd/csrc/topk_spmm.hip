@@ -27,16 +27,18 @@ __device__ __forceinline__ uint32_t masked_key(const float* __restrict__ row, co
     return order_key(row[i]);
 }
 
-template <bool STAGE>
-__global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ pred, int64_t ldp, int I,
+// NT threads per row: 1024 when the row is staged in LDS (the staged row allows one workgroup per CU anyway, and
+// the select is a chain of short LDS loops -- 16 waves hide their latency, 4 waves measured 2.4x slower)
+template <bool STAGE, int NT>
+__global__ __launch_bounds__(NT) void topk_kernel(const float* __restrict__ pred, int64_t ldp, int I,
                                                    const int64_t* __restrict__ indptr,
                                                    const int32_t* __restrict__ indices, int k, int KP,
                                                    int64_t* __restrict__ idx_out, float* __restrict__ val_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned long long* cand = reinterpret_cast<unsigned long long*>(smem_raw);  // [KP]
     uint32_t* hist = reinterpret_cast<uint32_t*>(cand + KP);                     // [256]
-    uint32_t* ctl = hist + 256;                                                  // [8]
-    uint32_t* bitmap = ctl + 8;                                                  // [ceil(I/32)]
+    uint32_t* ctl = hist + 256;                                                  // [24]: 4 scalars + one count per wave
+    uint32_t* bitmap = ctl + 24;                                                 // [ceil(I/32)]
     const int tid = threadIdx.x;
     const int row_id = blockIdx.x;
     const float* row = pred + (int64_t)row_id * ldp;
@@ -46,12 +48,12 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ pre
     // otherwise recomputed from global memory in every pass
     auto KEY = [&](int i) -> uint32_t { return STAGE ? keys[i] : masked_key(row, bitmap, i); };
 
-    for (int w = tid; w < nwords; w += 256) bitmap[w] = 0u;
-    for (int j = tid; j < KP; j += 256) cand[j] = 0ull;
+    for (int w = tid; w < nwords; w += NT) bitmap[w] = 0u;
+    for (int j = tid; j < KP; j += NT) cand[j] = 0ull;
     __syncthreads();
     if (indptr) {
         const int64_t beg = indptr[row_id], end = indptr[row_id + 1];
-        for (int64_t j = beg + tid; j < end; j += 256) {
+        for (int64_t j = beg + tid; j < end; j += NT) {
             const int c = indices[j];
             if (c >= 0 && c < I) atomicOr(&bitmap[c >> 5], 1u << (c & 31));
         }
@@ -59,17 +61,17 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ pre
     __syncthreads();
     if (STAGE) {
         int i = tid;
-        for (; i + 7 * 256 < I; i += 8 * 256) {
+        for (; i + 7 * NT < I; i += 8 * NT) {
             float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = row[i + u * 256];
+            for (int u = 0; u < 8; ++u) v[u] = row[i + u * NT];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                const int e = i + u * 256;
+                const int e = i + u * NT;
                 keys[e] = (bitmap[e >> 5] & (1u << (e & 31))) ? NEG_INF_KEY : order_key(v[u]);
             }
         }
-        for (; i < I; i += 256) keys[i] = masked_key(row, bitmap, i);
+        for (; i < I; i += NT) keys[i] = masked_key(row, bitmap, i);
         __syncthreads();
     }
 
@@ -77,13 +79,13 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ pre
     uint32_t prefix = 0, pmask = 0;
     int need = k;
     for (int shift = 24; shift >= 0; shift -= 8) {
-        hist[tid] = 0u;
+        if (tid < 256) hist[tid] = 0u;
         // Scores cluster (pass 1 sees ~2 exponent bins), so plain LDS atomics would serialise on one counter:
         // every thread counts the bin of a sampled key privately and only the other bins go through atomics.
         const uint32_t guess = (KEY(I >> 1) >> shift) & 255u;
         uint32_t local = 0;
         __syncthreads();
-        for (int i = tid; i < I; i += 256) {
+        for (int i = tid; i < I; i += NT) {
             const uint32_t key = KEY(i);
             if ((key & pmask) == prefix) {
                 const uint32_t b = (key >> shift) & 255u;
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ pre
     __syncthreads();
     if (n_eq_total == need) {
         // no surplus ties: order of collection is irrelevant
-        for (int i = tid; i < I; i += 256) {
+        for (int i = tid; i < I; i += NT) {
             const uint32_t key = KEY(i);
             if (key >= thr) {
                 const uint32_t slot = atomicAdd(&ctl[3], 1u);
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ pre
             }
         }
     } else {
-        for (int i = tid; i < I; i += 256) {
+        for (int i = tid; i < I; i += NT) {
             const uint32_t key = KEY(i);
             if (key > thr) {
                 const uint32_t slot = atomicAdd(&ctl[3], 1u);
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ pre
         // ties in index order: chunked ordered scan, stop once `need` were taken
         int taken = 0;
         const int lane = tid & 63, wave = tid >> 6;
-        for (int base = 0; base < I && taken < need; base += 256) {
+        for (int base = 0; base < I && taken < need; base += NT) {
             const int i = base + tid;
             const bool f = (i < I) && (KEY(i) == thr);
             const unsigned long long bal = __ballot(f);
@@ -162,7 +164,8 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ pre
             __syncthreads();
             int before = 0;
             for (int w = 0; w < wave; ++w) before += (int)ctl[4 + w];
-            const int total = (int)(ctl[4] + ctl[5] + ctl[6] + ctl[7]);
+            int total = 0;
+            for (int w = 0; w < NT / 64; ++w) total += (int)ctl[4 + w];
             const int rank = taken + before + (int)__popcll(bal & ((1ull << lane) - 1ull));
             if (f && rank < need)
                 cand[n_gt + rank] = ((unsigned long long)thr << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)i);
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ pre
     // bitonic sort, descending
     for (int size = 2; size <= KP; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int j = tid; j < KP / 2; j += 256) {
+            for (int j = tid; j < KP / 2; j += NT) {
                 const int lo = ((j / stride) * stride * 2) + (j % stride);
                 const int hi = lo + stride;
                 const bool desc = ((lo & size) == 0);
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(256) void topk_kernel(const float* __restrict__ pre
             __syncthreads();
         }
     }
-    for (int j = tid; j < k; j += 256) {
+    for (int j = tid; j < k; j += NT) {
         const unsigned long long c = cand[j];
         idx_out[(int64_t)row_id * k + j] = (int64_t)(0xFFFFFFFFu - (uint32_t)(c & 0xFFFFFFFFull));
         if (val_out) val_out[(int64_t)row_id * k + j] = key_to_float((uint32_t)(c >> 32));
@@ -386,7 +389,7 @@ int gdmcf_topk_masked_f32(const float* pred, int64_t ldp, int B, int I, const in
     GD_CHECK_ARG((mask_indptr == nullptr) == (mask_indices == nullptr), "topk: mask indptr/indices mismatch");
     int KP = 2;
     while (KP < k) KP <<= 1;
-    const size_t lds_base = (size_t)KP * 8 + (256 + 8) * 4 + (size_t)((I + 31) / 32) * 4;
+    const size_t lds_base = (size_t)KP * 8 + (256 + 24) * 4 + (size_t)((I + 31) / 32) * 4;
     const bool stage = lds_base + (size_t)I * 4 <= 150 * 1024;
     const size_t lds = lds_base + (stage ? (size_t)I * 4 : 0);
     if (lds > 160 * 1024) {
@@ -395,9 +398,9 @@ int gdmcf_topk_masked_f32(const float* pred, int64_t ldp, int B, int I, const in
     }
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(topk_kernel<true>),
+        hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_kernel<true, 1024>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(topk_kernel<false>),
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_kernel<false, 256>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e1 != hipSuccess || e2 != hipSuccess) {
             gdmcf_set_error("topk: hipFuncSetAttribute failed");
@@ -407,10 +410,10 @@ int gdmcf_topk_masked_f32(const float* pred, int64_t ldp, int B, int I, const in
     }
     GdProfScope prof(9, 4.0 * B * (double)I, (hipStream_t)stream);
     if (stage)
-        hipLaunchKernelGGL(topk_kernel<true>, dim3(B), dim3(256), lds, (hipStream_t)stream, pred, ldp, I, mask_indptr,
+        hipLaunchKernelGGL((topk_kernel<true, 1024>), dim3(B), dim3(1024), lds, (hipStream_t)stream, pred, ldp, I, mask_indptr,
                            mask_indices, k, KP, idx_out, val_out);
     else
-        hipLaunchKernelGGL(topk_kernel<false>, dim3(B), dim3(256), lds, (hipStream_t)stream, pred, ldp, I, mask_indptr,
+        hipLaunchKernelGGL((topk_kernel<false, 256>), dim3(B), dim3(256), lds, (hipStream_t)stream, pred, ldp, I, mask_indptr,
                            mask_indices, k, KP, idx_out, val_out);
     return gd_launch_status("topk");
 }
