@@ -623,8 +623,7 @@ template <int LAYA, int LAYB, int BM, int BN, int BK, int WM, int WN, int EPI>
 int launch_one(GdGemm& g, hipStream_t s) {
     using GA = TileGeom<LAYA, BM, BK>;
     using GB = TileGeom<LAYB, BN, BK>;
-    static const size_t lds_pad = getenv("GD_LDS_PAD") ? (size_t)atoi(getenv("GD_LDS_PAD")) : 0;  // occupancy experiments
-    size_t lds = (size_t)2 * (GA::FLOATS + GB::FLOATS) * sizeof(float) + lds_pad;
+    size_t lds = (size_t)2 * (GA::FLOATS + GB::FLOATS) * sizeof(float);
     // Row-contiguous x row-contiguous products (the weight gradients) run the wave-specialised kernel: measured
     // +6-7 % at 128x128 tiles on the Yelp shape, no gain or a loss for the K-contiguous products
     // (profiles/r01_spec_ab.txt).  GDMCF_GEMM_SPEC=0 switches it off for A/B runs.
