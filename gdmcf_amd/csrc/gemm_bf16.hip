@@ -375,13 +375,15 @@ int launch_one(GdGemm& g, hipStream_t s) {
 
 template <int LAYA, int LAYB, int EPI>
 int launch_class(int cls, GdGemm& g, hipStream_t s) {
-    // operands come from their bf16 shadows when both have one (classes 1 and 3: the ones the training step uses)
+    // operands come from their bf16 shadows when both have one
     const bool s16 = g.A16 != nullptr && g.B16 != nullptr;
     switch (cls) {
-        case 0: return launch_one<LAYA, LAYB, 80, 128, 1, 4, EPI, false>(g, s);
+        case 0: return s16 ? launch_one<LAYA, LAYB, 80, 128, 1, 4, EPI, true>(g, s)
+                           : launch_one<LAYA, LAYB, 80, 128, 1, 4, EPI, false>(g, s);
         case 1: return s16 ? launch_one<LAYA, LAYB, 128, 128, 2, 2, EPI, true>(g, s)
                            : launch_one<LAYA, LAYB, 128, 128, 2, 2, EPI, false>(g, s);
-        case 2: return launch_one<LAYA, LAYB, 64, 64, 2, 2, EPI, false>(g, s);
+        case 2: return s16 ? launch_one<LAYA, LAYB, 64, 64, 2, 2, EPI, true>(g, s)
+                           : launch_one<LAYA, LAYB, 64, 64, 2, 2, EPI, false>(g, s);
         case 3: return s16 ? launch_one<LAYA, LAYB, 208, 256, 1, 8, EPI, true>(g, s)
                            : launch_one<LAYA, LAYB, 208, 256, 1, 8, EPI, false>(g, s);
     }
