@@ -252,9 +252,16 @@ class DenoiserEngine:
 
     @_with_precision
     def train_backward(self, gloss):
+        """gloss: d(total)/d(loss_b) as a tensor [B] (what autograd hands over), or a Python float when every row has
+        the same upstream gradient (mean reduction: 1/B) -- then no autograd graph is needed at all."""
         sv = self._saved
+        if sv is None or sv.get("kind") != "train":
+            raise RuntimeError("gdmcf_amd: train_backward without a preceding training_losses")
         bufs = sv["bufs"]
-        rowscale = (gloss.to(torch.float32) * bufs.gradcoef).contiguous()
+        if isinstance(gloss, float):
+            rowscale = bufs.gradcoef * gloss
+        else:
+            rowscale = (gloss.to(torch.float32) * bufs.gradcoef).contiguous()
         return self._backward(sv, bufs.diff, bufs.ldi, rowscale)
 
     # ------------------------------------------------------------------------------------------
