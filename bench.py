@@ -35,7 +35,7 @@ TAGS = {1: "linear_fwd_gemm", 2: "loss_fwd_gemm", 3: "posterior_gemm", 4: "bwd_i
         6: "adamw", 7: "prep_input", 8: "spmm_csr", 9: "topk"}
 GEMM_TAGS = (1, 2, 3, 4, 5)
 # rocprofv3 kernel names of the tagged launches at the Yelp-shape workload (for the PMC traffic lookup)
-TRAFFIC_KERNEL = {"bwd_weight_gemm": "gemm_f32_spec_kernel<1, 1, 128, 128, 16, 2, 2, 4>",
+TRAFFIC_KERNEL = {"bwd_weight_gemm": "gemm_f32_spec_kernel<1, 1, 128, 128, 16, 2, 2, 4, 2>",
                   "loss_fwd_gemm": "gemm_f32_kernel<0, 0, 80, 128, 32, 1, 4, 2>",
                   "bwd_input_gemm": "gemm_f32_kernel<0, 1, 80, 128, 32, 1, 4, 0>",
                   "linear_fwd_gemm": "gemm_f32_kernel<0, 0, 80, 128, 32, 1, 4, 0>", "adamw": "adamw_kernel",
