@@ -503,10 +503,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(const int64_t* __restrict__ 
     for (int it = 0; it < ADAM_BLOCK_ELEMS / (256 * 4); ++it) {
         const int64_t i = base + (int64_t)(it * 256 + threadIdx.x) * 4;
         if (al && i + 3 < n) {
-            f32x4 pp = *reinterpret_cast<f32x4*>(p + i);
-            const f32x4 gg = *reinterpret_cast<const f32x4*>(g + i);
-            f32x4 mm = *reinterpret_cast<f32x4*>(m + i);
-            f32x4 vv = *reinterpret_cast<f32x4*>(v + i);
+            f32x4 pp = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(p + i));
+            const f32x4 gg = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(g + i));
+            f32x4 mm = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(m + i));
+            f32x4 vv = __builtin_nontemporal_load(reinterpret_cast<f32x4*>(v + i));
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float pj = pp[j], mj = mm[j], vj = vv[j];
@@ -515,9 +515,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(const int64_t* __restrict__ 
                 mm[j] = mj;
                 vv[j] = vj;
             }
-            *reinterpret_cast<f32x4*>(p + i) = pp;
-            *reinterpret_cast<f32x4*>(m + i) = mm;
-            *reinterpret_cast<f32x4*>(v + i) = vv;
+            __builtin_nontemporal_store(pp, reinterpret_cast<f32x4*>(p + i));
+            __builtin_nontemporal_store(mm, reinterpret_cast<f32x4*>(m + i));
+            __builtin_nontemporal_store(vv, reinterpret_cast<f32x4*>(v + i));
             if (p16) {
                 unsigned r = (unsigned)i / cols16, c = (unsigned)i - r * cols16;  // numel < 2^32 (checked on the host)
                 if (c + 3 < cols16) {
