@@ -83,15 +83,28 @@ __device__ __forceinline__ float temb_value(float t, int f, int E) {
 // x_t for 4 consecutive columns of one row (shared by the row-norm pass and the main pass)
 __device__ __forceinline__ void xt4(const PrepArgs& a, int b, int col, float ca, float cb, float (&v)[4]) {
     const float* xr = a.x + (int64_t)b * a.ldx;
+    if (col + 3 < a.I) {
+        // one 16-byte load (rows of the dense batch are only 4-byte aligned when I is odd: gfx950 takes that)
+        typedef f32x4 f32x4_u4 __attribute__((aligned(4)));
+        const f32x4 t4 = *reinterpret_cast<const f32x4_u4*>(xr + col);
+        v[0] = t4.x; v[1] = t4.y; v[2] = t4.z; v[3] = t4.w;
+    } else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = (col + j < a.I) ? xr[col + j] : 0.f;
+        for (int j = 0; j < 4; ++j) v[j] = (col + j < a.I) ? xr[col + j] : 0.f;
+    }
     if (a.ca) {
         float nz[4] = {0.f, 0.f, 0.f, 0.f};
         if (a.noise_mode == 1) {
             const float* nr = a.noise + (int64_t)b * a.ldn;
+            if (col + 3 < a.I) {
+                typedef f32x4 f32x4_u4 __attribute__((aligned(4)));
+                const f32x4 t4 = *reinterpret_cast<const f32x4_u4*>(nr + col);
+                nz[0] = t4.x; nz[1] = t4.y; nz[2] = t4.z; nz[3] = t4.w;
+            } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (col + j < a.I) nz[j] = nr[col + j];
+                for (int j = 0; j < 4; ++j)
+                    if (col + j < a.I) nz[j] = nr[col + j];
+            }
         } else if (a.noise_mode == 2) {
             const uint4 r = philox4x32_10(make_uint4((uint32_t)(col >> 2), (uint32_t)b, 0u, (uint32_t)a.offset),
                                           make_uint2((uint32_t)a.seed, (uint32_t)(a.seed >> 32)));
