@@ -159,6 +159,45 @@ class GaussianDiffusion(nn.Module):
         _lib.check(rc)
         return out[:, :I]
 
+    # -- the reference's per-step pieces, for callers that use them directly -----------------------
+    # (p_sample itself runs them fused into the last layer's epilogue: gdmcf_linear_posterior_fwd_f32)
+    def _predict_xstart_from_eps(self, x_t, t, eps):
+        """reference :518-523"""
+        assert x_t.shape == eps.shape
+        _lib.require_gpu(x_t, "x_t")
+        return (self._extract_into_tensor(self.sqrt_recip_alphas_cumprod, t, x_t.shape) * x_t
+                - self._extract_into_tensor(self.sqrt_recipm1_alphas_cumprod, t, x_t.shape) * eps)
+
+    def q_posterior_mean_variance(self, x_start, x_t, t):
+        """q(x_{t-1} | x_t, x_0): (mean, variance, clipped log variance), reference :451-471"""
+        assert x_start.shape == x_t.shape
+        _lib.require_gpu(x_t, "x_t")
+        posterior_mean = (self._extract_into_tensor(self.posterior_mean_coef1, t, x_t.shape) * x_start
+                          + self._extract_into_tensor(self.posterior_mean_coef2, t, x_t.shape) * x_t)
+        posterior_variance = self._extract_into_tensor(self.posterior_variance, t, x_t.shape)
+        posterior_log_variance_clipped = self._extract_into_tensor(self.posterior_log_variance_clipped, t, x_t.shape)
+        assert (posterior_mean.shape[0] == posterior_variance.shape[0] == posterior_log_variance_clipped.shape[0]
+                == x_start.shape[0])
+        return posterior_mean, posterior_variance, posterior_log_variance_clipped
+
+    def p_mean_variance(self, model, x, t):
+        """One reverse step's distribution parameters, reference :473-515 (the denoiser forward is the HIP path)."""
+        B, C = x.shape[:2]
+        assert t.shape == (B,)
+        model_output = model(x, t)
+        model_variance = self._extract_into_tensor(self.posterior_variance, t, x.shape)
+        model_log_variance = self._extract_into_tensor(self.posterior_log_variance_clipped, t, x.shape)
+        if self.mean_type == ModelMeanType.START_X:
+            pred_xstart = model_output
+        elif self.mean_type == ModelMeanType.EPSILON:
+            pred_xstart = self._predict_xstart_from_eps(x, t, eps=model_output)
+        else:
+            raise NotImplementedError(self.mean_type)
+        model_mean, _, _ = self.q_posterior_mean_variance(x_start=pred_xstart, x_t=x, t=t)
+        assert model_mean.shape == model_log_variance.shape == pred_xstart.shape == x.shape
+        return {"mean": model_mean, "variance": model_variance, "log_variance": model_log_variance,
+                "pred_xstart": pred_xstart}
+
     # -- training ------------------------------------------------------------------------------
     def training_losses(self, model, x_start, reweight=False, index=None, *, ts=None, pt=None, noise=None,
                         drop_mask=None):

@@ -125,6 +125,37 @@ def test_bf16_mode_on_every_reference_configuration(case):
     assert model.engine.buffers(meta["B"], torch.device(DEV)).shadows is not None  # the shadow path is what ran
 
 
+@pytest.mark.parametrize("case", ["tiny_x0", "tiny_eps"])
+def test_per_step_methods_match_oracle(case):
+    """The reference's per-step methods (p_mean_variance :473-515, q_posterior_mean_variance :451-471,
+    _predict_xstart_from_eps :518-523) exist with the reference's names and results; p_sample fuses them, these
+    are for callers that use them directly."""
+    fx = H.load("train_" + case)
+    meta = H.train_meta(fx)
+    model = gpu_model(meta, fx).eval()
+    diff = gpu_diffusion(meta)
+    om = O.DNN([meta["I"]] + meta["dims"], meta["dims"][::-1] + [meta["I"]], 10)
+    om.load_state_dict(H.state_dict_from(fx))
+    om.eval()
+    omt = {"x0": O.ModelMeanType.START_X, "eps": O.ModelMeanType.EPSILON}[meta["mean_type"]]
+    od = O.GaussianDiffusion(omt, meta.get("schedule", "linear-var"), meta["scale"], meta["nmin"], meta["nmax"], meta["T"])
+    inp = H.step_inputs(fx, 0)
+    x, t = inp["x"] + 0.1 * inp["noise"], inp["ts"]
+    with torch.no_grad():
+        got = diff.p_mean_variance(model, cu(x), cu(t))
+        want = od.p_mean_variance(om, x, t)
+    for k in ("mean", "variance", "log_variance", "pred_xstart"):
+        np.testing.assert_allclose(got[k].cpu().numpy(), want[k].numpy(), rtol=2e-5, atol=1e-6, err_msg=k)
+    m2 = diff.q_posterior_mean_variance(cu(inp["x"]), cu(x), cu(t))
+    w2 = od.q_posterior_mean_variance(inp["x"], x, t)
+    for a, b in zip(m2, w2):
+        np.testing.assert_array_equal(a.cpu().numpy(), b.numpy())  # elementwise f32 on the same tables
+    np.testing.assert_array_equal(diff._predict_xstart_from_eps(cu(x), cu(t), cu(inp["noise"])).cpu().numpy(),
+                                  od._predict_xstart_from_eps(x, t, inp["noise"]).numpy())
+    with pytest.raises(AssertionError):
+        diff.p_mean_variance(model, cu(x), cu(t[:-1]))
+
+
 def test_plain_forward_backward_matches_oracle():
     """model(x, t) + autograd through the HIP kernels vs the oracle's eager autograd."""
     fx = H.load("train_ragged_x0")
