@@ -69,13 +69,19 @@ class GaussianDiffusion(nn.Module):
         if noise_scale != 0.0:
             if noise_schedule not in _SCHEDULE_KIND:
                 raise NotImplementedError(f"unknown beta schedule: {noise_schedule}!")
-            tabs = _lib.schedule_tables(_SCHEDULE_KIND[noise_schedule], noise_scale, noise_min, noise_max, steps,
-                                        beta_fixed)
-            for name, row in zip(_lib.TABLE_NAMES, tabs):
-                setattr(self, name, torch.from_numpy(row.copy()).to(self.device))
-            self._derive_tables()
+            self.beta_fixed = beta_fixed
+            self.calculate_for_diffusion()
 
     # -- tables -----------------------------------------------------------------------------
+    def calculate_for_diffusion(self):
+        """All float64 schedule tables of the reference (:132-159: alphas_cumprod(_prev/_next), their roots and logs,
+        posterior variance / clipped log variance / mean coefficients), built by gdmcf_schedule_build."""
+        tabs = _lib.schedule_tables(_SCHEDULE_KIND[self.noise_schedule], self.noise_scale, self.noise_min, self.noise_max,
+                                    self.steps, self.beta_fixed)
+        for name, row in zip(_lib.TABLE_NAMES, tabs):
+            setattr(self, name, torch.from_numpy(row.copy()).to(self.device))
+        self._derive_tables()
+
     def get_betas(self):
         kind = _SCHEDULE_KIND.get(self.noise_schedule)
         if kind is None:
