@@ -226,8 +226,8 @@ def main():
                                           "compulsory bytes per launch (operands and results once; AdamW 28 B/param)"))
 
     spmm = None
-    if args.spmm and rank == 0:
-        spmm = bench_spmm(gdmcf_amd, lib, args.workload, dev)
+    if args.spmm and (rank == 0 or world > 1):
+        spmm = bench_spmm(gdmcf_amd, lib, args.workload, dev, world=world)  # world > 1: row-sharded, collective
 
     sampling = None
     if args.sampling and rank == 0:
@@ -294,14 +294,18 @@ def bench_sampling(gdmcf_amd, lib, model, diffusion, x, indptr, indices, dev, it
     return out
 
 
-def bench_spmm(gdmcf_amd, lib, workload, dev, layers=3, d=64, iters=20):
+def bench_spmm(gdmcf_amd, lib, workload, dev, layers=3, d=64, iters=20, world=1):
     """LightGCN propagation over the whole synthetic graph: ms per layer and HBM-roofline fraction
-    (algorithmic bytes = nnz*8 + (N+1)*8 + 2*N*d*4; rowptr is int64 here)."""
+    (algorithmic bytes = nnz*8 + (N+1)*8 + 2*N*d*4; rowptr is int64 here).  With world > 1 the adjacency is
+    row-sharded over the ranks (LightGCN(shard_rows=True): local SpMM + all-gather per layer); `ms_per_layer` then is
+    the SpMM kernel of this rank's block, `ms_per_propagation` the wall time of all layers including the all-gathers."""
     from gdmcf_amd import data
     cfg = data.SHAPES[workload]
     indptr, indices, I = data.synth_csr(workload, seed=0)
     users = np.repeat(np.arange(cfg["n_users"]), np.diff(indptr))
-    m = gdmcf_amd.LightGCN({"user_id_idx": users, "item_id_idx": indices}, cfg["n_users"], I, layers, d, device=dev).to(dev)
+    torch.manual_seed(0)  # identical E0 on every rank
+    m = gdmcf_amd.LightGCN({"user_id_idx": users, "item_id_idx": indices}, cfg["n_users"], I, layers, d, device=dev,
+                           shard_rows=world > 1).to(dev)
     nnz = m.nnz
     N = cfg["n_users"] + I
     torch.set_grad_enabled(False)
@@ -309,16 +313,19 @@ def bench_spmm(gdmcf_amd, lib, workload, dev, layers=3, d=64, iters=20):
         m.propagate_through_layers()
     torch.cuda.synchronize()
     lib.gdmcf_prof_enable(1)
+    t0 = time.perf_counter()
     for _ in range(iters):
         m.propagate_through_layers()
     torch.cuda.synchronize()
+    wall_ms = (time.perf_counter() - t0) * 1e3 / iters
     k = collect_prof(lib).get(8)
     lib.gdmcf_prof_enable(0)
     torch.set_grad_enabled(True)
     ms = k["ms"] / k["n"]
     alg = m.algorithmic_bytes()
     gbps = alg / (ms * 1e-3) / 1e9
-    return dict(ms_per_layer=round(ms, 4), nnz=nnz, nodes=N, d=d, algorithmic_MB=round(alg / 1e6, 2),
+    return dict(ms_per_layer=round(ms, 4), ms_per_propagation=round(wall_ms, 4), row_shards=world, nnz=nnz, nodes=N, d=d,
+                algorithmic_MB=round(alg / 1e6, 2),
                 achieved=round(gbps, 1), peak=PEAK_HBM_GBPS, unit="GB/s", frac=round(gbps / PEAK_HBM_GBPS, 4), bound="hbm")
 
 

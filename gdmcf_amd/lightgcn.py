@@ -75,9 +75,19 @@ def spmm_plan(indptr, chunk=SPMM_CHUNK, short=SPMM_SHORT, d=64):
 
 
 class LightGCN(nn.Module):
-    def __init__(self, data, n_users, n_items, n_layers, latent_dim, device="cuda"):
-        """data: DataFrame/dict with `user_id_idx` / `item_id_idx` columns (reference :147)."""
+    def __init__(self, data, n_users, n_items, n_layers, latent_dim, device="cuda", shard_rows=False, group=None):
+        """data: DataFrame/dict with `user_id_idx` / `item_id_idx` columns (reference :147).
+
+        shard_rows (new, multi-GPU; the reference is single-device): every rank of `group` keeps only a contiguous
+        block of ceil(N/world) rows of the normalised adjacency.  A layer is then a local SpMM on the full embedding
+        table of the previous layer plus an all-gather of the row blocks (N*d*4/world bytes per rank per layer over
+        xGMI); the backward pass all-reduces the cotangent first -- propagation is linear, so sum_r A~^l g_r =
+        A~^l sum_r g_r -- which makes E0.grad the SUM over ranks already (do not all-reduce it again)."""
         super().__init__()
+        import torch.distributed as dist
+        self._group = group
+        self._world = dist.get_world_size(group) if (shard_rows and dist.is_initialized()) else 1
+        self._rank = dist.get_rank(group) if self._world > 1 else 0
         self.data = data
         self.n_users, self.n_items = n_users, n_items
         self.n_layers, self.latent_dim = n_layers, latent_dim
@@ -95,6 +105,14 @@ class LightGCN(nn.Module):
                                                          np.asarray(self.data["item_id_idx"]), self.n_users,
                                                          self.n_items)
         dev = self._device
+        N = self.n_users + self.n_items
+        rpr = -(-N // self._world)  # rows per rank
+        r0 = min(self._rank * rpr, N)
+        r1 = min(r0 + rpr, N)
+        self._rows = (r0, r1, rpr)
+        if self._world > 1:
+            lo, hi = int(indptr[r0]), int(indptr[r1])
+            indptr, indices, vals = indptr[r0:r1 + 1] - indptr[r0], indices[lo:hi], vals[lo:hi]
         plan = spmm_plan(indptr, d=self.latent_dim)
         self._plan = {k: (torch.from_numpy(v).to(dev) if isinstance(v, np.ndarray) else v) for k, v in plan.items()}
         self._partial = torch.empty(max(plan["n_slots"], 1), self.latent_dim, dtype=torch.float32, device=dev)
@@ -104,7 +122,8 @@ class LightGCN(nn.Module):
     def algorithmic_bytes(self):
         """Compulsory HBM bytes of one layer: CSR once, X once, Y once."""
         N, d = self.n_users + self.n_items, self.latent_dim
-        return self.nnz * 8.0 + (N + 1) * 8.0 + 2.0 * N * d * 4.0
+        rows = self._rows[1] - self._rows[0]  # this rank's block: CSR once, X once, its rows of Y once
+        return self.nnz * 8.0 + (rows + 1) * 8.0 + (N + rows) * d * 4.0
 
     @torch.no_grad()
     def _propagate(self, X, return_layers=False):
@@ -118,17 +137,24 @@ class LightGCN(nn.Module):
         cur = X.contiguous()
         layers = [cur]
         nv, nl = pl["vrow"].numel(), pl["lrow"].numel()
+        r0, r1, rpr = self._rows
+        sharded = self._world > 1
         for layer in range(self.n_layers):
             last = (layer == self.n_layers - 1) and not return_layers
-            out = torch.empty_like(cur)
+            out = torch.zeros(rpr, d, dtype=cur.dtype, device=cur.device) if sharded else torch.empty_like(cur)
             adds = layers if last else []
-            arr = (ctypes.c_void_p * max(len(adds), 1))(*[a.data_ptr() for a in adds])
-            _lib.check(lib.gdmcf_spmm_csr_f32(
-                pl["vbeg"].data_ptr(), pl["vend"].data_ptr(), pl["vrow"].data_ptr(), pl["vslot"].data_ptr(), nv,
-                pl["n_short"], _lib.ptr(pl["lrow"]) if nl else None,
-                _lib.ptr(pl["lptr"]) if nl else None, nl, indices.data_ptr(), vals.data_ptr(), N, cur.data_ptr(),
-                cur.stride(0), d, out.data_ptr(), out.stride(0), self._partial.data_ptr(), arr, len(adds),
-                cur.stride(0), 1.0 / (self.n_layers + 1) if last else 1.0, self.algorithmic_bytes(), st))
+            # the fused layer mean reads this rank's rows of the earlier layers
+            arr = (ctypes.c_void_p * max(len(adds), 1))(*[a.data_ptr() + r0 * a.stride(0) * 4 for a in adds])
+            if r1 > r0:
+                _lib.check(lib.gdmcf_spmm_csr_f32(
+                    pl["vbeg"].data_ptr(), pl["vend"].data_ptr(), pl["vrow"].data_ptr(), pl["vslot"].data_ptr(), nv,
+                    pl["n_short"], _lib.ptr(pl["lrow"]) if nl else None,
+                    _lib.ptr(pl["lptr"]) if nl else None, nl, indices.data_ptr(), vals.data_ptr(), r1 - r0,
+                    cur.data_ptr(), cur.stride(0), d, out.data_ptr(), out.stride(0), self._partial.data_ptr(), arr,
+                    len(adds), cur.stride(0), 1.0 / (self.n_layers + 1) if last else 1.0, self.algorithmic_bytes(), st))
+            if sharded:
+                from .parallel import all_gather_rows
+                out = all_gather_rows(out, N, self._group)
             layers.append(out)
             cur = out
         if return_layers:
@@ -169,7 +195,13 @@ class _PropagateMean(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return None, ctx.module._propagate(g.contiguous())[0]
+        m = ctx.module
+        g = g.contiguous()
+        if m._world > 1:  # row-sharded: propagate the SUM of all ranks' cotangents (linearity), see LightGCN.__init__
+            from .parallel import _all_reduce
+            g = g.clone()
+            _all_reduce(g, m._group)
+        return None, m._propagate(g)[0]
 
 
 def bpr_loss(users, users_emb, pos_emb, neg_emb, userEmb0, posEmb0, negEmb0):

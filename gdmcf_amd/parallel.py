@@ -30,6 +30,20 @@ def _all_reduce(t, group, async_op=False):
     return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
 
 
+def all_gather_rows(local, n_total, group=None):
+    """[rows_per_rank, d] blocks of every rank, concatenated in rank order and cut to n_total rows (row-sharded
+    LightGCN propagation: every rank needs the full embedding table of the previous layer)."""
+    world = dist.get_world_size(group)
+    if local.is_cuda and _host_staged(group):
+        h = local.cpu()
+        parts = [torch.empty_like(h) for _ in range(world)]
+        dist.all_gather(parts, h, group=group)
+        return torch.cat(parts)[:n_total].to(local.device)
+    out = torch.empty(world * local.shape[0], local.shape[1], dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+    return out[:n_total]
+
+
 def allreduce_grads(params, group=None, bucket_bytes=256 << 20):
     """In-place SUM all-reduce of .grad over ranks.  Large tensors go alone (no copy); small ones are
     coalesced into one flat bucket.  xGMI is point-to-point, so few, large messages are preferred."""
