@@ -76,6 +76,7 @@ def parse():
     ap.add_argument("--fuse-optimizer", action="store_true",
                     help="single GPU: update the two large weights inside the weight-gradient GEMM epilogue "
                          "(FusedAdamW.fuse_into_backward); same update rule, gradient never materialised")
+    ap.add_argument("--bpr", action="store_true", help="also time a LightGCN BPR training step (reported under 'bpr')")
     ap.add_argument("--sampling", action="store_true", help="also time p_sample + masked top-k (reported under 'sampling')")
     return ap.parse_args()
 
@@ -229,6 +230,10 @@ def main():
     if args.spmm and (rank == 0 or world > 1):
         spmm = bench_spmm(gdmcf_amd, lib, args.workload, dev, world=world)  # world > 1: row-sharded, collective
 
+    bpr = None
+    if args.bpr and rank == 0:
+        bpr = bench_bpr(gdmcf_amd, args.workload, dev)
+
     sampling = None
     if args.sampling and rank == 0:
         sampling = bench_sampling(gdmcf_amd, lib, model, diffusion, x_dev[0], sub_ptr[:B + 1], sub_idx, dev)
@@ -259,6 +264,8 @@ def main():
             out["spmm"] = spmm
         if sampling:
             out["sampling"] = sampling
+        if bpr:
+            out["bpr"] = bpr
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
@@ -327,6 +334,41 @@ def bench_spmm(gdmcf_amd, lib, workload, dev, layers=3, d=64, iters=20, world=1)
     return dict(ms_per_layer=round(ms, 4), ms_per_propagation=round(wall_ms, 4), row_shards=world, nnz=nnz, nodes=N, d=d,
                 algorithmic_MB=round(alg / 1e6, 2),
                 achieved=round(gbps, 1), peak=PEAK_HBM_GBPS, unit="GB/s", frac=round(gbps / PEAK_HBM_GBPS, 4), bound="hbm")
+
+
+def bench_bpr(gdmcf_amd, workload, dev, layers=3, d=64, batch=1024, iters=20):
+    """One LightGCN BPR training step (reference lightGCN.py:291-298): propagate over the whole graph (3 SpMM layers),
+    gather the batch rows, BPR + regularisation loss, backward (the same propagation on the gradient), Adam."""
+    from gdmcf_amd import data
+    from gdmcf_amd.lightgcn import bpr_loss, sample_bpr_batch
+    cfg = data.SHAPES[workload]
+    indptr, indices, I = data.synth_csr(workload, seed=0)
+    U = cfg["n_users"]
+    users = np.repeat(np.arange(U), np.diff(indptr))
+    torch.manual_seed(0)
+    m = gdmcf_amd.LightGCN({"user_id_idx": users, "item_id_idx": indices}, U, I, layers, d, device=dev).to(dev)
+    opt = torch.optim.Adam(m.parameters(), lr=0.005)
+    rng = np.random.default_rng(0)
+    batches = [[torch.from_numpy(a).to(dev) for a in sample_bpr_batch(indptr, indices, U, I, batch, rng)] for _ in range(4)]
+
+    def step(i):
+        bu, bp, bn = batches[i % 4]
+        opt.zero_grad()
+        out = m(bu, bp, bn)
+        mf, reg = bpr_loss(bu, *out)
+        (mf + 1e-4 * reg).backward()
+        opt.step()
+        return mf
+
+    for i in range(3):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(iters):
+        mf = step(i)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3 / iters
+    return dict(ms_per_step=round(ms, 4), batch=batch, layers=layers, d=d, nodes=U + I, nnz=m.nnz, loss=float(mf))
 
 
 if __name__ == "__main__":
