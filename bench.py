@@ -38,7 +38,7 @@ GEMM_TAGS = (1, 2, 3, 4, 5)
 TRAFFIC_KERNEL = {"bwd_weight_gemm": "gemm_f32_spec_kernel<1, 1, 128, 128, 16, 2, 2, 4, 2>",
                   "loss_fwd_gemm": "gemm_f32_kernel<0, 0, 80, 128, 32, 1, 4, 2>",
                   "bwd_input_gemm": "gemm_f32_kernel<0, 1, 80, 128, 32, 1, 4, 0>",
-                  "linear_fwd_gemm": "gemm_f32_kernel<0, 0, 80, 128, 32, 1, 4, 0>", "adamw": "adamw_kernel",
+                  "linear_fwd_gemm": "gemm_f32_kernel<0, 0, 80, 128, 32, 1, 4, 0>", "adamw": "adamw_kernel<true>",
                   "prep_input": "prep_input_kernel"}
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_final_hbm_traffic.json")
 
