@@ -903,3 +903,31 @@ def test_fused_optimizer_row_epilogue_matches_separate_pass(shape, dtype):
         for w in (m1.in_layers[0].weight, m1.out_layers[0].weight):
             sh = m1.engine._wshadow[id(w)][0]
             assert torch.equal(sh.buf[:sh.rows, :sh.cols], w.detach().bfloat16())
+
+
+def test_bench_emits_the_contract_line():
+    """bench.py prints ONE JSON line with the driver's contract fields, the roofline object of the dominant kernel
+    (HIP-event timing inside the run) and, with the default flags, a cpu_baseline object."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "8", "--warmup", "2", "--cpu-seconds", "1"],
+                       capture_output=True, text=True, cwd=root, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"] == "training users/sec" and d["unit"] == "users/s" and d["n_gpus"] == 1 and d["steps"] == 8
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    ro = d["roofline"]
+    assert ro["bound"] in ("hbm", "mfma") and ro["unit"] in ("GB/s", "TFLOP/s") and 0 < ro["frac"] < 1
+    assert abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-3 and (ro["traffic"] is None or ro["traffic"] > 0)
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    assert abs(d["value"] - 400 * 8 / (d["ms_per_step"] * 8e-3)) / d["value"] < 1e-3
