@@ -63,6 +63,8 @@ def parse():
     ap.add_argument("--workload", default="yelp", choices=["yelp", "amazon-book", "stress"])
     ap.add_argument("--T", type=int, default=5, help="diffusion steps")
     ap.add_argument("--batch", type=int, default=400)
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="strong scaling: split this many rows over the ranks (per-rank batch = G / N) instead of --batch per rank")
     ap.add_argument("--hidden", type=int, default=1000)
     ap.add_argument("--gemm-dtype", default="f32", choices=["f32", "bf16"],
                     help="input precision of the denoiser GEMMs (bf16 = BASELINE configs[2]; f32 is the parity path)")
@@ -104,6 +106,7 @@ def cpu_baseline(args, I, x_batches, seconds):
     opt = O.make_optimizer(om, 1e-5)
     om.train()
     xs = [torch.from_numpy(b) for b in x_batches[:2]]
+    Bc = xs[0].shape[0]
     O.train_step(od, om, opt, xs[0], True)  # warm-up (allocations, thread pool)
     n, t0 = 0, time.perf_counter()
     while True:
@@ -112,8 +115,8 @@ def cpu_baseline(args, I, x_batches, seconds):
         el = time.perf_counter() - t0
         if (el >= seconds and n >= 3) or n >= 50:
             break
-    return dict(value=round(args.batch * n / el, 2), unit="users/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{n} train steps of B={args.batch}, I={I}, dims=[{args.hidden}], T={args.T} (oracle, PyTorch-CPU eager)",
+    return dict(value=round(Bc * n / el, 2), unit="users/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{n} train steps of B={Bc}, I={I}, dims=[{args.hidden}], T={args.T} (oracle, PyTorch-CPU eager)",
                 ms_per_step=round(1e3 * el / n, 2))
 
 
@@ -136,6 +139,11 @@ def main():
     lib = _lib.load()
 
     B, hid, T = args.batch, args.hidden, args.T
+    strong = args.global_batch > 0
+    if strong:
+        if args.global_batch % world:
+            raise SystemExit("--global-batch must be divisible by the number of ranks")
+        B = args.global_batch // world
     n_pool = 4
     indptr, indices, I = data.synth_csr(args.workload, n_rows=(world * n_pool) * B, seed=0)
     lo = rank * n_pool * B
@@ -247,7 +255,7 @@ def main():
         out = {
             "metric": "training users/sec", "value": round(users / el, 1), "unit": "users/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.gemm_dtype, "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": args.gemm_dtype, "data": "synthetic",
             "config": {"workload": f"{args.workload}-shape synthetic rows, batch={B}/GPU, dims=[{hid}], T={T}, "
                                    f"noise_scale=0.01, linear-var, mean_type=x0, reweight, AdamW lr=1e-5"
                                    + (" (BASELINE configs[1])" if args.workload == "yelp" and T == 5 and hid == 1000
