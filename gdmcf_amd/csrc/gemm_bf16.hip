@@ -1,10 +1,13 @@
 // bf16-input GEMM core on v_mfma_f32_16x16x32_bf16 (BASELINE config "bf16 denoiser GEMM on MFMA").
 //
 // Same products, operand descriptions, tile classes, split-K scheme and epilogues as gemm_f32.hip; only the
-// arithmetic of the inner product changes: both operands are rounded to bfloat16 (round-to-nearest-even,
-// v_cvt_pk_bf16_f32) on their way from global memory to LDS and multiplied on the bf16 matrix pipe with f32
-// accumulation.  Sources stay float32 in HBM (master weights, activations, gradients): nothing else in the
-// library changes layout, and the optimiser keeps working on f32 state.
+// arithmetic of the inner product changes: both operands are bfloat16 (round-to-nearest-even of the float32
+// values) multiplied on the bf16 matrix pipe with f32 accumulation.  The float32 tensors in HBM stay authoritative
+// (master weights, activations, gradients, optimiser state).  Two operand sources, same results bit for bit:
+//   * bf16 shadows (gdmcf_bf16_shadow_set, kept in sync by the producing kernels): streamed as they are, no
+//     conversion, half the bytes; their zero padding replaces every K-tail / edge predicate (Stage16);
+//   * the float32 tensors themselves, rounded with v_cvt_pk_bf16_f32 on the way to LDS (Stage) -- the fallback when
+//     an operand has no shadow.
 //
 // LDS image (both operands, whatever their global layout): rows of 64 bf16 = 128 bytes, eight 16-byte slots,
 // slot s of row r stored at s ^ ((r >> 1) & 7) -- byte-for-byte the access pattern of gemm_f32.hip's
