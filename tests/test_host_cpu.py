@@ -180,3 +180,49 @@ def test_bf16_shadow_registry_and_gemm_precision_are_host_side_state():
         _lib.check(lib.gdmcf_bf16_shadow_sync(pf + 4, 4, None))
     _lib.check(lib.gdmcf_bf16_shadow_clear(pf))
     assert _lib.shadow_info(pf) is None
+
+
+@pytest.mark.parametrize("d", [64, 20])
+def test_spmm_plan_covers_every_nonzero_once(d):
+    """Host-built execution plan of gdmcf_spmm_csr_f32 (gdmcf_amd/lightgcn.py:spmm_plan): emulate in numpy exactly
+    what the kernels do with it -- whole short rows, pieces of long rows, slot-ordered combination of cut rows --
+    and compare with the CSR product; also the invariants the kernels rely on.  Includes empty rows, a hub row cut
+    into many pieces, a row of exactly `chunk` nonzeros, and a width without the short-row path (d = 20)."""
+    import scipy.sparse as sp
+    from gdmcf_amd.lightgcn import spmm_plan
+    rng = np.random.default_rng(0)
+    n, m, chunk, short = 300, 120, 16, 5
+    deg = rng.integers(0, 12, n)
+    deg[7], deg[8], deg[9], deg[200] = 0, 119, chunk, short  # empty, hub, exactly one chunk, short-limit row
+    rows = np.repeat(np.arange(n), deg)
+    cols = np.concatenate([rng.choice(m, k, replace=False) for k in deg]) if deg.sum() else np.zeros(0, int)
+    A = sp.csr_matrix((rng.standard_normal(len(rows)), (rows, cols)), shape=(n, m))
+    A.sort_indices()
+    X = rng.standard_normal((m, d))
+    pl = spmm_plan(A.indptr, chunk=chunk, short=short, d=d)
+    nv = len(pl["vrow"])
+    assert len(pl["vbeg"]) == len(pl["vend"]) == len(pl["vslot"]) == nv
+    # every nonzero belongs to exactly one virtual row, pieces never exceed the chunk, short rows come first, whole
+    cover = np.zeros(A.nnz, int)
+    for b, e in zip(pl["vbeg"], pl["vend"]):
+        cover[b:e] += 1
+    assert (cover == 1).all()
+    ns = pl["n_short"]
+    assert (d == 20 and ns == 0) or (d == 64 and ns == int((np.diff(A.indptr) <= short).sum()))
+    assert (pl["vslot"][:ns] == -1).all() and ((pl["vend"] - pl["vbeg"])[ns:] <= chunk).all()
+    assert (pl["vbeg"][:ns] == A.indptr[pl["vrow"][:ns]]).all() and (pl["vend"][:ns] == A.indptr[pl["vrow"][:ns] + 1]).all()
+    # emulate: direct rows write Y, cut rows write partial slots that are added in slot order
+    Y = np.zeros((n, d))
+    partial = np.zeros((max(pl["n_slots"], 1), d))
+    for v in range(nv):
+        acc = np.zeros(d)
+        for j in range(pl["vbeg"][v], pl["vend"][v]):
+            acc += A.data[j] * X[A.indices[j]]
+        if pl["vslot"][v] < 0:
+            Y[pl["vrow"][v]] = acc
+        else:
+            partial[pl["vslot"][v]] = acc
+    for i, r in enumerate(pl["lrow"]):
+        Y[r] = partial[pl["lptr"][i]:pl["lptr"][i + 1]].sum(0)
+    np.testing.assert_allclose(Y, A @ X, rtol=1e-12, atol=1e-12)
+    assert 8 in pl["lrow"] and 9 not in pl["lrow"] and len(pl["lptr"]) == len(pl["lrow"]) + 1  # only cut rows combine
