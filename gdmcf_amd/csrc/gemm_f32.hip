@@ -593,15 +593,29 @@ __global__ __launch_bounds__(2 * NTHREADS, 4) void gemm_f32_spec_kernel(const Gd
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef GD_STAMP  // tools/gemm_probe.hip diagnostic build only (-DGD_STAMP): s_memtime stamps of one wave of every 269th
+                 // workgroup into g.rowpart -- per k-step: 0 after the barrier, 1 fragments in registers, 2 MFMAs issued,
+                 // 3 barrier passed.  The forced lgkmcnt(0) makes this build ~15 % slower than the real kernel.
+    unsigned long long* stamp_buf = reinterpret_cast<unsigned long long*>(g.rowpart);
+    const int stamp_slot = (stamp_buf && (blockIdx.x % 269) == 0 && tid == 0) ? (int)(blockIdx.x / 269) : -1;
+#define GD_ST(K) do { if (stamp_slot >= 0 && it < 32) stamp_buf[(stamp_slot * 32 + it) * 4 + (K)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define GD_ST(K) ((void)0)
+#endif
     __syncthreads();
     for (int it = 0; it < nt; ++it) {
         const float* As = (it & 1) ? L1 : L0;
         const float* Bs = As + GA::FLOATS;
+        GD_ST(0);
 #pragma unroll
         for (int c = 0; c < BK / 16; ++c) {
             float fa[TM][4], fb[TN][4];
             load_frag<LAYA, BM, BK, TM>(As, wm0, c, r, q, fa);
             load_frag<LAYB, BN, BK, TN>(Bs, wn0, c, r, q, fb);
+#ifdef GD_STAMP
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            GD_ST(1);
+#endif
 #pragma unroll
             for (int sg = 0; sg < 4; ++sg)
 #pragma unroll
@@ -610,8 +624,11 @@ __global__ __launch_bounds__(2 * NTHREADS, 4) void gemm_f32_spec_kernel(const Gd
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][sg], fb[j][sg], acc[i][j], 0, 0, 0);
         }
+        GD_ST(2);
         __syncthreads();
+        GD_ST(3);
     }
+#undef GD_ST
     if constexpr (EPI == GD_EPI_ADAMW)  // plain stores measured faster without the LDS round trip (0.260 vs 0.280 ms)
         gemm_epilogue_rows<BM, BN, TM, TN, WAVES_M, WAVES_N, EPI, spec_lds_floats<LAYA, LAYB, BM, BN, BK, WAVES_M, EPI>(),
                            NTHREADS>(acc, g, m0, n0, wn0, r, q, wave, tid, smem);

@@ -45,6 +45,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&dW1, (size_t)H * (I + E) * 4));
     CK(hipMalloc(&dW2, (size_t)I * H * 4));
     CK(hipMalloc(&rowpart, (size_t)B * 1024 * 4));
+    CK(hipMemset(rowpart, 0, (size_t)B * 1024 * 4));
     std::vector<float> init((size_t)I * H);
     srand(1);
     for (auto& v : init) v = (rand() / (float)RAND_MAX - 0.5f) * 0.02f;
@@ -81,6 +82,9 @@ int main(int argc, char** argv) {
         GdGemm g = {}; g.A = diff; g.lda = ldi; g.B = h; g.ldb = ldh; g.M = I; g.N = H; g.K = B; g.splits = 1; g.m_fastest = 0;
         g.C = dW2; g.ldc = H;
         cases.push_back({"dW2 cls0  ", GD_LAY_MC, GD_LAY_MC, GD_EPI_STORE, 0, g});
+#ifdef GD_STAMP
+        g.rowpart = rowpart;  // stamp buffer (cleared below)
+#endif
         cases.push_back({"dW2 cls1  ", GD_LAY_MC, GD_LAY_MC, GD_EPI_STORE, 1, g});
     }
     {   // dW1 = dhp^T * xin
@@ -108,6 +112,25 @@ int main(int argc, char** argv) {
         ms /= reps;
         const double fl = 2.0 * c.g.M * c.g.N * c.g.K;
         printf("%s  %.4f ms  %.1f TF  (grid %d)\n", c.name, ms, fl / ms / 1e9, g.tiles_m * g.tiles_n * g.splits);
+#ifdef GD_STAMP
+        if (c.g.rowpart && c.epi == GD_EPI_STORE && c.cls == 1) {
+            std::vector<unsigned long long> st(8 * 32 * 4);
+            CK(hipMemcpy(st.data(), rowpart, st.size() * 8, hipMemcpyDeviceToHost));
+            for (int slot = 0; slot < 8; ++slot) {
+                double rd = 0, mf = 0, bar = 0, tot = 0;
+                int n = 0;
+                for (int it = 1; it < 24; ++it) {
+                    const unsigned long long* a = &st[(slot * 32 + it) * 4];
+                    const unsigned long long* nx = &st[(slot * 32 + it + 1) * 4];
+                    if (!a[0] || !nx[0]) continue;
+                    rd += (double)(a[1] - a[0]); mf += (double)(a[2] - a[1]); bar += (double)(a[3] - a[2]);
+                    tot += (double)(nx[0] - a[0]); ++n;
+                }
+                if (n) printf("  stamps wg %4d: per k-step  lds-read %.0f  mfma-issue %.0f  barrier %.0f  total %.0f  (s_memtime ticks, %d steps)\n",
+                              slot * 269, rd / n, mf / n, bar / n, tot / n, n);
+            }
+        }
+#endif
     }
     return 0;
 }
