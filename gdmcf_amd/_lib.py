@@ -31,6 +31,7 @@ _SIGNATURES = {
     "gdmcf_dnn_prep_input_f32": (c_int, [P, c_int64, P, P, P, c_int, P, c_int64, c_int, P, c_int64, c_float, c_uint64,
                                          c_uint64, c_int, P, P, c_int, c_int, c_int, P, c_int64, P, c_int64, P, P, P]),
     "gdmcf_dnn_emb_cols_f32": (c_int, [P, P, P, c_int, c_int, c_int, P, c_int64, P, P]),
+    "gdmcf_topn_metrics_f64": (c_int, [P, c_int64, c_int, P, P, P, c_int, P, P]),
     "gdmcf_gemm_precision": (c_int, [c_int]),
     "gdmcf_bf16_shadow_set": (c_int, [P, P, c_int64, c_int64, c_int64]),
     "gdmcf_bf16_shadow_clear": (c_int, [P]),

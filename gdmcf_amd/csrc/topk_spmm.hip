@@ -377,6 +377,68 @@ __global__ __launch_bounds__(256) void spmm_combine_kernel(const int32_t* __rest
     }
 }
 
+// ---- ranking metrics (reference evaluate_utils.py:6-52) -----------------------------------------------------------
+// One thread per user walks its K predicted items once, in rank order, exactly as the reference's inner loop does
+// for every N (hits, dcg += 1/log2(j+2), ideal dcg over min(|GT|, N) ranks, reciprocal rank of the first hit), and
+// emits the four per-user terms whenever j+1 reaches one of the requested cut-offs.  float64 throughout, additions
+// in the reference's order: the per-user terms are bit-identical to the Python loop; the host adds them up in user
+// order.  Ground-truth rows must have sorted column indices (binary search).
+constexpr int TOPN_MAX = 8;
+struct TopNList {
+    int n;
+    int v[TOPN_MAX];
+};
+
+__global__ __launch_bounds__(256) void topn_metrics_kernel(const int64_t* __restrict__ pred, int64_t ldp, int U,
+                                                           const int64_t* __restrict__ gt_indptr,
+                                                           const int32_t* __restrict__ gt_idx, const TopNList tn,
+                                                           double* __restrict__ out) {
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= U) return;
+    const int64_t beg = gt_indptr[u], end = gt_indptr[u + 1];
+    const int64_t len = end - beg;
+    double* o = out + (int64_t)u * tn.n * 4;
+    if (len == 0) {
+        for (int k = 0; k < tn.n * 4; ++k) o[k] = 0.0;
+        return;
+    }
+    int hits = 0, next = 0;
+    int64_t left = len;
+    double dcg = 0.0, idcg = 0.0, mrr = 0.0;
+    bool first = true;
+    const int K = tn.v[tn.n - 1];
+    for (int j = 0; j < K; ++j) {
+        const int64_t item = pred[(int64_t)u * ldp + j];
+        int64_t lo = beg, hi = end;  // lower bound of `item` in the sorted row
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if ((int64_t)gt_idx[mid] < item) lo = mid + 1;
+            else hi = mid;
+        }
+        const double gain = 1.0 / log2((double)(j + 2));
+        if (lo < end && (int64_t)gt_idx[lo] == item) {
+            dcg += gain;
+            if (first) {
+                mrr = 1.0 / ((double)j + 1.0);
+                first = false;
+            }
+            ++hits;
+        }
+        if (left > 0) {
+            idcg += gain;
+            --left;
+        }
+        if (j + 1 == tn.v[next]) {
+            const double N = (double)tn.v[next];
+            o[next * 4 + 0] = (double)hits / N;
+            o[next * 4 + 1] = (double)hits / (double)len;
+            o[next * 4 + 2] = idcg != 0.0 ? dcg / idcg : 0.0;
+            o[next * 4 + 3] = mrr;
+            ++next;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -478,6 +540,22 @@ int gdmcf_spmm_csr_f32(const int64_t* vbeg, const int64_t* vend, const int32_t* 
                                n_long, partial_ws, d, Y, ldy, add);
     }
     return gd_launch_status("spmm_csr");
+}
+
+int gdmcf_topn_metrics_f64(const int64_t* pred_idx, int64_t ldp, int U, const int64_t* gt_indptr, const int32_t* gt_indices,
+                           const int* topN_host, int n_topn, double* out, void* stream) {
+    GD_CHECK_SHAPE(U > 0 && n_topn >= 1 && n_topn <= TOPN_MAX, "topn_metrics: bad shape (1..8 cut-offs)");
+    GD_CHECK_ARG(pred_idx && gt_indptr && gt_indices && topN_host && out, "topn_metrics: null pointer");
+    TopNList tn;
+    tn.n = n_topn;
+    for (int i = 0; i < n_topn; ++i) {
+        tn.v[i] = topN_host[i];
+        GD_CHECK_ARG(tn.v[i] >= 1 && (i == 0 || tn.v[i] > tn.v[i - 1]), "topn_metrics: cut-offs must be ascending and >= 1");
+    }
+    GD_CHECK_SHAPE(ldp >= tn.v[n_topn - 1], "topn_metrics: fewer predicted items per user than the largest cut-off");
+    hipLaunchKernelGGL(topn_metrics_kernel, dim3(gd_cdiv(U, 256)), dim3(256), 0, (hipStream_t)stream, pred_idx, ldp, U,
+                       gt_indptr, gt_indices, tn, out);
+    return gd_launch_status("topn_metrics");
 }
 
 }  // extern "C"

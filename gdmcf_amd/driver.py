@@ -48,7 +48,6 @@ def evaluate(diffusion, model, data_csr, data_te, mask_his, topN, sampling_steps
     mask_his: CSR of interactions to exclude from the ranking."""
     model.eval()
     n = mask_his.shape[0]
-    target_items = [data_te[i, :].nonzero()[1].tolist() for i in range(n)]
     predict_items = []
     dcsr = data_csr if isinstance(data_csr, DeviceCSR) else DeviceCSR(data_csr, device)
     for lo in range(0, n, batch_size):
@@ -56,6 +55,6 @@ def evaluate(diffusion, model, data_csr, data_te, mask_his, topN, sampling_steps
         batch = dcsr.rows(torch.from_numpy(rows))
         prediction = diffusion.p_sample(model, batch, sampling_steps, sampling_noise)
         indptr, cols = evaluate_utils.csr_rows_to_device(mask_his, rows, device)
-        indices = masked_topk(prediction, topN[-1], indptr, cols)
-        predict_items.extend(indices.cpu().numpy().tolist())
-    return evaluate_utils.computeTopNAccuracy(target_items, predict_items, topN)
+        predict_items.append(masked_topk(prediction, topN[-1], indptr, cols))
+    # the ranked lists never leave the device; the metric terms per user are computed there too
+    return evaluate_utils.computeTopNAccuracy_device(data_te, torch.cat(predict_items), topN)

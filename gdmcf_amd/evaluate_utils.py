@@ -2,6 +2,8 @@
 device-side history-mask + top-k used by main.py:296-301."""
 import math
 
+import numpy as np
+
 import torch
 
 from . import _lib
@@ -73,6 +75,38 @@ def computeTopNAccuracy(GroundTruth, predictedIndices, topN):
         NDCG.append(round(sum_n / n_users, 4))
         MRR.append(round(sum_m / n_users, 4))
     return precision, recall, NDCG, MRR
+
+
+def computeTopNAccuracy_device(ground_truth_csr, predicted_idx, topN):
+    """computeTopNAccuracy with the per-user work on the MI355X (gdmcf_topn_metrics_f64): `ground_truth_csr` is a
+    scipy CSR (one row per predicted user), `predicted_idx` an int64 device tensor [U, >= max(topN)] as masked_topk
+    returns it.  The per-user terms are bit-identical to the Python loop; they are added up in user order on the
+    host, so the rounded results equal computeTopNAccuracy's (the reference's) exactly."""
+    import ctypes
+    from . import _lib
+    _lib.require_gpu(predicted_idx, "predicted indices")
+    topN = [int(n) for n in topN]
+    if topN != sorted(set(topN)) or not topN:
+        raise ValueError("topN must be ascending and non-empty")
+    gt = ground_truth_csr.tocsr().astype(np.float32, copy=True)
+    gt.eliminate_zeros()
+    gt.sort_indices()
+    U = gt.shape[0]
+    pred = predicted_idx if predicted_idx.dtype == torch.int64 else predicted_idx.to(torch.int64)
+    if pred.stride(-1) != 1:
+        pred = pred.contiguous()
+    assert pred.shape[0] == U and pred.shape[1] >= topN[-1], "one prediction row per ground-truth row, >= max(topN) items"
+    dev = pred.device
+    indptr = torch.from_numpy(gt.indptr.astype(np.int64)).to(dev)
+    indices = torch.from_numpy(gt.indices.astype(np.int32)).to(dev)
+    out = torch.empty(U, len(topN), 4, dtype=torch.float64, device=dev)
+    tn = (ctypes.c_int * len(topN))(*topN)
+    _lib.check(_lib.load().gdmcf_topn_metrics_f64(pred.data_ptr(), pred.stride(0), U, indptr.data_ptr(), indices.data_ptr(),
+                                                  tn, len(topN), out.data_ptr(), _lib.stream_ptr()))
+    terms = out.cpu().numpy()
+    sums = np.add.accumulate(terms, axis=0)[-1]  # sequential float64 additions in user order, as the reference's loop
+    res = [[round(float(sums[k, m]) / U, 4) for k in range(len(topN))] for m in range(4)]
+    return res[0], res[1], res[2], res[3]
 
 
 def print_results(loss, valid_result, test_result):

@@ -234,6 +234,14 @@ int gdmcf_topk_masked_f32(const float* pred, int64_t ldp, int B, int I, const in
                           const int32_t* mask_indices, int k, int64_t* idx_out, float* val_out,
                           void* stream);
 
+/* Ranking metrics of reference evaluate_utils.py:6-52 (computeTopNAccuracy) on the device: per user and per cut-off
+ * N of topN_host (ascending, at most 8) the four terms precision = hits/N, recall = hits/|GT|, NDCG = dcg/idcg,
+ * MRR = 1/(rank of the first hit), all 0 for a user with an empty ground truth -- float64, accumulated in rank order
+ * exactly as the reference's loop, written to out[U][n_topn][4].  pred_idx: [U, >= max N] item ids (row stride ldp);
+ * ground truth as CSR with sorted column indices.  The caller adds the terms up over users and divides by U.        */
+int gdmcf_topn_metrics_f64(const int64_t* pred_idx, int64_t ldp, int U, const int64_t* gt_indptr, const int32_t* gt_indices,
+                           const int* topN_host, int n_topn, double* out, void* stream);
+
 /* ---- LightGCN propagation: CSR SpMM (lightGCN.py:184-189) --------------------------------
  * Y[r,:] = ( sum_j val[j]*X[col[j],:]  +  sum_k addend_k[r,:] ) * scale
  * The adjacency is plain CSR (col int32, val float32) plus a host-built execution plan of "virtual rows"

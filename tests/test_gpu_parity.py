@@ -582,6 +582,32 @@ def test_bf16_shadows_stay_in_sync():
     check(eng._wshadow[id(model.out_layers[0].weight)][0], model.out_layers[0].weight)
 
 
+def test_device_metrics_equal_the_reference_loop():
+    """gdmcf_topn_metrics_f64 (device) == computeTopNAccuracy (the reference's Python loop, pinned by the golden
+    vectors in the CPU suite): identical 4-decimal results on random rankings incl. users with empty ground truth,
+    ground truths longer and shorter than N, hits at rank 1 and at the last rank; cut-off validation errors."""
+    import scipy.sparse as sp
+    from gdmcf_amd import evaluate_utils as EU
+    rng = np.random.default_rng(3)
+    U, I, K = 700, 900, 100
+    topN = [1, 10, 20, 50, 100]
+    dens = rng.choice([0.0, 0.002, 0.02, 0.2], size=U, p=[0.1, 0.4, 0.4, 0.1])
+    gt = sp.csr_matrix((rng.random((U, I)) < dens[:, None]).astype(np.float32))
+    pred = np.stack([rng.permutation(I)[:K] for _ in range(U)]).astype(np.int64)
+    for u in range(0, U, 7):  # plant certain hits at the first / last rank
+        row = gt[u].indices
+        if len(row):
+            pred[u, 0 if u % 2 else K - 1] = row[0]
+            pred[u] = np.concatenate([pred[u][:1], [x for x in pred[u][1:] if x != pred[u][0]], rng.permutation(I)[:5]])[:K]
+    want = EU.computeTopNAccuracy([gt[u].indices.tolist() for u in range(U)], pred.tolist(), topN)
+    got = EU.computeTopNAccuracy_device(gt, torch.from_numpy(pred).to(DEV), topN)
+    assert got == want
+    with pytest.raises(ValueError):
+        EU.computeTopNAccuracy_device(gt, torch.from_numpy(pred).to(DEV), [20, 10])
+    with pytest.raises(AssertionError):
+        EU.computeTopNAccuracy_device(gt, torch.from_numpy(pred[:, :50]).to(DEV), [10, 100])
+
+
 def test_driver_train_and_evaluate_match_oracle_loop():
     """reference main.py:327-351 + :267-310 end to end on a small synthetic problem: the HIP driver and the
     oracle loop start from the same weights, see the same batches and the same injected randomness, and must
