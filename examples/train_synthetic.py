@@ -2,6 +2,8 @@
 
     python examples/train_synthetic.py --users 8000 --epochs 3            # fp32
     python examples/train_synthetic.py --users 8000 --epochs 3 --bf16     # bf16 GEMM inputs
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        examples/train_synthetic.py --users 64000 --epochs 3               # data parallel: one process per GPU (RCCL)
 
 Synthetic users interact with popularity-skewed items (gdmcf_amd/data.py); 20 % of every user's interactions are held
 out as the test set.  Prints the mean training loss per epoch, users/s, and Precision / Recall / NDCG / MRR @ topN.
@@ -32,7 +34,14 @@ def main():
     ap.add_argument("--lr", type=float, default=1e-4)
     ap.add_argument("--bf16", action="store_true")
     args = ap.parse_args()
-    dev = torch.device("cuda:0")
+    world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    say = print if rank == 0 else (lambda *a, **k: None)
     indptr, indices, I = data.synth_csr(args.shape, n_rows=args.users, seed=0)
     U = len(indptr) - 1
     rng = np.random.default_rng(0)
@@ -40,23 +49,33 @@ def main():
     rows = np.repeat(np.arange(U), np.diff(indptr))
     mk = lambda m: sp.csr_matrix((np.ones(int(m.sum()), np.float32), (rows[m], indices[m])), shape=(U, I))
     train, test = mk(~held), mk(held)
+    # data parallel: rank r trains on the users r, r + world, ... (every step then covers `world` x batch users whose
+    # gradients are all-reduced); evaluation runs on rank 0 over all users
+    n_dp = (U // (world * args.batch)) * world * args.batch  # every rank must run the same number of steps
+    my_train = train[:n_dp][rank::world] if world > 1 else train
     torch.manual_seed(0)
     model = gdmcf_amd.DNN([I, args.hidden], [args.hidden, I], 10, time_type="cat", norm=False,
                           gemm_dtype="bf16" if args.bf16 else "f32").to(dev)
     diffusion = gdmcf_amd.GaussianDiffusion(gdmcf_amd.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, args.T, dev)
     opt = gdmcf_amd.FusedAdamW(model.parameters(), lr=args.lr, weight_decay=0.0)
     gen = torch.Generator().manual_seed(0)
+    from gdmcf_amd.parallel import DataParallelStep
+    step = DataParallelStep(diffusion, model, opt)  # broadcasts rank 0's weights when world > 1
     topN = [10, 20, 50, 100]
     for epoch in range(args.epochs):
         t0 = time.perf_counter()
-        total, count = driver.train_one_epoch(diffusion, model, opt, train, args.batch, dev, generator=gen)
+        total, count = driver.train_one_epoch(diffusion, model, opt, my_train, args.batch, dev, generator=gen, step=step)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        print(f"epoch {epoch}: mean loss {total / max(count, 1):.4f}, {count * args.batch / dt:,.0f} users/s", flush=True)
-    t0 = time.perf_counter()
-    res = driver.evaluate(diffusion, model, train, test, train, topN, 0, False, args.batch, dev)
-    print(f"evaluation of {U} users: {time.perf_counter() - t0:.2f} s")
-    print_results(None, None, res)
+        say(f"epoch {epoch}: mean loss {total / max(count, 1):.4f}, {world * count * args.batch / dt:,.0f} users/s", flush=True)
+    if rank == 0:
+        t0 = time.perf_counter()
+        res = driver.evaluate(diffusion, model, train, test, train, topN, 0, False, args.batch, dev)
+        print(f"evaluation of {U} users: {time.perf_counter() - t0:.2f} s")
+        print_results(None, None, res)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
