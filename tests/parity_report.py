@@ -1,5 +1,5 @@
 """Parity numbers in one table (what the GPU tests assert, measured): HIP path vs the committed outputs of the real
-reference (tests/golden) and vs the CPU oracle.  Run on the MI355X:  python tools/parity_report.py"""
+reference (tests/golden) and vs the CPU oracle.  Test infrastructure (it uses the oracle as the checker, like the tests).  Run on the MI355X:  python tests/parity_report.py"""
 import os
 import sys
 
