@@ -226,3 +226,19 @@ def test_spmm_plan_covers_every_nonzero_once(d):
         Y[r] = partial[pl["lptr"][i]:pl["lptr"][i + 1]].sum(0)
     np.testing.assert_allclose(Y, A @ X, rtol=1e-12, atol=1e-12)
     assert 8 in pl["lrow"] and 9 not in pl["lrow"] and len(pl["lptr"]) == len(pl["lrow"]) + 1  # only cut rows combine
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/gdmcf_hip.h is the C ABI: it must compile as C99 with nothing but the standard headers (no C++, no HIP,
+    no torch types in any signature)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    src = tmp_path / "use_header.c"
+    src.write_text('#include "%s"\nint probe(void) { return GDMCF_OK + GDMCF_GEMM_BF16; }\n' % os.path.join(ROOT, "include", "gdmcf_hip.h"))
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-c", str(src), "-o", str(tmp_path / "o.o")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "gdmcf_hip.h")).read(), flags=re.S)  # code only
+    assert "at::" not in hdr and "Tensor" not in hdr and "hipStream_t" not in hdr and "std::" not in hdr
