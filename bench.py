@@ -79,6 +79,8 @@ def parse():
                     help="single GPU: update the two large weights inside the weight-gradient GEMM epilogue "
                          "(FusedAdamW.fuse_into_backward); same update rule, gradient never materialised")
     ap.add_argument("--bpr", action="store_true", help="also time a LightGCN BPR training step (reported under 'bpr')")
+    ap.add_argument("--shard-optimizer", action="store_true",
+                    help="N > 1: reduce-scatter + AdamW on 1/N of the rows + all-gather instead of all-reduce + full AdamW")
     ap.add_argument("--sampling", action="store_true", help="also time p_sample + masked top-k (reported under 'sampling')")
     return ap.parse_args()
 
@@ -167,7 +169,7 @@ def main():
         opt.fuse_into_backward(model)
     model.train()
     torch.manual_seed(1234 + rank)
-    step = DataParallelStep(diffusion, model, opt)
+    step = DataParallelStep(diffusion, model, opt, shard_optimizer=args.shard_optimizer)
 
     def sync():
         torch.cuda.synchronize()
@@ -264,7 +266,8 @@ def main():
                                       if args.workload == "amazon-book" and args.gemm_dtype == "bf16" else ""),
                        "n_items": I, "global_batch": world * B, "parallelism": f"dp{world}"},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": klist, "final_loss": final_loss,
-            "optimizer": "FusedAdamW" + (" fused into the dW GEMM epilogues" if (args.fuse_optimizer and world == 1) else " (separate pass)"),
+            "optimizer": "FusedAdamW" + (" fused into the dW GEMM epilogues" if (args.fuse_optimizer and world == 1) else
+                                         " (row-sharded over the ranks)" if (args.shard_optimizer and world > 1) else " (separate pass)"),
         }
         if cpu:
             out["speedup_vs_cpu"] = round(out["value"] / cpu["value"], 1)

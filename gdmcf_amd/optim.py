@@ -116,6 +116,33 @@ class FusedAdamW(torch.optim.Optimizer):
         return st
 
     @torch.no_grad()
+    def step_rows(self, param, grad_rows, row0):
+        """Sharded-optimiser building block (parallel.DataParallelStep(shard_optimizer=True)): apply this step's update
+        to rows [row0, row0 + grad_rows.shape[0]) of the 2-D `param` only, with `grad_rows` (contiguous, already
+        reduced over the ranks) as their gradient.  The moments are full-size tensors of which a rank keeps just its
+        rows current.  May be called several times per step for disjoint row ranges; the following step() skips the
+        tensor (as after step_subset)."""
+        if param.dim() != 2 or not param.is_contiguous() or grad_rows.dim() != 2 or grad_rows.shape[1] != param.shape[1]:
+            raise RuntimeError("FusedAdamW.step_rows: 2-D contiguous parameter and matching gradient rows expected")
+        n = int(grad_rows.shape[0])
+        if n == 0:
+            return
+        gi, group = next((i, g) for i, g in enumerate(self.param_groups) if any(q is param for q in g["params"]))
+        st = self._init_state(param)
+        g = grad_rows if grad_rows.is_contiguous() and grad_rows.dtype == torch.float32 else grad_rows.float().contiguous()
+        C, off = param.shape[1], row0 * param.shape[1] * 4
+        row = (param.data_ptr() + off, g.data_ptr(), st["exp_avg"].data_ptr() + off, st["exp_avg_sq"].data_ptr() + off, n * C, 0)
+        table = torch.tensor([row], dtype=torch.int64).to(param.device)
+        lib = _lib.load()
+        b1, b2 = group["betas"]
+        _lib.check(lib.gdmcf_adamw_f32(table.data_ptr(), 1, (n * C + _BLOCK - 1) // _BLOCK, group["lr"], b1, b2, group["eps"],
+                                       group["weight_decay"], int(st["step"]) + 1, float(self.grad_scale), _lib.stream_ptr()))
+        self._row_tables = getattr(self, "_row_tables", [])
+        self._row_tables.append((table, g))  # alive until the stream has consumed them (dropped at the next step())
+        st["_fused_pending"] = True
+        torch.autograd.graph.increment_version(param)
+
+    @torch.no_grad()
     def step_subset(self, params):
         """Apply this step's update to `params` now; the following step() handles the remaining tensors and skips
         these.  Lets a data-parallel driver update a tensor as soon as its all-reduce has finished while other
@@ -138,6 +165,7 @@ class FusedAdamW(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        self._row_tables = []  # row-shard tables of the previous step: their kernels are long enqueued behind us
         for gi, group in enumerate(self.param_groups):
             done = set()
             for p in group["params"]:  # tensors already updated (inside the backward pass or by step_subset)

@@ -44,6 +44,38 @@ def all_gather_rows(local, n_total, group=None):
     return out[:n_total]
 
 
+def reduce_scatter_rows(rows, group=None):
+    """SUM over ranks of `rows` [world * n, C] (contiguous), returning this rank's block [n, C] and a work handle (None
+    when the collective already completed)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n = rows.shape[0] // world
+    if rows.is_cuda and _host_staged(group):  # gloo rehearsal: all-reduce on the host, keep the own block
+        h = rows.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        return h[rank * n:(rank + 1) * n].to(rows.device), None
+    if _host_staged(group):
+        h = rows.clone()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        return h[rank * n:(rank + 1) * n].contiguous(), None
+    out = torch.empty(n, rows.shape[1], dtype=rows.dtype, device=rows.device)
+    return out, dist.reduce_scatter_tensor(out, rows, op=dist.ReduceOp.SUM, group=group, async_op=True)
+
+
+def all_gather_rows_inplace(full, group=None):
+    """`full` [world * n, C] (contiguous): every rank has written its own block of n rows; fetch the other ranks'
+    blocks in place."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    n = full.shape[0] // world
+    mine = full[rank * n:(rank + 1) * n]
+    if _host_staged(group):
+        h = mine.cpu() if mine.is_cuda else mine.clone()
+        parts = [torch.empty_like(h) for _ in range(world)]
+        dist.all_gather(parts, h, group=group)
+        full.copy_(torch.cat(parts).to(full.device))
+        return None
+    return dist.all_gather_into_tensor(full, mine, group=group, async_op=True)
+
+
 def allreduce_grads(params, group=None, bucket_bytes=256 << 20):
     """In-place SUM all-reduce of .grad over ranks.  Large tensors go alone (no copy); small ones are
     coalesced into one flat bucket.  xGMI is point-to-point, so few, large messages are preferred."""
@@ -107,6 +139,11 @@ class DataParallelStep:
     RCCL's stream, so out_layers' gradient travels over xGMI while the dh / dW1 GEMMs still run; the few
     small tensors are reduced in one flat bucket at the end.  Everything is waited for before AdamW.
 
+    `shard_optimizer=True` (opt-in): large 2-D weights are reduce-scattered by row blocks instead of all-reduced, every
+    rank runs AdamW on its 1/world of the rows only (`FusedAdamW.step_rows`) and the updated rows are all-gathered in
+    place -- the same bytes on the wire as an all-reduce, 1/world of the optimiser's HBM traffic per GPU.  The moments
+    of a sharded weight are then current only in the rank's own rows (`gather_optimizer_state()` before saving).
+
     Single process (world == 1): no exchange.  `early_update=True` issues the AdamW update of a large tensor on a
     side stream the moment its gradient GEMM is enqueued (the engine then computes a layer's input gradient BEFORE
     its weight gradient, so nothing reads the old weight any more); same kernels, same values as the sequential
@@ -114,9 +151,12 @@ class DataParallelStep:
     MI355X at the Yelp shape it LOSES 3-4 % (1.76 -> 1.83 ms/step) -- the HBM-bound update and the MFMA-bound dW1
     GEMM slow each other down by more than the 0.17 ms that is hidden."""
 
-    def __init__(self, diffusion, model, optimizer, group=None, overlap=True, early_update=False, direct_backward=True):
+    def __init__(self, diffusion, model, optimizer, group=None, overlap=True, early_update=False, direct_backward=True,
+                 shard_optimizer=False):
         self.diffusion, self.model, self.optimizer, self.group = diffusion, model, optimizer, group
         self.direct_backward = direct_backward
+        self.shard_optimizer = bool(shard_optimizer) and overlap and hasattr(optimizer, "step_rows")
+        self._sharded = []
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._handles, self._small = [], []
         if self.world > 1:
@@ -136,12 +176,36 @@ class DataParallelStep:
             model.engine.input_grad_first = True
 
     def _sink(self, param, grad):
+        if (self.shard_optimizer and param.grad is None and grad.dim() == 2 and grad.is_contiguous()
+                and grad.numel() * grad.element_size() >= (1 << 20) and grad.shape[0] >= self.world):
+            # sharded optimiser: rank r receives the summed gradient of its block of rows only (half the bytes of an
+            # all-reduce on the wire), updates those rows, and the updated rows are all-gathered afterwards; the
+            # R mod world leftover rows are all-reduced and updated by every rank
+            n_eq = grad.shape[0] // self.world * self.world
+            shard, h = reduce_scatter_rows(grad[:n_eq], self.group)
+            tail = grad[n_eq:]
+            h2 = _all_reduce(tail, self.group, async_op=True) if tail.numel() else None
+            self._sharded.append((param, grad, shard, h, tail, h2, n_eq))
+            return
         param.grad = grad if param.grad is None else param.grad.add_(grad)
         g = param.grad
         if g.numel() * g.element_size() >= (1 << 20):
             self._handles.append((param, _all_reduce(g, self.group, async_op=True)))
         else:
             self._small.append(g)
+
+    def gather_optimizer_state(self):
+        """Sharded optimiser: make exp_avg / exp_avg_sq of the sharded weights complete on every rank (checkpoints)."""
+        if not (self.shard_optimizer and self.world > 1):
+            return
+        for p in self.model.parameters():
+            st = self.optimizer.state.get(p)
+            if st and p.dim() == 2 and p.numel() * 4 >= (1 << 20) and p.shape[0] >= self.world:
+                n_eq = p.shape[0] // self.world * self.world
+                for key in ("exp_avg", "exp_avg_sq"):
+                    h = all_gather_rows_inplace(st[key][:n_eq], self.group)
+                    if h is not None:
+                        h.wait()
 
     def _sink_local(self, param, grad):
         param.grad = grad if param.grad is None else param.grad.add_(grad)
@@ -174,6 +238,20 @@ class DataParallelStep:
         hist[rank, :, 1] = lu
         # the large all-reduces complete in launch order; every tensor but the last is updated the moment its
         # own reduction is done, so that AdamW pass overlaps the reductions still on the wire
+        gathers = []
+        rank = dist.get_rank(self.group)
+        for param, grad, shard, h, tail, h2, n_eq in self._sharded:
+            if h is not None:
+                h.wait()
+            n = n_eq // self.world
+            self.optimizer.step_rows(param, shard, rank * n)
+            if tail.numel():
+                if h2 is not None:
+                    h2.wait()
+                self.optimizer.step_rows(param, tail, n_eq)
+            gathers.append((param, all_gather_rows_inplace(param.data[:n_eq], self.group)))
+        self._sharded = []
+        self._gathers = gathers
         early = hasattr(self.optimizer, "step_subset")
         for k, (param, h) in enumerate(self._handles):
             if h is not None:
@@ -220,4 +298,9 @@ class DataParallelStep:
             torch.cuda.current_stream().wait_stream(self._side)
             self._side_busy = False
         self.optimizer.step()
+        for param, h in getattr(self, "_gathers", []):  # updated row blocks of the other ranks
+            if h is not None:
+                h.wait()
+            torch.autograd.graph.increment_version(param)
+        self._gathers = []
         return loss.detach()

@@ -162,3 +162,52 @@ def test_row_sharded_lightgcn_equals_single_process(tmp_path):
     r0, r1 = torch.load(tmp_path / "g0.pt"), torch.load(tmp_path / "g1.pt")
     assert r0["ok_fwd"] and r1["ok_fwd"] and r0["ok_bwd"] and r1["ok_bwd"]
     assert r0["rows"][:2] == (0, 252) and r1["rows"][:2] == (252, 504)
+
+
+def _shard_worker(rank, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    import gdmcf_amd
+    from gdmcf_amd.parallel import DataParallelStep
+    dev, I2, H2, B2 = "cuda:0", 3001, 128, 32  # 3001 rows: one leftover row that every rank updates
+
+    def run(shard):
+        torch.manual_seed(5)
+        m = gdmcf_amd.DNN([I2, H2], [H2, I2], 10).to(dev).train()
+        d = gdmcf_amd.GaussianDiffusion(gdmcf_amd.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, T, dev)
+        o = gdmcf_amd.FusedAdamW(m.parameters(), lr=1e-3, weight_decay=0.01)
+        step = DataParallelStep(d, m, o, shard_optimizer=shard)
+        losses = []
+        for s in range(4):
+            g = torch.Generator().manual_seed(50 + s)
+            x = (torch.rand(2 * B2, I2, generator=g) < 0.03).float()[rank * B2:(rank + 1) * B2].to(dev)
+            ts = torch.randint(0, T, (2 * B2,), generator=g)[rank * B2:(rank + 1) * B2].to(dev)
+            noise = torch.randn(2 * B2, I2, generator=g)[rank * B2:(rank + 1) * B2].to(dev)
+            keep = (torch.rand(2 * B2, I2, generator=g) < 0.5).float()[rank * B2:(rank + 1) * B2].to(dev)
+            losses.append(float(step(x, True, ts=ts, pt=torch.ones(B2, device=dev), noise=noise, drop_mask=keep)))
+        step.gather_optimizer_state()
+        torch.cuda.synchronize()
+        return m, o, losses, step
+
+    m0, o0, l0, _ = run(False)
+    m1, o1, l1, st1 = run(True)
+    ok = st1.shard_optimizer and l0 == l1
+    for a, b in zip(m0.parameters(), m1.parameters()):
+        ok = ok and torch.equal(a, b) and torch.equal(o0.state[a]["exp_avg"], o1.state[b]["exp_avg"]) \
+            and torch.equal(o0.state[a]["exp_avg_sq"], o1.state[b]["exp_avg_sq"]) and o0.state[a]["step"] == o1.state[b]["step"]
+    torch.save(dict(ok=bool(ok), params=[p.detach().cpu() for p in m1.parameters()]), os.path.join(out_dir, f"s{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_sharded_optimizer_equals_all_reduce_path(tmp_path):
+    """DataParallelStep(shard_optimizer=True): reduce-scatter of the row blocks, AdamW on the own rows, in-place
+    all-gather of the updated rows (+ all-reduce for the R mod world leftover row).  Same losses, weights, moments and
+    step counts as the all-reduce path, bit for bit, and identical replicas."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_shard_worker, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
+    r0, r1 = torch.load(tmp_path / "s0.pt"), torch.load(tmp_path / "s1.pt")
+    assert r0["ok"] and r1["ok"]
+    for a, b in zip(r0["params"], r1["params"]):
+        assert torch.equal(a, b)
