@@ -101,3 +101,35 @@ def test_single_process_paths_are_noops():
     ts, lu = torch.arange(4), torch.rand(4, dtype=torch.float64)
     a, b = parallel.gather_history_inputs(ts, lu)
     assert a is ts and b is lu
+
+
+def _rows_worker(rank, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    g = torch.Generator().manual_seed(10 + rank)
+    rows = torch.randn(6, 5, generator=g)            # this rank's contribution, [world * 3, 5]
+    mine, h = parallel.reduce_scatter_rows(rows.clone())
+    if h is not None:
+        h.wait()
+    full = torch.full((6, 5), float("nan"))
+    full[rank * 3:(rank + 1) * 3] = mine * 10 + rank   # "updated rows" of this rank
+    h = parallel.all_gather_rows_inplace(full)
+    if h is not None:
+        h.wait()
+    block = torch.full((4, 2), float(rank))            # ceil(7 / 2) = 4 rows per rank, 7 in total
+    table = parallel.all_gather_rows(block, 7)
+    torch.save(dict(rows=rows, mine=mine, full=full, table=table), os.path.join(out_dir, f"q{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_row_collectives_world2(tmp_path):
+    """reduce_scatter_rows / all_gather_rows_inplace (sharded optimiser) and all_gather_rows (row-sharded LightGCN)."""
+    port = _free_port()
+    mp.spawn(_rows_worker, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
+    q0, q1 = torch.load(tmp_path / "q0.pt"), torch.load(tmp_path / "q1.pt")
+    total = q0["rows"] + q1["rows"]
+    assert torch.equal(q0["mine"], total[:3]) and torch.equal(q1["mine"], total[3:])
+    want = torch.cat([total[:3] * 10 + 0, total[3:] * 10 + 1])
+    assert torch.equal(q0["full"], want) and torch.equal(q1["full"], want)
+    want_t = torch.cat([torch.zeros(4, 2), torch.ones(3, 2)])
+    assert torch.equal(q0["table"], want_t) and torch.equal(q1["table"], want_t)
