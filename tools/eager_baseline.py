@@ -60,3 +60,27 @@ for name, kw in (("foreach", dict(foreach=True)), ("fused", dict(fused=True))):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) * 1e3 / n
     print(f"PyTorch eager, AdamW({name}): {ms:.3f} ms/step = {B / ms * 1e3:,.0f} users/s", flush=True)
+
+# the optimiser alone: torch's fused AdamW next to gdmcf_amd.FusedAdamW on the same parameters / gradients
+import os  # noqa: E402
+import sys  # noqa: E402
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import gdmcf_amd  # noqa: E402
+
+for p in model.parameters():
+    p.grad = torch.randn_like(p)
+for name, opt in (("torch.optim.AdamW(fused=True)", torch.optim.AdamW(model.parameters(), lr=1e-5, weight_decay=0.0, fused=True)),
+                  ("gdmcf_amd.FusedAdamW", gdmcf_amd.FusedAdamW(model.parameters(), lr=1e-5, weight_decay=0.0))):
+    for _ in range(5):
+        opt.step()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(30):
+        opt.step()
+    e.record()
+    torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / 30
+    n = sum(p.numel() for p in model.parameters())
+    print(f"{name}: {ms:.3f} ms per step over {n / 1e6:.1f} M parameters = {28.0 * n / ms / 1e9:.2f} TB/s of 28 B/param")
