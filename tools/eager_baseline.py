@@ -35,16 +35,18 @@ ab = torch.linspace(0.99999, 0.9999, T, device=dev, dtype=torch.float64)
 sa, sb = ab.sqrt().float(), (1 - ab).sqrt().float()
 w = torch.ones(T, device=dev, dtype=torch.float64)
 x = (torch.rand(B, I, device=dev) < 0.00075).float()
-for name, kw in (("foreach", dict(foreach=True)), ("fused", dict(fused=True))):
+for name, kw in (("foreach", dict(foreach=True)), ("fused", dict(fused=True)), ("fused + autocast bf16", dict(fused=True))):
     opt = torch.optim.AdamW(model.parameters(), lr=1e-5, weight_decay=0.0, **kw)
+    amp = "autocast" in name
 
     def step():
         opt.zero_grad()
         ts = torch.randint(0, T, (B,), device=dev)
         noise = torch.randn_like(x)
         x_t = sa[ts][:, None] * x + sb[ts][:, None] * noise
-        out = model(x_t, ts)
-        mse = ((x - out) ** 2).mean(dim=1)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            out = model(x_t, ts)
+        mse = ((x - out.float()) ** 2).mean(dim=1)
         loss = (w[ts] * mse).mean()
         loss.backward()
         opt.step()
