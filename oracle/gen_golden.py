@@ -330,6 +330,9 @@ if __name__ == "__main__":
               nmin=0.0005, nmax=0.005)
     gen_train("deep_x0", 16, 200, [48, 24], 5, "x0", seed=6, density=0.05, n_steps=2)
     gen_train("norm_x0", 8, 96, [32], 5, "x0", seed=8, norm=True, n_steps=1)
+    gen_train("cosine_eps", 12, 130, [24], 8, "eps", seed=21, density=0.06, schedule="cosine", scale=0.05, n_steps=2)
+    gen_train("binomial_x0", 12, 130, [24], 6, "x0", seed=22, density=0.06, schedule="binomial", n_steps=2)
+    gen_train("deep_eps_norm", 10, 150, [40, 20], 5, "eps", seed=23, density=0.08, norm=True, wd=0.02, n_steps=2)
     gen_sample("tiny_x0", 8, 64, [16], 5, "x0", seed=11, k=10)
     gen_sample("ragged_x0", 32, 515, [100], 5, "x0", seed=12, k=20)
     gen_sample("ragged_eps", 16, 515, [100], 5, "eps", seed=13, k=20, scale=50.0)
