@@ -184,10 +184,10 @@ def gen_train(name, B, I, dims, T, mean_type, schedule="linear-var", scale=0.01,
 
 
 # ----------------------------------------------------------------------------------------
-def gen_sample(name, B, I, dims, T, mean_type, seed=0, density=0.08, scale=0.01, nmin=0.001, nmax=0.01, k=20):
+def gen_sample(name, B, I, dims, T, mean_type, seed=0, density=0.08, scale=0.01, nmin=0.001, nmax=0.01, k=20, norm=False):
     torch.manual_seed(seed)
     g = torch.Generator().manual_seed(seed + 7)
-    model = RefDNN([I] + dims, dims[::-1] + [I], 10, time_type="cat", norm=False)
+    model = RefDNN([I] + dims, dims[::-1] + [I], 10, time_type="cat", norm=norm)
     # spread the outputs so that top-k gaps are far above fp32 summation-order noise
     with torch.no_grad():
         model.out_layers[-1].bias.normal_(0.0, 0.5, generator=g)
@@ -196,7 +196,7 @@ def gen_sample(name, B, I, dims, T, mean_type, seed=0, density=0.08, scale=0.01,
     diff = gd.GaussianDiffusion(mt, "linear-var", scale, nmin, nmax, T, "cpu")
     x = make_rows(B, I, density, g)
     out = dict(sd_np(model))
-    out["meta"] = np.array([f"{B}|{I}|{','.join(map(str, dims))}|{T}|{mean_type}|{scale}|{nmin}|{nmax}|{k}"])
+    out["meta"] = np.array([f"{B}|{I}|{','.join(map(str, dims))}|{T}|{mean_type}|{scale}|{nmin}|{nmax}|{k}" + ("|1" if norm else "")])
     out["x_start"] = npy(x).astype(np.uint8)
     cap = {"noises": []}
     orig_randn = gd.th.randn_like
@@ -336,5 +336,6 @@ if __name__ == "__main__":
     gen_sample("tiny_x0", 8, 64, [16], 5, "x0", seed=11, k=10)
     gen_sample("ragged_x0", 32, 515, [100], 5, "x0", seed=12, k=20)
     gen_sample("ragged_eps", 16, 515, [100], 5, "eps", seed=13, k=20, scale=50.0)
+    gen_sample("norm_x0", 12, 150, [32], 5, "x0", seed=14, k=10, norm=True)
     gen_lightgcn("small", 50, 40, 8, 3, 300, seed=0)
     gen_lightgcn("mid", 600, 400, 64, 3, 6000, seed=1)

@@ -9,7 +9,7 @@ from oracle import gdmcf_oracle as O
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TRAIN_CASES = ["tiny_x0", "tiny_eps", "ragged_x0", "ragged_eps_wd", "imp_T40", "deep_x0", "norm_x0", "cosine_eps",
                "binomial_x0", "deep_eps_norm"]
-SAMPLE_CASES = ["tiny_x0", "ragged_x0", "ragged_eps"]
+SAMPLE_CASES = ["tiny_x0", "ragged_x0", "ragged_eps", "norm_x0"]
 
 
 def load(name):
@@ -24,9 +24,10 @@ def train_meta(fx):
 
 
 def sample_meta(fx):
-    B, I, dims, T, mt, scale, nmin, nmax, k = str(fx["meta"][0]).split("|")
+    f = str(fx["meta"][0]).split("|")
+    B, I, dims, T, mt, scale, nmin, nmax, k = f[:9]
     return dict(B=int(B), I=int(I), dims=[int(d) for d in dims.split(",")], T=int(T), mean_type=mt,
-                scale=float(scale), nmin=float(nmin), nmax=float(nmax), k=int(k))
+                scale=float(scale), nmin=float(nmin), nmax=float(nmax), k=int(k), norm=len(f) > 9 and f[9] == "1")
 
 
 def state_dict_from(fx, prefix="sd."):
