@@ -14,6 +14,11 @@ Besides the contract fields the JSON line carries
                   stream inside the timed region (gdmcf_prof_*), against the gfx950 peak;
   cpu_baseline -- the oracle (a PyTorch-CPU restatement of the reference path, parity-pinned to
                   the reference by tests/golden) timed on this host's cores on the same workload.
+
+Other legs / variants (not part of the default line): --gemm-dtype bf16 (BASELINE configs[2]), --workload
+amazon-book|stress, --fuse-optimizer (AdamW inside the weight-gradient GEMM epilogues, N = 1), --shard-optimizer
+(N > 1: reduce-scatter + AdamW on 1/N of the rows + all-gather), --global-batch G (strong scaling), --spmm (LightGCN
+propagation; row-sharded when N > 1), --bpr (LightGCN BPR training step), --sampling (p_sample + masked top-k).
 """
 import argparse
 import ctypes
