@@ -135,6 +135,7 @@ struct GdGemm {
 //                3 = bf16 only: 208x256 on 8 waves (batch-sized M, see gemm_bf16.hip)
 int gd_gemm_launch(int layA, int layB, int epi, int shape_class, GdGemm& g, hipStream_t s);
 int gd_gemm_bf16_launch(int layA, int layB, int epi, int shape_class, GdGemm& g, hipStream_t s);  // g.bf16 != 0
+int gd_gemm_small_launch(int layA, int layB, int epi, GdGemm& g, hipStream_t s);  // degenerate shapes (gemm_small.hip)
 int gd_gemm_tile_m(int shape_class);
 int gd_gemm_tile_n(int shape_class);
 int gd_gemm_bk(int layA, int layB);

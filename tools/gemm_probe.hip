@@ -12,6 +12,7 @@
 
 bool g_gd_prof_on = false;
 int gd_gemm_bf16_launch(int, int, int, int, GdGemm&, hipStream_t) { return GDMCF_E_UNSUPPORTED; }  // f32 probe only
+int gd_gemm_small_launch(int, int, int, GdGemm&, hipStream_t) { return GDMCF_E_UNSUPPORTED; }
 void gd_prof_begin(int, double, hipStream_t) {}
 void gd_prof_end(hipStream_t) {}
 void gdmcf_set_error(const char* fmt, ...) {
