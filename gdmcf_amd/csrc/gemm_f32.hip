@@ -183,7 +183,7 @@ struct TileStage {
                                          int kend, int kbeg, bool rows_full, int tid) {
         // exactly two variants with the same number of loads in the same order, so the compiler's counted
         // vmcnt waits stay exact across the join (a third, predicated path would force conservative waits
-        // that drain the second register stage).  Degenerate shapes are rejected on the host.
+        // that drain the second register stage).  Degenerate shapes never get here (gemm_small.hip takes them).
         const bool k_full = (k0 + BK <= kend);
         if (k_full && (LAY == GD_LAY_KC || rows_full)) {
             mode = 0;
