@@ -703,7 +703,16 @@ int gdmcf_row_loss_finish_f64(const float* rowsum, const float* rowdiv, const fl
                               float* gradcoef, void* stream) {
     GD_CHECK_SHAPE(B > 0 && T > 0 && H > 0, "row_loss_finish: bad shape");
     const size_t lds = (size_t)T * H * 8 + (size_t)T * 8 + (size_t)B * 4 + 16;
-    GD_CHECK_ARG(lds <= 64 * 1024, "row_loss_finish: T*H and B too large for the LDS-resident FIFO update");
+    GD_CHECK_ARG(lds <= 150 * 1024, "row_loss_finish: T*H and B too large for the LDS-resident FIFO update (150 KiB)");
+    static bool attr_set = false;
+    if (!attr_set && lds > 48 * 1024) {  // T = 1000 diffusion steps x 10 history entries need 88 KB
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(row_loss_finish_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            gdmcf_set_error("row_loss_finish: hipFuncSetAttribute failed");
+            return GDMCF_E_HIP;
+        }
+        attr_set = true;
+    }
     hipLaunchKernelGGL(row_loss_finish_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, rowsum, rowdiv, alpha,
                        gradcoef, ts, weight_t, pt, B, T, H, Lt_history, Lt_count, update_history, loss_unscaled, loss);
     return gd_launch_status("row_loss_finish");
@@ -713,7 +722,16 @@ int gdmcf_lt_history_update(const int64_t* ts, const double* loss_unscaled, int 
                             int64_t* Lt_count, void* stream) {
     GD_CHECK_SHAPE(B > 0 && T > 0 && H > 0, "lt_history_update: bad shape");
     const size_t lds = (size_t)T * H * 8 + (size_t)T * 8 + (size_t)B * 4 + 16;
-    GD_CHECK_ARG(lds <= 64 * 1024, "lt_history_update: T*H and B too large for the LDS-resident FIFO update");
+    GD_CHECK_ARG(lds <= 150 * 1024, "lt_history_update: T*H and B too large for the LDS-resident FIFO update (150 KiB)");
+    static bool attr_set = false;
+    if (!attr_set && lds > 48 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(lt_history_update_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            gdmcf_set_error("lt_history_update: hipFuncSetAttribute failed");
+            return GDMCF_E_HIP;
+        }
+        attr_set = true;
+    }
     hipLaunchKernelGGL(lt_history_update_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, ts, loss_unscaled, B, T,
                        H, Lt_history, Lt_count);
     return gd_launch_status("lt_history_update");

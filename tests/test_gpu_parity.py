@@ -200,6 +200,42 @@ def test_degenerate_sizes_match_oracle(T, B, I, hid):
     assert idx.shape == (B, k)
 
 
+def test_thousand_diffusion_steps_match_oracle():
+    """T = 1000 (DDPM-scale): the [T, 10] float64 loss history no longer fits the default 48 KB of LDS -- the FIFO
+    kernels ask for up to 150 KB.  Training step, history bookkeeping, importance probabilities vs the oracle."""
+    T, B, I, hid = 1000, 64, 200, 32
+    torch.manual_seed(1)
+    om = O.DNN([I, hid], [hid, I], 10)
+    gm = gdmcf_amd.DNN([I, hid], [hid, I], 10)
+    gm.load_state_dict(om.state_dict())
+    gm = gm.to(DEV)
+    od = O.GaussianDiffusion(O.ModelMeanType.START_X, "linear-var", 0.0001, 0.0005, 0.005, T)
+    gd_ = gdmcf_amd.GaussianDiffusion(ModelMeanType.START_X, "linear-var", 0.0001, 0.0005, 0.005, T, DEV)
+    g = torch.Generator().manual_seed(2)
+    hist0 = torch.rand(T, 10, generator=g, dtype=torch.float64) * 5 + 0.1
+    od.Lt_history, od.Lt_count = hist0.clone(), torch.full((T,), 10, dtype=torch.int64)
+    gd_.Lt_history.copy_(hist0)
+    gd_.Lt_count.fill_(10)
+    np.testing.assert_allclose(gd_.importance_probs().cpu().numpy(), od.importance_probs().numpy(), rtol=1e-12)
+    om.train(), gm.train()
+    oopt, gopt = O.make_optimizer(om, 1e-3), gdmcf_amd.FusedAdamW(gm.parameters(), lr=1e-3, weight_decay=0.0)
+    for _ in range(2):
+        x = (torch.rand(B, I, generator=g) < 0.1).float()
+        ts = torch.randint(0, T, (B,), generator=g)
+        ts[:4] = torch.tensor([0, T - 1, 7, 7])  # first / last step and a repeated step in one batch
+        noise, keep = torch.randn(B, I, generator=g), (torch.rand(B, I, generator=g) < 0.5).float()
+        pt = torch.rand(B, generator=g, dtype=torch.float64) + 0.5
+        oloss, ovec = O.train_step(od, om, oopt, x, True, ts=ts, pt=pt, noise=noise, drop_mask=keep)
+        gopt.zero_grad()
+        terms = gd_.training_losses(gm, cu(x), True, ts=cu(ts), pt=cu(pt), noise=cu(noise), drop_mask=cu(keep))
+        terms["loss"].mean().backward()
+        gopt.step()
+        np.testing.assert_allclose(terms["loss"].detach().cpu().numpy(), ovec.numpy(), rtol=1e-5)
+        np.testing.assert_allclose(gd_.Lt_history.cpu().numpy(), od.Lt_history.numpy(), rtol=1e-5)
+    t_dev, pt_dev = gd_.sample_timesteps(B, DEV, "importance")
+    assert int(t_dev.min()) >= 0 and int(t_dev.max()) < T and bool((pt_dev > 0).all())
+
+
 def test_plain_forward_backward_matches_oracle():
     """model(x, t) + autograd through the HIP kernels vs the oracle's eager autograd."""
     fx = H.load("train_ragged_x0")
