@@ -462,7 +462,7 @@ int gdmcf_topk_masked_f32(const float* pred, int64_t ldp, int B, int I, const in
     if (!attr_set) {
         hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_kernel<true, 1024>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_kernel<false, 256>),
+        hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&topk_kernel<false, 1024>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e1 != hipSuccess || e2 != hipSuccess) {
             gdmcf_set_error("topk: hipFuncSetAttribute failed");
@@ -475,7 +475,7 @@ int gdmcf_topk_masked_f32(const float* pred, int64_t ldp, int B, int I, const in
         hipLaunchKernelGGL((topk_kernel<true, 1024>), dim3(B), dim3(1024), lds, (hipStream_t)stream, pred, ldp, I, mask_indptr,
                            mask_indices, k, KP, idx_out, val_out);
     else
-        hipLaunchKernelGGL((topk_kernel<false, 256>), dim3(B), dim3(256), lds, (hipStream_t)stream, pred, ldp, I, mask_indptr,
+        hipLaunchKernelGGL((topk_kernel<false, 1024>), dim3(B), dim3(1024), lds, (hipStream_t)stream, pred, ldp, I, mask_indptr,
                            mask_indices, k, KP, idx_out, val_out);
     return gd_launch_status("topk");
 }

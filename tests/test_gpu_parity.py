@@ -335,6 +335,23 @@ def test_topk_edge_cases_against_oracle():
         gdmcf_amd.masked_topk(cu(pred), I + 1)
 
 
+def test_topk_wide_rows_take_the_unstaged_path():
+    """Rows wider than the LDS staging limit (~37 k items; the Amazon-Book shape has 94 949): the keys are recomputed
+    from global memory in every radix pass.  Same lists as the oracle, ties included."""
+    g = torch.Generator().manual_seed(4)
+    B, I = 6, 60011
+    pred = torch.randn(B, I, generator=g)
+    pred[:, ::5] = pred[:, 1::5][:, : pred[:, ::5].shape[1]]  # exact ties
+    pred[2] = -1.5  # constant row: pure index order
+    mask = (torch.rand(B, I, generator=g) < 0.01)
+    rows, cols = mask.nonzero(as_tuple=True)
+    csr = mask.float().to_sparse_csr()
+    for k in (1, 100, 257):
+        ref = O.masked_topk(pred, rows, cols, k)
+        got = gdmcf_amd.masked_topk(cu(pred), k, csr.crow_indices().to(DEV), csr.col_indices().to(DEV))
+        np.testing.assert_array_equal(got.cpu().numpy(), ref.numpy(), err_msg=f"k={k}")
+
+
 @pytest.mark.parametrize("case", ["small", "mid"])
 def test_lightgcn_propagation_matches_reference(case):
     fx = H.load("lightgcn_" + case)
