@@ -200,6 +200,33 @@ def test_degenerate_sizes_match_oracle(T, B, I, hid):
     assert idx.shape == (B, k)
 
 
+@pytest.mark.parametrize("emb", [7, 3, 16])
+def test_odd_embedding_widths_match_oracle(emb):
+    """timestep_embedding zero-pads an odd width (reference models/DNN.py:1823-1824)."""
+    B, I, hid, T = 9, 70, 12, 5
+    torch.manual_seed(emb)
+    om = O.DNN([I, hid], [hid, I], emb)
+    gm = gdmcf_amd.DNN([I, hid], [hid, I], emb)
+    gm.load_state_dict(om.state_dict())
+    gm = gm.to(DEV)
+    od = O.GaussianDiffusion(O.ModelMeanType.EPSILON, "linear-var", 0.01, 0.001, 0.01, T)
+    gd_ = gdmcf_amd.GaussianDiffusion(ModelMeanType.EPSILON, "linear-var", 0.01, 0.001, 0.01, T, DEV)
+    g = torch.Generator().manual_seed(1)
+    x = (torch.rand(B, I, generator=g) < 0.2).float()
+    ts = torch.randint(0, T, (B,), generator=g)
+    noise, keep = torch.randn(B, I, generator=g), (torch.rand(B, I, generator=g) < 0.5).float()
+    np.testing.assert_allclose(gdmcf_amd.timestep_embedding(cu(ts), emb).cpu().numpy(), O.timestep_embedding(ts, emb).numpy(),
+                               rtol=1e-6, atol=1e-7)
+    om.train(), gm.train()
+    oopt = O.make_optimizer(om, 1e-3)
+    oloss, ovec = O.train_step(od, om, oopt, x, True, ts=ts, pt=torch.ones(B), noise=noise, drop_mask=keep)
+    terms = gd_.training_losses(gm, cu(x), True, ts=cu(ts), pt=cu(torch.ones(B)), noise=cu(noise), drop_mask=cu(keep))
+    terms["loss"].mean().backward()
+    np.testing.assert_allclose(terms["loss"].detach().cpu().numpy(), ovec.numpy(), rtol=1e-5)
+    for (k, p), q in zip(gm.named_parameters(), om.parameters()):
+        assert H.relerr(p.grad.cpu().numpy(), q.grad.numpy()) < 1e-4 or float(q.grad.abs().max()) < 1e-12, k
+
+
 def test_thousand_diffusion_steps_match_oracle():
     """T = 1000 (DDPM-scale): the [T, 10] float64 loss history no longer fits the default 48 KB of LDS -- the FIFO
     kernels ask for up to 150 KB.  Training step, history bookkeeping, importance probabilities vs the oracle."""
