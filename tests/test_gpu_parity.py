@@ -227,6 +227,41 @@ def test_odd_embedding_widths_match_oracle(emb):
         assert H.relerr(p.grad.cpu().numpy(), q.grad.numpy()) < 1e-4 or float(q.grad.abs().max()) < 1e-12, k
 
 
+@pytest.mark.parametrize("p", [0.0, 0.25, 0.9])
+def test_dropout_rates_match_oracle(p):
+    """DNN(dropout=p): survivors are scaled by 1/(1-p) (reference models/DNN.py:37,77); p = 0 keeps everything.  Also
+    the in-kernel Philox mask: the kept fraction matches 1-p and kept elements carry exactly the 1/(1-p) scale."""
+    B, I, hid, T = 16, 300, 24, 5
+    torch.manual_seed(5)
+    om = O.DNN([I, hid], [hid, I], 10, dropout=p)
+    gm = gdmcf_amd.DNN([I, hid], [hid, I], 10, dropout=p)
+    gm.load_state_dict(om.state_dict())
+    gm = gm.to(DEV)
+    od = O.GaussianDiffusion(O.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, T)
+    gd_ = gdmcf_amd.GaussianDiffusion(ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, T, DEV)
+    g = torch.Generator().manual_seed(2)
+    x = (torch.rand(B, I, generator=g) < 0.1).float()
+    ts = torch.randint(0, T, (B,), generator=g)
+    noise = torch.randn(B, I, generator=g)
+    keep = (torch.rand(B, I, generator=g) < (1 - p)).float()
+    om.train(), gm.train()
+    oloss, ovec = O.train_step(od, om, O.make_optimizer(om, 1e-3), x, True, ts=ts, pt=torch.ones(B), noise=noise, drop_mask=keep)
+    terms = gd_.training_losses(gm, cu(x), True, ts=cu(ts), pt=cu(torch.ones(B)), noise=cu(noise), drop_mask=cu(keep))
+    terms["loss"].mean().backward()
+    np.testing.assert_allclose(terms["loss"].detach().cpu().numpy(), ovec.numpy(), rtol=1e-5)
+    for pg, q in zip(gm.parameters(), om.parameters()):
+        assert H.relerr(pg.grad.cpu().numpy(), q.grad.numpy()) < 1e-4
+    # Philox path: statistics of the mask
+    xs = torch.ones(64, 4096, device=DEV)
+    big = gdmcf_amd.DNN([4096, 8], [8, 4096], 10, dropout=p).to(DEV).train()
+    big.engine.manual_seed(7)
+    big(xs, torch.zeros(64, dtype=torch.int64, device=DEV))
+    xin = big.engine.buffers(64, torch.device(DEV)).xin[:, :4096]
+    kept = xin != 0
+    assert abs(float(kept.float().mean()) - (1 - p)) < 0.01
+    assert bool(torch.all(torch.abs(xin[kept] * (1.0 - p) - 1.0) < 1e-6))
+
+
 def test_thousand_diffusion_steps_match_oracle():
     """T = 1000 (DDPM-scale): the [T, 10] float64 loss history no longer fits the default 48 KB of LDS -- the FIFO
     kernels ask for up to 150 KB.  Training step, history bookkeeping, importance probabilities vs the oracle."""
