@@ -262,6 +262,32 @@ def test_dropout_rates_match_oracle(p):
     assert bool(torch.all(torch.abs(xin[kept] * (1.0 - p) - 1.0) < 1e-6))
 
 
+def test_unweighted_loss_branch():
+    """reweight=False: the reference multiplies unit weights with an undefined `loss` (gaussian_diffusion.py:349-352 --
+    it raises); this build and the oracle take DiffRec's reading, unit weights on the mse, for the x0 target and refuse
+    the eps target loudly."""
+    fx = H.load("train_ragged_x0")
+    meta = H.train_meta(fx)
+    model, diff = gpu_model(meta, fx).train(), gpu_diffusion(meta)
+    om = H.oracle_model(meta, fx).train()
+    od = O.GaussianDiffusion(O.ModelMeanType.START_X, "linear-var", meta["scale"], meta["nmin"], meta["nmax"], meta["T"])
+    inp = H.step_inputs(fx, 0)
+    want = od.training_losses(om, inp["x"], False, ts=inp["ts"], pt=inp["pt"], noise=inp["noise"], drop_mask=inp["drop_mask"])["loss"]
+    got = diff.training_losses(model, cu(inp["x"]), False, ts=cu(inp["ts"]), pt=cu(inp["pt"]), noise=cu(inp["noise"]),
+                               drop_mask=cu(inp["drop_mask"]))["loss"]
+    np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=1e-5)
+    got.mean().backward()
+    want.mean().backward()
+    for p, q in zip(model.parameters(), om.parameters()):
+        assert H.relerr(p.grad.cpu().numpy(), q.grad.numpy()) < 2e-4
+    fe = H.load("train_tiny_eps")
+    me = H.train_meta(fe)
+    ie = H.step_inputs(fe, 0)
+    with pytest.raises(NotImplementedError):
+        gpu_diffusion(me).training_losses(gpu_model(me, fe).train(), cu(ie["x"]), False, ts=cu(ie["ts"]), pt=cu(ie["pt"]),
+                                          noise=cu(ie["noise"]), drop_mask=cu(ie["drop_mask"]))
+
+
 def test_thousand_diffusion_steps_match_oracle():
     """T = 1000 (DDPM-scale): the [T, 10] float64 loss history no longer fits the default 48 KB of LDS -- the FIFO
     kernels ask for up to 150 KB.  Training step, history bookkeeping, importance probabilities vs the oracle."""
