@@ -4,9 +4,9 @@ from . import _lib  # noqa: F401
 from .DNN import DNN, timestep_embedding  # noqa: F401
 from .gaussian_diffusion import GaussianDiffusion, GaussianDiffusionDiscrete, ModelMeanType  # noqa: F401
 from .optim import FusedAdamW  # noqa: F401
-from .evaluate_utils import computeTopNAccuracy, masked_topk, print_results  # noqa: F401
+from .evaluate_utils import computeTopNAccuracy, computeTopNAccuracy_device, masked_topk, print_results  # noqa: F401
 from .lightgcn import LightGCN  # noqa: F401
 from . import checkpoint, data_utils, driver, parallel  # noqa: F401
 
 __all__ = ["DNN", "timestep_embedding", "GaussianDiffusion", "GaussianDiffusionDiscrete", "ModelMeanType", "FusedAdamW", "computeTopNAccuracy",
-           "masked_topk", "print_results", "LightGCN"]
+           "computeTopNAccuracy_device", "masked_topk", "print_results", "LightGCN"]
