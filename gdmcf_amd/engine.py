@@ -225,7 +225,7 @@ class DenoiserEngine:
         if eps_mode:
             # target = eps, except rows with t == 0 whose term is the x0-likelihood
             # mean((x0 - (r1*x_t - r2*eps_hat))^2 / 2)  (reference gaussian_diffusion.py:344-348)
-            is0 = (ts == 0)
+            is0 = (ts == 0) if spec.get("t0_likelihood", True) else torch.zeros_like(ts, dtype=torch.bool)
             noise = keepalive[1]
             target = torch.where(is0[:, None], spec["r1_0"] * bufs.xt[:, : self.I] - x0c, noise)
             alpha = torch.where(is0, spec["r2_0"], torch.ones((), dtype=torch.float32, device=dev)).float().contiguous()

@@ -231,13 +231,12 @@ class GaussianDiffusion(nn.Module):
         if reweight == True:  # noqa: E712  (the reference's own test)
             weight_t = self._weights["eps" if eps_mode else "x0"]
         else:
-            if eps_mode:
-                raise NotImplementedError("reweight=False with mean_type EPSILON")
             # the reference leaves `loss` undefined here (NameError); DiffRec semantics: unit weights on the mse
+            # (for the eps target that also means no x0-likelihood term on the t == 0 rows)
             weight_t = self._weights["one"]
         spec = dict(x_start=x_start, ts=ts, pt=pt, ca=ca, cb=cb, noise=noise, drop_mask=drop_mask, eps_mode=eps_mode,
                     weight_t=weight_t, T=self.steps, H=self.history_num_per_term, Lt_history=self.Lt_history,
-                    Lt_count=self.Lt_count, update_history=self.update_history)
+                    Lt_count=self.Lt_count, update_history=self.update_history, t0_likelihood=(reweight == True))  # noqa: E712
         if eps_mode:
             spec["r1_0"] = self._t32["r1"][0]
             spec["r2_0"] = self._t32["r2"][0]

@@ -264,8 +264,7 @@ def test_dropout_rates_match_oracle(p):
 
 def test_unweighted_loss_branch():
     """reweight=False: the reference multiplies unit weights with an undefined `loss` (gaussian_diffusion.py:349-352 --
-    it raises); this build and the oracle take DiffRec's reading, unit weights on the mse, for the x0 target and refuse
-    the eps target loudly."""
+    it raises); this build and the oracle take DiffRec's reading: unit weights on the mse, for both targets."""
     fx = H.load("train_ragged_x0")
     meta = H.train_meta(fx)
     model, diff = gpu_model(meta, fx).train(), gpu_diffusion(meta)
@@ -283,9 +282,13 @@ def test_unweighted_loss_branch():
     fe = H.load("train_tiny_eps")
     me = H.train_meta(fe)
     ie = H.step_inputs(fe, 0)
-    with pytest.raises(NotImplementedError):
-        gpu_diffusion(me).training_losses(gpu_model(me, fe).train(), cu(ie["x"]), False, ts=cu(ie["ts"]), pt=cu(ie["pt"]),
-                                          noise=cu(ie["noise"]), drop_mask=cu(ie["drop_mask"]))
+    oe = O.GaussianDiffusion(O.ModelMeanType.EPSILON, "linear-var", me["scale"], me["nmin"], me["nmax"], me["T"])
+    want = oe.training_losses(H.oracle_model(me, fe).train(), ie["x"], False, ts=ie["ts"], pt=ie["pt"], noise=ie["noise"],
+                              drop_mask=ie["drop_mask"])["loss"]
+    got = gpu_diffusion(me).training_losses(gpu_model(me, fe).train(), cu(ie["x"]), False, ts=cu(ie["ts"]), pt=cu(ie["pt"]),
+                                            noise=cu(ie["noise"]), drop_mask=cu(ie["drop_mask"]))["loss"]
+    assert bool((ie["ts"] == 0).any())  # the t == 0 rows are the ones whose treatment differs from the weighted branch
+    np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=1e-5)
 
 
 def test_thousand_diffusion_steps_match_oracle():
