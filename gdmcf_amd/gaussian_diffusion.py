@@ -71,6 +71,9 @@ class GaussianDiffusion(nn.Module):
                 raise NotImplementedError(f"unknown beta schedule: {noise_schedule}!")
             self.beta_fixed = beta_fixed
             self.calculate_for_diffusion()
+        else:  # no noising: the reference builds no tables at all (:86-89); only the unweighted loss is defined
+            self._t32 = {}
+            self._weights = {"one": torch.ones(steps, dtype=torch.float64, device=self.device)}
 
     # -- tables -----------------------------------------------------------------------------
     def calculate_for_diffusion(self):
@@ -229,6 +232,9 @@ class GaussianDiffusion(nn.Module):
         if drop_mask is None and self.rng == "torch" and model.training and model.drop.p > 0:
             drop_mask = torch.bernoulli(torch.full_like(x_start, 1.0 - model.drop.p, dtype=torch.float32)).to(torch.uint8)
         if reweight == True:  # noqa: E712  (the reference's own test)
+            if self.noise_scale == 0.0:
+                raise AttributeError("GaussianDiffusion has no schedule tables (noise_scale == 0): the SNR weights of "
+                                     "reweight=True do not exist -- the reference fails the same way (:340, :525-530)")
             weight_t = self._weights["eps" if eps_mode else "x0"]
         else:
             # the reference leaves `loss` undefined here (NameError); DiffRec semantics: unit weights on the mse

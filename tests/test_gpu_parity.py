@@ -291,6 +291,23 @@ def test_unweighted_loss_branch():
     np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=1e-5)
 
 
+def test_noise_scale_zero_feeds_the_rows_unnoised():
+    """noise_scale == 0: no schedule tables are built and x_t = x_start (reference gaussian_diffusion.py:86-89,
+    :299-302); only the unweighted loss is defined then."""
+    fx = H.load("train_ragged_x0")
+    meta = H.train_meta(fx)
+    model, om = gpu_model(meta, fx).train(), H.oracle_model(meta, fx).train()
+    od = O.GaussianDiffusion(O.ModelMeanType.START_X, "linear-var", 0.0, meta["nmin"], meta["nmax"], meta["T"])
+    gd_ = gdmcf_amd.GaussianDiffusion(ModelMeanType.START_X, "linear-var", 0.0, meta["nmin"], meta["nmax"], meta["T"], DEV)
+    inp = H.step_inputs(fx, 0)
+    want = od.training_losses(om, inp["x"], False, ts=inp["ts"], pt=inp["pt"], noise=inp["noise"], drop_mask=inp["drop_mask"])["loss"]
+    got = gd_.training_losses(model, cu(inp["x"]), False, ts=cu(inp["ts"]), pt=cu(inp["pt"]), noise=cu(inp["noise"]),
+                              drop_mask=cu(inp["drop_mask"]))["loss"]
+    np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=1e-5)
+    with pytest.raises(AttributeError):  # the SNR weights need tables that were never built -- as in the reference
+        gd_.training_losses(model, cu(inp["x"]), True, ts=cu(inp["ts"]), pt=cu(inp["pt"]))
+
+
 def test_thousand_diffusion_steps_match_oracle():
     """T = 1000 (DDPM-scale): the [T, 10] float64 loss history no longer fits the default 48 KB of LDS -- the FIFO
     kernels ask for up to 150 KB.  Training step, history bookkeeping, importance probabilities vs the oracle."""
