@@ -17,7 +17,11 @@ class FusedAdamW(torch.optim.Optimizer):
             raise NotImplementedError("FusedAdamW: amsgrad is not supported")
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
             raise ValueError("FusedAdamW: invalid hyper-parameter")
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        # the remaining keys are torch.optim.AdamW's own (fixed here): with them a state_dict of this optimiser loads into
+        # torch.optim.AdamW with the same meaning -- without `decoupled_weight_decay` torch would fall back to Adam's L2 decay
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, maximize=False,
+                                      foreach=None, capturable=False, differentiable=False, fused=None,
+                                      decoupled_weight_decay=True))
         self._tables = {}
         self.grad_scale = 1.0
         self._fused_ids = set()

@@ -3,6 +3,8 @@
   * the CPU oracle on the same seeded inputs.
 Tolerances: training loss <= 1e-4 relative (north_star); q_sample / history bookkeeping / top-k
 index sets bit-exact; everything else fp32 summation-order noise (stated per test)."""
+import copy
+
 import numpy as np
 import pytest
 import torch
@@ -306,6 +308,41 @@ def test_noise_scale_zero_feeds_the_rows_unnoised():
     np.testing.assert_allclose(got.detach().cpu().numpy(), want.detach().numpy(), rtol=1e-5)
     with pytest.raises(AttributeError):  # the SNR weights need tables that were never built -- as in the reference
         gd_.training_losses(model, cu(inp["x"]), True, ts=cu(inp["ts"]), pt=cu(inp["pt"]))
+
+
+def test_optimizer_state_interchanges_with_torch_adamw():
+    """FusedAdamW's state_dict (step / exp_avg / exp_avg_sq per parameter, the reference optimiser's layout, main.py:258)
+    loads into torch.optim.AdamW and back; both then take the same next step."""
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(37, 53, device=DEV)), torch.nn.Parameter(torch.randn(11, device=DEV))]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    fo = gdmcf_amd.FusedAdamW(ps, lr=1e-2, weight_decay=0.05)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    for _ in range(3):
+        for p in ps:
+            p.grad = torch.randn(p.shape, device=DEV, generator=g)
+        fo.step()
+    to = torch.optim.AdamW(qs, lr=1e-2, weight_decay=0.05)
+    for q, p in zip(qs, ps):
+        q.data.copy_(p.data)
+    # state_dict() hands out the live moment tensors (torch's does too): copy as a checkpoint round trip would
+    to.load_state_dict(copy.deepcopy(fo.state_dict()))  # ours -> torch
+    grads = [torch.randn(p.shape, device=DEV, generator=g) for p in ps]
+    for p, q, gr in zip(ps, qs, grads):
+        p.grad, q.grad = gr.clone(), gr.clone()
+    fo.step()
+    to.step()
+    for p, q in zip(ps, qs):
+        np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=2e-6, atol=2e-7)
+    fo2 = gdmcf_amd.FusedAdamW(ps, lr=1e-2, weight_decay=0.05)
+    fo2.load_state_dict(copy.deepcopy(to.state_dict()))  # torch -> ours (torch keeps `step` as a tensor)
+    for p, q, gr in zip(ps, qs, grads):
+        p.grad, q.grad = gr.clone(), gr.clone()
+    fo2.step()
+    to.step()
+    for p, q in zip(ps, qs):
+        np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=2e-6, atol=2e-7)
+        assert int(fo2.state[p]["step"]) == int(to.state[q]["step"]) == 5
 
 
 def test_thousand_diffusion_steps_match_oracle():
