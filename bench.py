@@ -84,6 +84,9 @@ def parse():
                     help="single GPU: update the two large weights inside the weight-gradient GEMM epilogue "
                          "(FusedAdamW.fuse_into_backward); same update rule, gradient never materialised")
     ap.add_argument("--bpr", action="store_true", help="also time a LightGCN BPR training step (reported under 'bpr')")
+    ap.add_argument("--rehearse-dp", action="store_true",
+                    help="N = 1 only: create a one-rank RCCL group and run every data-parallel collective through it "
+                         "(rehearsal of the N > 1 code path on a single-GPU box)")
     ap.add_argument("--shard-optimizer", action="store_true",
                     help="N > 1: reduce-scatter + AdamW on 1/N of the rows + all-gather instead of all-reduce + full AdamW")
     ap.add_argument("--sampling", action="store_true", help="also time p_sample + masked top-k (reported under 'sampling')")
@@ -133,8 +136,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
-    if world > 1:
+    if world > 1 or args.rehearse_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
     dev = torch.device(f"cuda:{local}")
@@ -174,11 +180,11 @@ def main():
         opt.fuse_into_backward(model)
     model.train()
     torch.manual_seed(1234 + rank)
-    step = DataParallelStep(diffusion, model, opt, shard_optimizer=args.shard_optimizer)
+    step = DataParallelStep(diffusion, model, opt, shard_optimizer=args.shard_optimizer, force_exchange=args.rehearse_dp)
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -199,7 +205,7 @@ def main():
     kernels = collect_prof(lib) if prof else {}
     lib.gdmcf_prof_enable(0)
     final_loss = float(loss)
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t)
@@ -283,7 +289,7 @@ def main():
         if bpr:
             out["bpr"] = bpr
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

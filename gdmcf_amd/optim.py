@@ -136,7 +136,12 @@ class FusedAdamW(torch.optim.Optimizer):
         g = grad_rows if grad_rows.is_contiguous() and grad_rows.dtype == torch.float32 else grad_rows.float().contiguous()
         C, off = param.shape[1], row0 * param.shape[1] * 4
         row = (param.data_ptr() + off, g.data_ptr(), st["exp_avg"].data_ptr() + off, st["exp_avg_sq"].data_ptr() + off, n * C, 0)
-        table = torch.tensor([row], dtype=torch.int64).to(param.device)
+        cache = self.__dict__.setdefault("_row_cache", {})
+        table = cache.get(row)  # gradient shards cycle through a few allocator addresses: no H2D copy once warm
+        if table is None:
+            if len(cache) >= 32:
+                cache.clear()
+            table = cache[row] = torch.tensor([row], dtype=torch.int64).to(param.device)
         lib = _lib.load()
         b1, b2 = group["betas"]
         _lib.check(lib.gdmcf_adamw_f32(table.data_ptr(), 1, (n * C + _BLOCK - 1) // _BLOCK, group["lr"], b1, b2, group["eps"],

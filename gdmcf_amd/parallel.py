@@ -76,10 +76,10 @@ def all_gather_rows_inplace(full, group=None):
     return dist.all_gather_into_tensor(full, mine, group=group, async_op=True)
 
 
-def allreduce_grads(params, group=None, bucket_bytes=256 << 20):
+def allreduce_grads(params, group=None, bucket_bytes=256 << 20, force=False):
     """In-place SUM all-reduce of .grad over ranks.  Large tensors go alone (no copy); small ones are
     coalesced into one flat bucket.  xGMI is point-to-point, so few, large messages are preferred."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
         return
     small, handles = [], []
     for p in params:
@@ -102,9 +102,9 @@ def allreduce_grads(params, group=None, bucket_bytes=256 << 20):
             h.wait()
 
 
-def gather_history_inputs(ts, loss_unscaled, group=None):
+def gather_history_inputs(ts, loss_unscaled, group=None, force=False):
     """All-gather (ts, unscaled per-row loss) in rank order -> tensors of the GLOBAL batch."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
         return ts, loss_unscaled
     world = dist.get_world_size(group)
     dev = ts.device
@@ -117,8 +117,8 @@ def gather_history_inputs(ts, loss_unscaled, group=None):
     return torch.cat(ts_all).to(dev), torch.cat(lu_all).to(dev)
 
 
-def broadcast_parameters(model, group=None, src=0):
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+def broadcast_parameters(model, group=None, src=0, force=False):
+    if dist.is_initialized() and (dist.get_world_size(group) > 1 or force):
         for p in model.parameters():
             if p.is_cuda and _host_staged(group):
                 h = p.data.cpu()
@@ -152,17 +152,20 @@ class DataParallelStep:
     GEMM slow each other down by more than the 0.17 ms that is hidden."""
 
     def __init__(self, diffusion, model, optimizer, group=None, overlap=True, early_update=False, direct_backward=True,
-                 shard_optimizer=False):
+                 shard_optimizer=False, force_exchange=False):
         self.diffusion, self.model, self.optimizer, self.group = diffusion, model, optimizer, group
         self.direct_backward = direct_backward
         self.shard_optimizer = bool(shard_optimizer) and overlap and hasattr(optimizer, "step_rows")
         self._sharded = []
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._handles, self._small = [], []
-        if self.world > 1:
+        # force_exchange: run every collective even in a group of one rank (rehearsal of the RCCL code path on a
+        # single-GPU box; a one-rank SUM is the identity, so the step must equal the plain single-process step)
+        self.exchange = self.world > 1 or (bool(force_exchange) and dist.is_initialized())
+        if self.exchange:
             diffusion.update_history = False  # replayed below on the gathered global batch
             optimizer.grad_scale = 1.0 / self.world
-            broadcast_parameters(model, group)
+            broadcast_parameters(model, group, force=True)
             model.engine.fused_opt = None  # gradients must be all-reduced before the update
             if hasattr(optimizer, "_fused_ids"):
                 optimizer._fused_ids = set()
@@ -196,7 +199,7 @@ class DataParallelStep:
 
     def gather_optimizer_state(self):
         """Sharded optimiser: make exp_avg / exp_avg_sq of the sharded weights complete on every rank (checkpoints)."""
-        if not (self.shard_optimizer and self.world > 1):
+        if not (self.shard_optimizer and self.exchange):
             return
         for p in self.model.parameters():
             st = self.optimizer.state.get(p)
@@ -222,29 +225,38 @@ class DataParallelStep:
     def _finish_exchange(self):
         """One small float64 all-reduce carries (a) every small gradient and (b) the (ts, unscaled loss) pairs of
         all ranks: each rank writes its slice of a zero-initialised [world, B, 2] block, so SUM == all-gather in
-        rank order.  Returns (ts_all, lu_all) of the global batch."""
+        rank order (gdmcf_dp_pack_f64 / gdmcf_dp_unpack_f64: one kernel each side of the collective).  Returns
+        (ts_all, lu_all) of the global batch."""
+        import ctypes
+        from . import _lib
+        lib, st = _lib.load(), _lib.stream_ptr()
         d = self.diffusion
         ts, lu = d.last_ts, d.last_loss_unscaled
         B, dev = ts.numel(), ts.device
-        n_small = sum(g.numel() for g in self._small)
-        flat = torch.zeros(n_small + self.world * B * 2, dtype=torch.float64, device=dev)
-        off = 0
-        for g in self._small:
-            flat[off:off + g.numel()] = g.reshape(-1)
-            off += g.numel()
-        hist = flat[n_small:].view(self.world, B, 2)
         rank = dist.get_rank(self.group)
-        hist[rank, :, 0] = ts.to(torch.float64)  # exact for any realistic number of diffusion steps
-        hist[rank, :, 1] = lu
-        # the large all-reduces complete in launch order; every tensor but the last is updated the moment its
+        small = self._small
+        for i, g in enumerate(small):
+            if g.dtype != torch.float32 or not g.is_contiguous():
+                raise RuntimeError("DataParallelStep: small gradients must be contiguous float32")
+        n = len(small)
+        if n > 16:
+            raise RuntimeError("DataParallelStep: more than 16 small gradient tensors")
+        ptrs = (ctypes.c_void_p * max(n, 1))(*[g.data_ptr() for g in small])
+        counts = (ctypes.c_int64 * max(n, 1))(*[g.numel() for g in small])
+        n_small = sum(g.numel() for g in small)
+        flat = torch.empty(n_small + self.world * B * 2, dtype=torch.float64, device=dev)
+        ts = ts if ts.dtype == torch.int64 and ts.is_contiguous() else ts.to(torch.int64).contiguous()
+        lu = lu if lu.dtype == torch.float64 and lu.is_contiguous() else lu.double().contiguous()
+        _lib.check(lib.gdmcf_dp_pack_f64(ptrs, counts, n, ts.data_ptr(), lu.data_ptr(), B, rank, self.world,
+                                         flat.data_ptr(), st))
+        # the large exchanges complete in launch order; every tensor but the last is updated the moment its
         # own reduction is done, so that AdamW pass overlaps the reductions still on the wire
         gathers = []
-        rank = dist.get_rank(self.group)
         for param, grad, shard, h, tail, h2, n_eq in self._sharded:
             if h is not None:
                 h.wait()
-            n = n_eq // self.world
-            self.optimizer.step_rows(param, shard, rank * n)
+            nr = n_eq // self.world
+            self.optimizer.step_rows(param, shard, rank * nr)
             if tail.numel():
                 if h2 is not None:
                     h2.wait()
@@ -259,12 +271,12 @@ class DataParallelStep:
             if early and k + 1 < len(self._handles):
                 self.optimizer.step_subset([param])
         _all_reduce(flat, self.group)
-        off = 0
-        for g in self._small:
-            g.copy_(flat[off:off + g.numel()].view_as(g))
-            off += g.numel()
+        ts_all = torch.empty(self.world * B, dtype=torch.int64, device=dev)
+        lu_all = torch.empty(self.world * B, dtype=torch.float64, device=dev)
+        _lib.check(lib.gdmcf_dp_unpack_f64(flat.data_ptr(), ptrs, counts, n, B, self.world, ts_all.data_ptr(),
+                                           lu_all.data_ptr(), st))
         self._handles, self._small = [], []
-        return hist[:, :, 0].reshape(-1).to(torch.int64).contiguous(), hist[:, :, 1].reshape(-1).contiguous()
+        return ts_all, lu_all
 
     def __call__(self, batch, reweight=True, **rand):
         from . import _lib
@@ -284,13 +296,13 @@ class DataParallelStep:
             losses = self.diffusion.training_losses(self.model, batch, reweight, **rand)
             loss = losses["loss"].mean()
             loss.backward()
-        if self.world > 1:
+        if self.exchange:
             d = self.diffusion
             if self.model.engine.grad_sink is not None:
                 ts_all, lu_all = self._finish_exchange()
             else:
-                allreduce_grads(self.model.parameters(), self.group)
-                ts_all, lu_all = gather_history_inputs(d.last_ts, d.last_loss_unscaled, self.group)
+                allreduce_grads(self.model.parameters(), self.group, force=True)
+                ts_all, lu_all = gather_history_inputs(d.last_ts, d.last_loss_unscaled, self.group, force=True)
             _lib.check(_lib.load().gdmcf_lt_history_update(ts_all.data_ptr(), lu_all.data_ptr(), ts_all.numel(),
                                                            d.steps, d.history_num_per_term, d.Lt_history.data_ptr(),
                                                            d.Lt_count.data_ptr(), _lib.stream_ptr()))

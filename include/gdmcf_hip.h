@@ -202,6 +202,21 @@ int gdmcf_row_loss_finish_f64(const float* rowsum, const float* rowdiv, const fl
 int gdmcf_lt_history_update(const int64_t* ts, const double* loss_unscaled, int B, int T, int H,
                             double* Lt_history, int64_t* Lt_count, void* stream);
 
+/* ---- data-parallel exchange helpers (new: the reference is single-process; main.py:345-351 is the step whose
+ * gradients are exchanged).  One float64 buffer `flat` carries, per rank and step,
+ *   [ sum(counts) ]   the n (<= 16) small float32 gradients, concatenated in table order, and
+ *   [world][B][2]     (ts, unscaled loss) of every rank's rows -- a rank writes its own slice, zeros elsewhere,
+ * so a single SUM all-reduce of `flat` both reduces the small gradients and gathers the history inputs in rank
+ * order (what gdmcf_lt_history_update then replays on the global batch).  `grads` / `counts` are HOST arrays of
+ * device pointers / element counts (copied into the kernel arguments).
+ * pack: flat <- this rank's contribution.  unpack: gradients <- (float)flat, ts_all[world*B] (int64) and
+ * loss_unscaled_all[world*B] (float64) contiguous in rank order.                                              */
+int gdmcf_dp_pack_f64(const float* const* grads, const int64_t* counts, int n, const int64_t* ts,
+                      const double* loss_unscaled, int B, int rank, int world, double* flat,
+                      void* stream);
+int gdmcf_dp_unpack_f64(const double* flat, float* const* grads, const int64_t* counts, int n, int B,
+                        int world, int64_t* ts_all, double* loss_unscaled_all, void* stream);
+
 /* ---- importance-sampled timesteps (gaussian_diffusion.py:373-397), one launch, no host sync ----
  * Until every Lt_count == H: t ~ uniform{0..T-1}, pt = 1.  Afterwards p = sqrt(mean(Lt_history^2))
  * normalised, mixed as p*(1-uniform_prob) + uniform_prob/T; t by inverse CDF, pt = p[t]*T.

@@ -211,3 +211,68 @@ def test_sharded_optimizer_equals_all_reduce_path(tmp_path):
     assert r0["ok"] and r1["ok"]
     for a, b in zip(r0["params"], r1["params"]):
         assert torch.equal(a, b)
+
+
+def _rccl_worker(rank, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    import gdmcf_amd
+    from gdmcf_amd import parallel
+    from gdmcf_amd.parallel import DataParallelStep
+    dev, I2, H2, B2 = "cuda:0", 3001, 128, 32
+
+    def run(**kw):
+        torch.manual_seed(5)
+        m = gdmcf_amd.DNN([I2, H2], [H2, I2], 10).to(dev).train()
+        d = gdmcf_amd.GaussianDiffusion(gdmcf_amd.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, T, dev)
+        o = gdmcf_amd.FusedAdamW(m.parameters(), lr=1e-3, weight_decay=0.01)
+        step = DataParallelStep(d, m, o, **kw)
+        losses = []
+        for s in range(4):
+            g = torch.Generator().manual_seed(50 + s)
+            x = (torch.rand(B2, I2, generator=g) < 0.03).float().to(dev)
+            ts = torch.randint(0, T, (B2,), generator=g).to(dev)
+            noise = torch.randn(B2, I2, generator=g).to(dev)
+            keep = (torch.rand(B2, I2, generator=g) < 0.5).float().to(dev)
+            losses.append(float(step(x, True, ts=ts, pt=torch.ones(B2, device=dev), noise=noise, drop_mask=keep)))
+        step.gather_optimizer_state()
+        torch.cuda.synchronize()
+        return m, o, losses, d, step
+
+    ref = run()  # one rank, no exchange
+    res = {}
+    for name, kw in (("allreduce", dict(force_exchange=True)), ("sharded", dict(force_exchange=True, shard_optimizer=True)),
+                     ("no_overlap", dict(force_exchange=True, overlap=False))):
+        got = run(**kw)
+        ok = got[4].exchange and ref[2] == got[2]
+        for a, b in zip(ref[0].parameters(), got[0].parameters()):
+            ok = ok and torch.equal(a, b) and torch.equal(ref[1].state[a]["exp_avg_sq"], got[1].state[b]["exp_avg_sq"])
+        ok = ok and torch.equal(ref[3].Lt_history, got[3].Lt_history) and torch.equal(ref[3].Lt_count, got[3].Lt_count)
+        res[name] = bool(ok)
+    # the row collectives on device tensors
+    t = torch.arange(12, dtype=torch.float32, device=dev).view(4, 3)
+    full = t.clone()
+    h = parallel.all_gather_rows_inplace(full)
+    if h is not None:
+        h.wait()
+    shard, h = parallel.reduce_scatter_rows(t.clone())
+    if h is not None:
+        h.wait()
+    torch.cuda.synchronize()
+    res["rows"] = bool(torch.equal(full, t) and torch.equal(shard, t) and torch.equal(parallel.all_gather_rows(t, 3), t[:3]))
+    torch.save(res, os.path.join(out_dir, "rccl.pt"))
+    dist.destroy_process_group()
+
+
+def test_rccl_one_rank_group_runs_every_collective(tmp_path):
+    """The production backend ("nccl" = RCCL) cannot put two ranks on the one GPU of the test box, so the device-side
+    collective calls (async all-reduce handles, reduce_scatter_tensor, the in-place all_gather_into_tensor, broadcast)
+    are rehearsed in a group of ONE rank with force_exchange=True: a one-rank SUM is the identity, so losses, weights,
+    moments and the Lt history must equal the plain single-process step bit for bit."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_rccl_worker, args=(port, str(tmp_path)), nprocs=1, join=True)
+    res = torch.load(tmp_path / "rccl.pt")
+    assert res == dict(allreduce=True, sharded=True, no_overlap=True, rows=True), res
