@@ -16,8 +16,9 @@ Besides the contract fields the JSON line carries
                   the reference by tests/golden) timed on this host's cores on the same workload.
 
 Other legs / variants (not part of the default line): --gemm-dtype bf16 (BASELINE configs[2]), --workload
-amazon-book|stress, --fuse-optimizer (AdamW inside the weight-gradient GEMM epilogues, N = 1), --shard-optimizer
-(N > 1: reduce-scatter + AdamW on 1/N of the rows + all-gather), --global-batch G (strong scaling), --spmm (LightGCN
+amazon-book|stress, --fuse-optimizer (AdamW inside the weight-gradient GEMM epilogues, N = 1), --allreduce-optimizer (N > 1: plain
+all-reduce + full AdamW on every rank instead of the default reduce-scatter + AdamW on 1/N of the rows + deferred
+all-gather), --rehearse-dp (N = 1: every collective through a one-rank RCCL group), --global-batch G (strong scaling), --spmm (LightGCN
 propagation; row-sharded when N > 1), --bpr (LightGCN BPR training step), --sampling (p_sample + masked top-k).
 """
 import argparse
@@ -88,7 +89,10 @@ def parse():
                     help="N = 1 only: create a one-rank RCCL group and run every data-parallel collective through it "
                          "(rehearsal of the N > 1 code path on a single-GPU box)")
     ap.add_argument("--shard-optimizer", action="store_true",
-                    help="N > 1: reduce-scatter + AdamW on 1/N of the rows + all-gather instead of all-reduce + full AdamW")
+                    help="reduce-scatter + AdamW on 1/N of the rows + all-gather (the default when N > 1; with "
+                         "--rehearse-dp it selects that path at N = 1)")
+    ap.add_argument("--allreduce-optimizer", action="store_true",
+                    help="N > 1: all-reduce of the gradients + full AdamW on every rank instead of the sharded optimiser")
     ap.add_argument("--sampling", action="store_true", help="also time p_sample + masked top-k (reported under 'sampling')")
     return ap.parse_args()
 
@@ -180,7 +184,10 @@ def main():
         opt.fuse_into_backward(model)
     model.train()
     torch.manual_seed(1234 + rank)
-    step = DataParallelStep(diffusion, model, opt, shard_optimizer=args.shard_optimizer, force_exchange=args.rehearse_dp)
+    # N > 1: the same bytes cross xGMI either way (reduce-scatter + all-gather == all-reduce), but the sharded
+    # optimiser touches 1/N of the AdamW state per GPU and its all-gathers overlap the next step's first GEMMs
+    sharded = (args.shard_optimizer or world > 1) and not args.allreduce_optimizer
+    step = DataParallelStep(diffusion, model, opt, shard_optimizer=sharded, force_exchange=args.rehearse_dp)
 
     def sync():
         torch.cuda.synchronize()
@@ -278,7 +285,9 @@ def main():
                        "n_items": I, "global_batch": world * B, "parallelism": f"dp{world}"},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": klist, "final_loss": final_loss,
             "optimizer": "FusedAdamW" + (" fused into the dW GEMM epilogues" if (args.fuse_optimizer and world == 1) else
-                                         " (row-sharded over the ranks)" if (args.shard_optimizer and world > 1) else " (separate pass)"),
+                                         " (row-sharded over the ranks: reduce-scatter, AdamW on 1/N rows, deferred all-gather)"
+                                         if (sharded and step.exchange) else
+                                         " (separate pass after the gradient all-reduce)" if step.exchange else " (separate pass)"),
         }
         if cpu:
             out["speedup_vs_cpu"] = round(out["value"] / cpu["value"], 1)

@@ -65,6 +65,24 @@ class DenoiserEngine:
         # compute a layer's input gradient before its weight gradient (needed when the weight may be updated as
         # soon as its gradient exists: fused optimiser, single-process early update in parallel.DataParallelStep)
         self.input_grad_first = False
+        # id(weight) -> callable that makes the current stream wait until the weight is complete.  Set by the sharded
+        # data-parallel optimiser, whose all-gather of the other ranks' updated rows may still be on the wire when the
+        # next step starts: train_forward waits per layer, right before the first GEMM that reads the weight, so the
+        # last layer's gather travels under the first layers' GEMMs.  Every other entry point waits for all up front.
+        self.weight_waiters = {}
+
+    def _use_weight(self, w):
+        fn = self.weight_waiters.pop(id(w), None) if self.weight_waiters else None
+        if fn is not None:
+            fn()
+            rec = self._wshadow.get(id(w))
+            if rec is not None and rec[1] != w._version:
+                rec[0].sync()
+                rec[1] = w._version
+
+    def flush_weight_waiters(self):
+        while self.weight_waiters:
+            self.weight_waiters.popitem()[1]()
 
     @property
     def gemm_dtype(self):
@@ -105,9 +123,12 @@ class DenoiserEngine:
         for w, _, _ in layers:
             rec = self._wshadow.get(id(w))
             if rec is None or rec[0].ptr != w.data_ptr():
+                self._use_weight(w)  # the first cast reads the weight
                 if rec is not None:
                     rec[0].close()
                 self._wshadow[id(w)] = [_lib.Bf16Shadow(w.detach()), w._version]
+            elif id(w) in self.weight_waiters:
+                continue  # still arriving: refreshed in _use_weight
             elif rec[1] != w._version:
                 rec[0].sync()
                 rec[1] = w._version
@@ -194,6 +215,7 @@ class DenoiserEngine:
         for li, (w, bias, act) in enumerate(layers[:-1]):
             N, K = w.shape
             out = bufs.acts[li]
+            self._use_weight(w)
             _lib.check(lib.gdmcf_linear_fwd_f32(A.data_ptr(), lda, w.data_ptr(), w.stride(0), bias.data_ptr(), act, B,
                                                 N, K, out.data_ptr(), out.stride(0), bufs.ws.data_ptr(),
                                                 bufs.ws_bytes, st))
@@ -236,6 +258,7 @@ class DenoiserEngine:
         A, lda = self._hidden_forward(bufs, layers, B)
         w, bias, _ = layers[-1]
         N, K = w.shape
+        self._use_weight(w)
         _lib.check(lib.gdmcf_linear_loss_fwd_f32(A.data_ptr(), lda, w.data_ptr(), w.stride(0), bias.data_ptr(),
                                                  target.data_ptr(), target.stride(0), _lib.ptr(alpha), B, N, K, None,
                                                  0, bufs.diff.data_ptr(), bufs.ldi, bufs.rowpart.data_ptr(),
@@ -269,6 +292,7 @@ class DenoiserEngine:
     # ------------------------------------------------------------------------------------------
     @_with_precision
     def forward_plain(self, x, timesteps, training, drop_mask=None):
+        self.flush_weight_waiters()
         B, dev = x.shape[0], x.device
         layers = self._layers()
         bufs = self.buffers(B, dev)
@@ -387,6 +411,7 @@ class DenoiserEngine:
                       capture=None):
         """tabs32: dict of float32 device tables [T] (sqrt_ab, sqrt_1mab, c1, c2, r1, r2, sigma)."""
         m, lib = self.model, self.lib
+        self.flush_weight_waiters()
         B, dev, I = x_start.shape[0], x_start.device, self.I
         layers = self._layers()
         bufs = self.buffers(B, dev)

@@ -11,6 +11,8 @@ shards over ranks with exactly one exchange per step:
     global batch in rank order.
 The reference has no distributed path; this is new, MI355X-first design.
 """
+import functools
+
 import torch
 import torch.distributed as dist
 
@@ -143,6 +145,10 @@ class DataParallelStep:
     rank runs AdamW on its 1/world of the rows only (`FusedAdamW.step_rows`) and the updated rows are all-gathered in
     place -- the same bytes on the wire as an all-reduce, 1/world of the optimiser's HBM traffic per GPU.  The moments
     of a sharded weight are then current only in the rank's own rows (`gather_optimizer_state()` before saving).
+    The all-gathers are issued first-layer first and NOT waited for at the end of the step (`defer_gather`): the engine
+    waits right before the first GEMM that reads each weight, so the last layer's gather travels under the next step's
+    input builder and first-layer GEMMs.  Any forward through the engine and `model.state_dict()` wait by themselves;
+    call `flush()` before reading `model.parameters()` directly.
 
     Single process (world == 1): no exchange.  `early_update=True` issues the AdamW update of a large tensor on a
     side stream the moment its gradient GEMM is enqueued (the engine then computes a layer's input gradient BEFORE
@@ -152,9 +158,10 @@ class DataParallelStep:
     GEMM slow each other down by more than the 0.17 ms that is hidden."""
 
     def __init__(self, diffusion, model, optimizer, group=None, overlap=True, early_update=False, direct_backward=True,
-                 shard_optimizer=False, force_exchange=False):
+                 shard_optimizer=False, force_exchange=False, defer_gather=True):
         self.diffusion, self.model, self.optimizer, self.group = diffusion, model, optimizer, group
         self.direct_backward = direct_backward
+        self.defer_gather = bool(defer_gather)
         self.shard_optimizer = bool(shard_optimizer) and overlap and hasattr(optimizer, "step_rows")
         self._sharded = []
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -171,6 +178,8 @@ class DataParallelStep:
                 optimizer._fused_ids = set()
             if overlap:
                 model.engine.grad_sink = self._sink
+            if self.shard_optimizer and self.defer_gather:
+                model.register_state_dict_pre_hook(lambda *a, **k: self.flush())  # complete weights in checkpoints
         elif (early_update and hasattr(optimizer, "step_subset") and getattr(model.engine, "fused_opt", None) is None
               and next(model.parameters()).is_cuda):
             self._side = torch.cuda.Stream()
@@ -201,6 +210,7 @@ class DataParallelStep:
         """Sharded optimiser: make exp_avg / exp_avg_sq of the sharded weights complete on every rank (checkpoints)."""
         if not (self.shard_optimizer and self.exchange):
             return
+        self.flush()
         for p in self.model.parameters():
             st = self.optimizer.state.get(p)
             if st and p.dim() == 2 and p.numel() * 4 >= (1 << 20) and p.shape[0] >= self.world:
@@ -249,9 +259,9 @@ class DataParallelStep:
         lu = lu if lu.dtype == torch.float64 and lu.is_contiguous() else lu.double().contiguous()
         _lib.check(lib.gdmcf_dp_pack_f64(ptrs, counts, n, ts.data_ptr(), lu.data_ptr(), B, rank, self.world,
                                          flat.data_ptr(), st))
-        # the large exchanges complete in launch order; every tensor but the last is updated the moment its
-        # own reduction is done, so that AdamW pass overlaps the reductions still on the wire
-        gathers = []
+        # sharded optimiser: the tiny bucket goes on the wire right behind the reduce-scatters, ahead of the all-gathers
+        hflat = _all_reduce(flat, self.group, async_op=True) if self._sharded else None
+        pending = []
         for param, grad, shard, h, tail, h2, n_eq in self._sharded:
             if h is not None:
                 h.wait()
@@ -261,16 +271,22 @@ class DataParallelStep:
                 if h2 is not None:
                     h2.wait()
                 self.optimizer.step_rows(param, tail, n_eq)
-            gathers.append((param, all_gather_rows_inplace(param.data[:n_eq], self.group)))
-        self._sharded = []
-        self._gathers = gathers
+            pending.append((param, n_eq))
+        # gradients arrive last-layer first, the next forward needs the first layer first: gather in reverse order
+        self._gathers = [(param, all_gather_rows_inplace(param.data[:n_eq], self.group)) for param, n_eq in reversed(pending)]
+        had_sharded, self._sharded = bool(self._sharded), []
+        # the large all-reduces complete in launch order; every tensor but the last is updated the moment its
+        # own reduction is done, so that AdamW pass overlaps the reductions still on the wire
         early = hasattr(self.optimizer, "step_subset")
         for k, (param, h) in enumerate(self._handles):
             if h is not None:
                 h.wait()
             if early and k + 1 < len(self._handles):
                 self.optimizer.step_subset([param])
-        _all_reduce(flat, self.group)
+        if not had_sharded:
+            _all_reduce(flat, self.group)
+        elif hflat is not None:
+            hflat.wait()
         ts_all = torch.empty(self.world * B, dtype=torch.int64, device=dev)
         lu_all = torch.empty(self.world * B, dtype=torch.float64, device=dev)
         _lib.check(lib.gdmcf_dp_unpack_f64(flat.data_ptr(), ptrs, counts, n, B, self.world, ts_all.data_ptr(),
@@ -311,8 +327,23 @@ class DataParallelStep:
             self._side_busy = False
         self.optimizer.step()
         for param, h in getattr(self, "_gathers", []):  # updated row blocks of the other ranks
-            if h is not None:
-                h.wait()
-            torch.autograd.graph.increment_version(param)
+            if self.defer_gather and eng is not None:
+                # still on the wire: the engine waits right before the first GEMM of the next forward that reads it
+                eng.weight_waiters[id(param)] = functools.partial(self._arrived, param, h)
+            else:
+                self._arrived(param, h)
         self._gathers = []
         return loss.detach()
+
+    @staticmethod
+    def _arrived(param, h):
+        if h is not None:
+            h.wait()
+        torch.autograd.graph.increment_version(param)
+
+    def flush(self):
+        """Wait (on the current stream) for every all-gather of updated weight rows still in flight.  The engine does
+        this by itself before any forward; call it before reading the parameters directly (checkpoints, copies)."""
+        eng = getattr(self.model, "engine", None)
+        if eng is not None:
+            eng.flush_weight_waiters()

@@ -236,9 +236,12 @@ def _rccl_worker(rank, port, out_dir):
             noise = torch.randn(B2, I2, generator=g).to(dev)
             keep = (torch.rand(B2, I2, generator=g) < 0.5).float().to(dev)
             losses.append(float(step(x, True, ts=ts, pt=torch.ones(B2, device=dev), noise=noise, drop_mask=keep)))
+        deferred = len(m.engine.weight_waiters)  # all-gathers of updated rows not waited for yet
+        m.state_dict()
+        deferred = (deferred, len(m.engine.weight_waiters))
         step.gather_optimizer_state()
         torch.cuda.synchronize()
-        return m, o, losses, d, step
+        return m, o, losses, d, step, deferred
 
     ref = run()  # one rank, no exchange
     res = {}
@@ -249,6 +252,7 @@ def _rccl_worker(rank, port, out_dir):
         for a, b in zip(ref[0].parameters(), got[0].parameters()):
             ok = ok and torch.equal(a, b) and torch.equal(ref[1].state[a]["exp_avg_sq"], got[1].state[b]["exp_avg_sq"])
         ok = ok and torch.equal(ref[3].Lt_history, got[3].Lt_history) and torch.equal(ref[3].Lt_count, got[3].Lt_count)
+        ok = ok and got[5] == ((2, 0) if name == "sharded" else (0, 0))
         res[name] = bool(ok)
     # the row collectives on device tensors
     t = torch.arange(12, dtype=torch.float32, device=dev).view(4, 3)
