@@ -207,6 +207,7 @@ def main():
         if prof:
             lib.gdmcf_prof_enable(1 if i % every == 0 else 2)  # 2 = pause, records kept
         loss = step(dcsr.rows(row_ids[i % n_pool], out=x_buf), True)
+    host_el = time.perf_counter() - t0  # enqueue time only: well below `el` when the host runs ahead of the GPU
     sync()
     el = time.perf_counter() - t0
     kernels = collect_prof(lib) if prof else {}
@@ -284,6 +285,7 @@ def main():
                                       if args.workload == "amazon-book" and args.gemm_dtype == "bf16" else ""),
                        "n_items": I, "global_batch": world * B, "parallelism": f"dp{world}"},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": klist, "final_loss": final_loss,
+            "host_enqueue_ms_per_step": round(1e3 * host_el / args.steps, 4),
             "optimizer": "FusedAdamW" + (" fused into the dW GEMM epilogues" if (args.fuse_optimizer and world == 1) else
                                          " (row-sharded over the ranks: reduce-scatter, AdamW on 1/N rows, deferred all-gather)"
                                          if (sharded and step.exchange) else
