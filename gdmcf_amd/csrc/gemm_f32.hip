@@ -71,7 +71,7 @@ struct TileStage {
     using G = TileGeom<LAY, R, BK>;
     f32x4 reg[G::NL];
 
-    // Interior tile: k0 + BK <= kend and (MC layout) row0 + R <= nrows.  Nothing but address arithmetic and
+    // Interior tile: k0 + BK <= kend and (MC layout) row0 + R <= nrows or nrows % 4 == 0.  Nothing but address arithmetic and
     // loads, so all of them issue back to back and the only wait is at the LDS write after the MFMAs.
     // KC rows past `nrows` are clamped onto valid rows (their products land in accumulator rows/columns
     // that the epilogue never stores).
@@ -86,8 +86,10 @@ struct TileStage {
                 const int gr = min(row0 + r, nrows - 1);
                 reg[i] = gload16(P + (int64_t)gr * ld + (k0 + kk));
             } else {
+                // partial last row block with nrows % 4 == 0 (see load()): groups past the edge are clamped onto the
+                // last valid one; their products land in accumulator rows/columns that are never stored
                 const int kk = idx / (R / 4), r = (idx % (R / 4)) * 4;
-                reg[i] = gload16(P + (int64_t)(k0 + kk) * ld + (row0 + r));
+                reg[i] = gload16(P + (int64_t)(k0 + kk) * ld + min(row0 + r, nrows - 4));
             }
         }
     }
@@ -160,8 +162,11 @@ struct TileStage {
             const int r = idx / (BK / 4), kk = (idx % (BK / 4)) * 4;
             return P + (int64_t)min(row0 + r, nrows - 1) * ld + (k0 + kk);
         }
+        // M-contiguous operand, last row block: 4-float groups past `nrows` are clamped onto the last valid group
+        // (callers take this path for partial blocks only when nrows % 4 == 0, so no group straddles the edge);
+        // what they carry lands in accumulator rows/columns the epilogue never stores.
         const int kk = idx / (R / 4), r = (idx % (R / 4)) * 4;
-        return P + (int64_t)(k0 + kk) * ld + (row0 + r);
+        return P + (int64_t)(k0 + kk) * ld + min(row0 + r, nrows - 4);
     }
     static __device__ __forceinline__ int64_t tile_step(int64_t ld) { return (LAY == GD_LAY_KC) ? BK : (int64_t)BK * ld; }
     // LDS float offset of slot i (-1: this thread has no element in the partial last slot)
@@ -185,7 +190,7 @@ struct TileStage {
         // vmcnt waits stay exact across the join (a third, predicated path would force conservative waits
         // that drain the second register stage).  Degenerate shapes never get here (gemm_small.hip takes them).
         const bool k_full = (k0 + BK <= kend);
-        if (k_full && (LAY == GD_LAY_KC || rows_full)) {
+        if (k_full && (LAY == GD_LAY_KC || rows_full || (nrows & 3) == 0)) {
             mode = 0;
             load_plain(P, ld, row0, nrows, k0, tid);
         } else {
@@ -351,7 +356,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GdGemm g) {
     // fragments of chunk 1 are fetched during chunk 0.  sched_barrier(0) pins the order.  Interior tiles
     // only; the generic loop below finishes the tail (and runs boundary workgroups entirely).
     const int nt_full = (kend - kbeg) / BK;
-    if ((LAYA == GD_LAY_KC || a_full) && (LAYB == GD_LAY_KC || b_full) && nt_full >= 4) {
+    // (an M-contiguous operand's partial last block qualifies when its extent is a multiple of 4: slot_ptr clamps)
+    if ((LAYA == GD_LAY_KC || a_full || (g.M & 3) == 0) && (LAYB == GD_LAY_KC || b_full || (g.N & 3) == 0) && nt_full >= 4) {
         const float* pa[GA::NL];
         const float* pb[GB::NL];
         int wa[GA::NL], wb[GB::NL];
