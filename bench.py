@@ -218,6 +218,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t)
 
+    # ---- data parallel: every replica must hold bit-identical parameters after the run (outside the timed region) ----
+    in_sync = None
+    if dist.is_initialized():
+        step.flush()
+        cs = torch.stack([p.detach().double().sum() for p in model.parameters()] +
+                         [p.detach().double().abs().max() for p in model.parameters()])
+        lo, hi = cs.clone(), cs.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        in_sync = bool(torch.equal(lo, hi))
+
     # ---- roofline of the dominant kernel (rank 0's events) ----
     roofline, klist = None, []
     for tag, d in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"]):
@@ -286,6 +297,7 @@ def main():
                        "n_items": I, "global_batch": world * B, "parallelism": f"dp{world}"},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": klist, "final_loss": final_loss,
             "host_enqueue_ms_per_step": round(1e3 * host_el / args.steps, 4),
+            "replicas_in_sync": in_sync,
             "optimizer": "FusedAdamW" + (" fused into the dW GEMM epilogues" if (args.fuse_optimizer and world == 1) else
                                          " (row-sharded over the ranks: reduce-scatter, AdamW on 1/N rows, deferred all-gather)"
                                          if (sharded and step.exchange) else

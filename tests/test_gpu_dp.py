@@ -280,3 +280,24 @@ def test_rccl_one_rank_group_runs_every_collective(tmp_path):
     mp.spawn(_rccl_worker, args=(port, str(tmp_path)), nprocs=1, join=True)
     res = torch.load(tmp_path / "rccl.pt")
     assert res == dict(allreduce=True, sharded=True, no_overlap=True, rows=True), res
+
+
+def test_bench_data_parallel_path_in_a_one_rank_rccl_group():
+    """bench.py --rehearse-dp: the line the driver gets at N > 1 (sharded optimiser, deferred all-gathers, barrier +
+    max-over-ranks timing, replica check) produced through a one-rank RCCL group; same loss as the plain run."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for extra in (["--rehearse-dp", "--shard-optimizer"], ["--rehearse-dp", "--allreduce-optimizer"], []):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "2",
+                            "--no-cpu-baseline"] + extra, capture_output=True, text=True, cwd=root, timeout=600,
+                           env=dict(os.environ, MASTER_PORT="29571"))
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1]))
+    sh, ar, plain = outs
+    assert sh["replicas_in_sync"] is True and ar["replicas_in_sync"] is True and plain["replicas_in_sync"] is None
+    assert "row-sharded" in sh["optimizer"] and "all-reduce" in ar["optimizer"]
+    assert sh["final_loss"] == ar["final_loss"] == plain["final_loss"]
+    assert sh["n_gpus"] == 1 and sh["scaling"] == "weak"
