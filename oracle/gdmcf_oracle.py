@@ -13,6 +13,8 @@ per-batch forward / reverse Gaussian-diffusion path in eager PyTorch-CPU / numpy
   * train step (AdamW)      reference main.py:258, :343-351
   * evaluate / top-k        reference main.py:267-310, evaluate_utils.py:6-52
   * LightGCN propagation    reference lightGCN.py:145-194
+  * one-hot variant (f1a)   reference models/DNN.py:360-477 (DNNOneHot), gaussian_diffusion.py:552-1135
+                            (GaussianDiffusionDiscrete, CatOneHot=True, indexIn=False)
 
 Parity status: PINNED.  The reference ships no tests or golden vectors, so the
 oracle is pinned against outputs of the reference itself, run in the build container by
@@ -335,6 +337,191 @@ class GaussianDiffusion:
             else:
                 x_t = out["mean"]
         return x_t
+
+
+# ----------------------------------------------------------------------------------------
+# one-hot / discrete-noise variant (first slice): backbone `DNNOneHot` (reference models/DNN.py:360-477)
+# driven by `GaussianDiffusionDiscrete` with CatOneHot=True, indexIn=False (reference gaussian_diffusion.py:552-1135)
+# ----------------------------------------------------------------------------------------
+class DNNOneHot(nn.Module):
+    """Two input branches -- [x_t, emb] through in_layers and the flattened one-hot rows [x_U (2 per item), emb] through
+    in_layers2 -- concatenated in front of out_layers.  As in the reference, `out_dims[0]` of the CALLER's list grows by
+    the width of the second branch (DNN.py:384-385 aliases and mutates it)."""
+
+    def __init__(self, in_dims, out_dims, emb_size, time_type="cat", norm=False, dropout=0.5):
+        super().__init__()
+        self.in_dims = in_dims
+        self.in_dims2 = list(in_dims)
+        self.in_dims2[0] *= 2
+        self.out_dims = out_dims
+        assert out_dims[0] == in_dims[-1], "In and out dimensions must equal to each other."
+        if time_type != "cat":
+            raise ValueError("Unimplemented timestep embedding type %s" % time_type)
+        self.time_type, self.time_emb_dim, self.norm, self.p = time_type, emb_size, norm, dropout
+        self.emb_layer = nn.Linear(emb_size, emb_size)
+        ind = [in_dims[0] + emb_size] + list(in_dims[1:])
+        ind2 = [self.in_dims2[0] + emb_size] + list(self.in_dims2[1:])
+        out_dims[0] += self.in_dims2[-1]
+        self.in_layers = nn.ModuleList([nn.Linear(a, b) for a, b in zip(ind[:-1], ind[1:])])
+        self.in_layers2 = nn.ModuleList([nn.Linear(a, b) for a, b in zip(ind2[:-1], ind2[1:])])
+        self.out_layers = nn.ModuleList([nn.Linear(a, b) for a, b in zip(out_dims[:-1], out_dims[1:])])
+        self.drop = nn.Dropout(dropout)
+        self.init_weights()
+
+    def init_weights(self):
+        # draw order of the reference (DNN.py:401-440): in_layers, in_layers2, out_layers, emb_layer; weight then bias
+        for layer in list(self.in_layers) + list(self.in_layers2) + list(self.out_layers) + [self.emb_layer]:
+            fan_out, fan_in = layer.weight.shape
+            layer.weight.data.normal_(0.0, np.sqrt(2.0 / (fan_in + fan_out)))
+            layer.bias.data.normal_(0.0, 0.001)
+
+    def forward(self, x, timesteps, x_U, drop_mask=None, drop_mask_U=None):  # reference DNN.py:442-477
+        x_U = x_U.reshape(x_U.shape[0], -1)
+        emb = self.emb_layer(timestep_embedding(timesteps, self.time_emb_dim).to(x.device))
+        if self.norm:
+            x = torch.nn.functional.normalize(x)
+            x_U = torch.nn.functional.normalize(x_U)
+        if drop_mask is not None:
+            x = x * (drop_mask.to(x.dtype) / (1.0 - self.p))
+            x_U = x_U * (drop_mask_U.reshape(x_U.shape).to(x.dtype) / (1.0 - self.p))
+        else:
+            x = self.drop(x)
+            x_U = self.drop(x_U)
+        h = torch.cat([x, emb], dim=-1)
+        for layer in self.in_layers:
+            h = torch.tanh(layer(h))
+        h_U = torch.cat([x_U, emb], dim=-1)
+        for layer in self.in_layers2:
+            h_U = torch.tanh(layer(h_U))
+        h = torch.cat([h, h_U], dim=1)
+        for i, layer in enumerate(self.out_layers):
+            h = layer(h)
+            if i != len(self.out_layers) - 1:
+                h = torch.tanh(h)
+        return h
+
+
+class GaussianDiffusionDiscrete(GaussianDiffusion):
+    """CatOneHot path of the reference's GaussianDiffusionDiscrete (gaussian_diffusion.py:552-1135), indexIn False:
+    the rows are additionally handed to the model as one-hot pairs whose bits survive only where a draw from
+    Q_bar = a*I + (1-a)*[[e,1-e],[e,1-e]] (:597-614) reproduces the true class; a = ts / batch_size (:775 -- the
+    reference divides the integer timestep by the batch size), e = `discrete` (:590; the ctor's `epps` is unused)."""
+
+    def __init__(self, mean_type, noise_schedule, noise_scale, noise_min, noise_max, steps, history_num_per_term=10,
+                 beta_fixed=True, discrete=0.99, CatOneHot=False, user_guided=False):
+        super().__init__(mean_type, noise_schedule, noise_scale, noise_min, noise_max, steps, history_num_per_term,
+                         beta_fixed)
+        self.discrete, self.CatOneHot, self.user_guided = discrete, CatOneHot, user_guided
+        self.u_x = torch.tensor([[discrete, 1 - discrete], [discrete, 1 - discrete]]).unsqueeze(0)
+        self.u_x_eye = torch.eye(2).unsqueeze(0)
+
+    def get_Qt_bar(self, alpha_bar_t):  # reference :597-614
+        a = alpha_bar_t.unsqueeze(1).unsqueeze(1)
+        return a * self.u_x_eye + (1 - a) * self.u_x
+
+    def apply_noise(self, ts, x_start, sampled=None):  # reference :770-831, :999-1038
+        """x_start: one-hot [B, I, 2] float.  Returns one-hot int64 [B, I, 2] of the sampled classes; `sampled` [B, I]
+        (class indices) replaces the multinomial draw."""
+        B = x_start.size(0)
+        probX = x_start @ self.get_Qt_bar(ts.float() / B)
+        if sampled is None:
+            sampled = probX.reshape(B * probX.shape[1], -1).multinomial(1).reshape(B, -1)
+        return torch.nn.functional.one_hot(sampled.long(), num_classes=2), probX
+
+    def training_losses(self, model, x_start, reweight=False, ts=None, pt=None, noise=None, drop_mask=None,
+                        capture=None, ts_U=None, sampled=None, drop_mask_U=None):  # reference :834-957
+        if not self.CatOneHot:
+            return super().training_losses(model, x_start, reweight, ts, pt, noise, drop_mask, capture)
+        B = x_start.size(0)
+        onehot = torch.nn.functional.one_hot(x_start.long(), num_classes=2)
+        if ts_U is None:
+            ts_U, _ = self.sample_timesteps(B, "importance")  # first draw: noises the one-hot rows only (:843)
+        x_tU, _ = self.apply_noise(ts_U, onehot.float(), sampled)
+        x_tU = (x_tU & onehot).float()
+        if ts is None:
+            ts, pt = self.sample_timesteps(B, "importance")  # second, independent draw: the one the model sees (:865)
+        if noise is None:
+            noise = torch.randn_like(x_start)
+        x_t = self.q_sample(x_start, ts, noise) if self.noise_scale != 0.0 else x_start
+        out = model(x_t, ts, x_tU, drop_mask, drop_mask_U) if drop_mask is not None else model(x_t, ts, x_tU)
+        target = {ModelMeanType.START_X: x_start, ModelMeanType.EPSILON: noise}[self.mean_type]
+        assert out.shape == target.shape == x_start.shape
+        mse = mean_flat((target - out) ** 2)
+        if reweight:
+            if self.mean_type == ModelMeanType.START_X:
+                weight = torch.where(ts == 0, 1.0, self.SNR(ts - 1) - self.SNR(ts))
+                loss = mse
+            else:
+                weight = (1 - self.alphas_cumprod[ts]) / ((1 - self.alphas_cumprod_prev[ts]) ** 2 * (1 - self.betas[ts]))
+                weight = torch.where(ts == 0, 1.0, weight)
+                likelihood = mean_flat((x_start - self._predict_xstart_from_eps(x_t, ts, out)) ** 2 / 2.0)
+                loss = torch.where(ts == 0, likelihood, mse)
+        else:
+            weight = torch.tensor([1.0] * B)
+            loss = mse
+        terms = {"loss": weight * loss}
+        self.update_history(ts, terms["loss"])
+        terms["loss"] = terms["loss"] / pt
+        if capture is not None:
+            capture.update(ts=ts, pt=pt, noise=noise, x_t=x_t, x_tU=x_tU, model_output=out, mse=mse, weight=weight)
+        return terms
+
+    def p_sample(self, model, x_start, steps, sampling_noise=False, noise0=None, step_noise=None, capture=None,
+                 sampled0=None):  # reference :668-768
+        if not self.CatOneHot:
+            return super().p_sample(model, x_start, steps, sampling_noise, noise0, step_noise, capture)
+        assert steps <= self.steps, "Too much steps in inference."
+        B = x_start.shape[0]
+        onehot = torch.nn.functional.one_hot(x_start.long(), num_classes=2)
+        injected = sampled0 is not None or noise0 is not None
+        if steps == 0:
+            x_tU, x_t = onehot.float(), x_start
+        else:
+            t = torch.tensor([steps - 1] * B)
+            x_tU, _ = self.apply_noise(t, onehot.float(), sampled0)
+            x_tU = x_tU & onehot
+            x_t = self.q_sample(x_start, t, noise0)
+        indices = list(range(self.steps))[::-1]
+        if self.noise_scale == 0.0:
+            for i in indices:
+                x_t = model(x_t, torch.tensor([i] * B), x_tU)
+            return x_t
+        zero = torch.nn.functional.one_hot(torch.zeros_like(x_start.long()), num_classes=2)
+        for n, i in enumerate(indices):
+            t = torch.tensor([i] * B)
+            if not injected:
+                # per-step degree-guided graph (:706-729): consumed only by the GCN backbones (`graph=`), but its two
+                # multinomial draws advance the generator, so they are replayed when the randomness is not injected
+                g_i, _ = self.apply_noise(t, zero.float())
+                deg = x_start.sum(dim=1)
+                deg = (deg / deg.max()).unsqueeze(1)
+                pick = torch.cat([1 - deg, deg], dim=1).multinomial(1).repeat_interleave(x_start.shape[1], dim=1)
+                if self.user_guided:
+                    g_i = g_i & torch.nn.functional.one_hot(pick, num_classes=2)
+                zero = torch.nn.functional.one_hot(g_i.argmax(dim=2) | zero.argmax(dim=2), num_classes=2)
+            out = self._p_mean_variance_onehot(model, x_t, t, x_tU)
+            if capture is not None:
+                capture.setdefault("pred_xstart", []).append(out["pred_xstart"])
+                capture.setdefault("mean", []).append(out["mean"])
+            if sampling_noise:
+                z = step_noise[n] if step_noise is not None else torch.randn_like(x_t)
+                nz = (t != 0).float().view(-1, *([1] * (x_t.dim() - 1)))
+                x_t = out["mean"] + nz * torch.exp(0.5 * out["log_variance"]) * z
+            else:
+                x_t = out["mean"]
+        return x_t
+
+    def _p_mean_variance_onehot(self, model, x, t, x_tU):  # reference :1063-1103, CatOneHot and not indexIn
+        assert t.shape == (x.shape[0],)
+        out = model(x, t, x_tU)
+        if self.mean_type == ModelMeanType.START_X:
+            pred = out
+        elif self.mean_type == ModelMeanType.EPSILON:
+            pred = self._predict_xstart_from_eps(x, t, out)
+        else:
+            raise NotImplementedError(self.mean_type)
+        mean, var, logvar = self.q_posterior_mean_variance(pred, x, t)
+        return {"mean": mean, "variance": var, "log_variance": logvar, "pred_xstart": pred}
 
 
 # ----------------------------------------------------------------------------------------

@@ -45,6 +45,9 @@ import models.gaussian_diffusion as gd  # noqa: E402  (the real reference)
 
 _ns = dict(torch=torch, nn=nn, F=F, np=np, math=math)
 RefDNN, ref_timestep_embedding = _extract(f"{REF}/models/DNN.py", ["DNN", "timestep_embedding"], _ns)
+import copy  # noqa: E402
+_ns["copy"] = copy
+(RefDNNOneHot,) = _extract(f"{REF}/models/DNN.py", ["DNNOneHot"], _ns)
 (ref_topn,) = _extract(f"{REF}/evaluate_utils.py", ["computeTopNAccuracy"], dict(math=math, np=np, torch=torch))
 
 
@@ -256,6 +259,147 @@ def gen_sample(name, B, I, dims, T, mean_type, seed=0, density=0.08, scale=0.01,
 
 
 # ----------------------------------------------------------------------------------------
+# one-hot variant (first slice): GaussianDiffusionDiscrete(CatOneHot=True), indexIn False, DNNOneHot
+class _Args:  # the reference reads only args.user_guided (:720)
+    user_guided = False
+
+
+class _Index:  # the reference calls index.cuda() (:744) and, with indexIn False, never uses the result
+    def cuda(self):
+        return self
+
+
+def _onehot_pair(I, dims, T, mean_type, schedule, scale, nmin, nmax, norm, emb=10):
+    import contextlib
+    import io
+    out_dims = dims[::-1] + [I]
+    in_dims = [I] + dims
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = RefDNNOneHot(in_dims, out_dims, emb, time_type="cat", norm=norm)
+        mt = {"x0": gd.ModelMeanType.START_X, "eps": gd.ModelMeanType.EPSILON}[mean_type]
+        diff = gd.GaussianDiffusionDiscrete(mt, schedule, scale, nmin, nmax, T, "cpu", discrete=0.99, CatOneHot=True,
+                                            args=_Args())
+    return model, diff
+
+
+def gen_train_onehot(name, B, I, dims, T, mean_type, schedule="linear-var", scale=0.01, nmin=0.001, nmax=0.01, n_steps=2,
+                     lr=1e-3, wd=0.0, seed=0, density=0.1, norm=False):
+    torch.manual_seed(seed)
+    g = torch.Generator().manual_seed(seed + 100)
+    model, diff = _onehot_pair(I, dims, T, mean_type, schedule, scale, nmin, nmax, norm)
+    opt = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=wd)
+    out = dict(sd_np(model))
+    out["meta"] = np.array([f"{B}|{I}|{','.join(map(str, dims))}|{T}|{mean_type}|{schedule}|{scale}|{nmin}|{nmax}|"
+                            f"{n_steps}|{lr}|{wd}|10|{int(norm)}|0.99"])
+    cap = {"st": [], "drops": []}
+    orig_st, orig_q, orig_sd = diff.sample_timesteps, diff.q_sample, diff.sample_discrete_features
+
+    def st(*a, **k):
+        cap["depth"] = cap.get("depth", 0) + 1  # 'importance' falls back to a nested 'uniform' call until the history is full
+        t, pt = orig_st(*a, **k)
+        cap["depth"] -= 1
+        if cap["depth"] == 0:
+            cap["st"].append((t.clone(), pt.clone()))
+        return t, pt
+
+    def q(x, t, noise=None):
+        cap["noise"] = noise.clone()
+        r = orig_q(x, t, noise)
+        cap["x_t"] = r.clone()
+        return r
+
+    def sd(probX):
+        cap["probX"] = probX.clone()
+        r = orig_sd(probX)
+        cap["sampled"] = r.clone()
+        return r
+
+    diff.sample_timesteps, diff.q_sample, diff.sample_discrete_features = st, q, sd
+    model.drop.register_forward_hook(lambda m, i, o: cap["drops"].append((i[0].clone(), o.clone())))
+    model.register_forward_hook(lambda m, i, o: cap.update(model_output=o.clone(), x_tU=i[2].clone()))
+    model.train()
+    for s in range(n_steps):
+        x = make_rows(B, I, density, g)
+        cap["st"].clear()
+        cap["drops"].clear()
+        opt.zero_grad()
+        terms = diff.training_losses(model, x, True)
+        loss = terms["loss"].mean()
+        loss.backward()
+        assert len(cap["st"]) == 2 and len(cap["drops"]) == 2
+        (din, dout), (din_u, dout_u) = cap["drops"]
+        mask, mask_u = (dout != 0), (dout_u != 0)
+        assert torch.equal(dout, din * mask.float() * 2.0) and torch.equal(dout_u, din_u * mask_u.float() * 2.0)
+        p = f"s{s}."
+        out[p + "x_start"] = npy(x).astype(np.uint8)
+        out[p + "ts_U"] = npy(cap["st"][0][0])
+        out[p + "ts"], out[p + "pt"] = npy(cap["st"][1][0]), npy(cap["st"][1][1])
+        out[p + "sampled"] = npy(cap["sampled"]).astype(np.uint8)
+        out[p + "prob1"] = npy(cap["probX"][..., 1])
+        out[p + "x_tU"] = npy(cap["x_tU"]).astype(np.uint8)
+        out[p + "noise"] = npy(cap["noise"])
+        out[p + "drop_mask"] = npy(mask).astype(np.uint8)
+        out[p + "drop_mask_U"] = npy(mask_u).astype(np.uint8)  # [B, 2I]; 0 where the input bit was 0 (irrelevant there)
+        out[p + "x_t"] = npy(cap["x_t"])
+        out[p + "model_output"] = npy(cap["model_output"])
+        out[p + "loss_vec"] = npy(terms["loss"])
+        out[p + "loss"] = npy(loss)
+        if s == 0:
+            for k, v in model.named_parameters():
+                out["g0." + k] = npy(v.grad)
+        opt.step()
+        out[p + "Lt_history"], out[p + "Lt_count"] = npy(diff.Lt_history), npy(diff.Lt_count)
+    for k, v in model.named_parameters():
+        out["pN." + k] = npy(v)
+        out["m." + k], out["v." + k] = npy(opt.state[v]["exp_avg"]), npy(opt.state[v]["exp_avg_sq"])
+    np.savez_compressed(os.path.join(OUT, f"onehot_train_{name}.npz"), **out)
+    print(f"onehot_train_{name}: loss0={float(out['s0.loss']):.6g} kept bits {int(out['s0.x_tU'].sum())}")
+
+
+def gen_sample_onehot(name, B, I, dims, T, mean_type, seed=0, density=0.08, scale=0.01, nmin=0.001, nmax=0.01):
+    torch.manual_seed(seed)
+    g = torch.Generator().manual_seed(seed + 7)
+    model, diff = _onehot_pair(I, dims, T, mean_type, "linear-var", scale, nmin, nmax, False)
+    with torch.no_grad():
+        model.out_layers[-1].bias.normal_(0.0, 0.5, generator=g)
+    model.eval()
+    x = make_rows(B, I, density, g)
+    out = dict(sd_np(model))
+    out["meta"] = np.array([f"{B}|{I}|{','.join(map(str, dims))}|{T}|{mean_type}|{scale}|{nmin}|{nmax}|0.99"])
+    out["x_start"] = npy(x).astype(np.uint8)
+    cap = {"noises": [], "sampled": []}
+    orig_randn, orig_sd = gd.th.randn_like, diff.sample_discrete_features
+
+    def rl(t):
+        n = orig_randn(t)
+        cap["noises"].append(n.clone())
+        return n
+
+    def sd(probX):
+        r = orig_sd(probX)
+        cap["sampled"].append(r.clone())
+        return r
+
+    gd.th.randn_like, diff.sample_discrete_features = rl, sd
+    with torch.no_grad():
+        out["pred_steps0"] = npy(diff.p_sample(model, x, 0, False, index=_Index()))
+        cap["noises"].clear()
+        cap["sampled"].clear()
+        out["pred_stepsT"] = npy(diff.p_sample(model, x, T, False, index=_Index()))
+        out["noise_stepsT"], out["sampled_stepsT"] = npy(cap["noises"][0]), npy(cap["sampled"][0]).astype(np.uint8)
+        assert len(cap["noises"]) == 1 and len(cap["sampled"]) == 1 + T  # + one graph draw per reverse step
+        cap["noises"].clear()
+        cap["sampled"].clear()
+        out["pred_noisy"] = npy(diff.p_sample(model, x, 2, True, index=_Index()))
+        assert len(cap["noises"]) == 1 + T
+        out["noise_noisy0"], out["sampled_noisy0"] = npy(cap["noises"][0]), npy(cap["sampled"][0]).astype(np.uint8)
+        out["noise_noisy_steps"] = np.stack([npy(n) for n in cap["noises"][1:]])
+    gd.th.randn_like = orig_randn
+    np.savez_compressed(os.path.join(OUT, f"onehot_sample_{name}.npz"), **out)
+    print(f"onehot_sample_{name}: |pred0| {np.abs(out['pred_steps0']).mean():.3g}")
+
+
+# ----------------------------------------------------------------------------------------
 def gen_lightgcn(name, U, It, d, L, nnz, seed=0):
     rng = np.random.default_rng(seed)
     users = rng.integers(0, U, nnz)
@@ -317,8 +461,19 @@ def gen_data_load():
     print("data_load:", nu, ni, t.max())
 
 
+def gen_onehot():
+    gen_train_onehot("tiny_x0", 8, 64, [16], 5, "x0", seed=31)
+    gen_train_onehot("ragged_eps_wd", 12, 131, [24], 5, "eps", seed=32, density=0.05, wd=0.01, schedule="linear", scale=0.1)
+    gen_train_onehot("deep_x0", 10, 90, [32, 16], 5, "x0", seed=33, density=0.06)
+    gen_sample_onehot("tiny_x0", 8, 64, [16], 5, "x0", seed=41)
+    gen_sample_onehot("ragged_eps", 10, 131, [24], 5, "eps", seed=42, scale=50.0)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if sys.argv[1:] == ["onehot"]:  # only the fixtures of the one-hot variant
+        gen_onehot()
+        sys.exit(0)
     gen_data_load()
     gen_schedules()
     gen_metrics()
@@ -339,3 +494,4 @@ if __name__ == "__main__":
     gen_sample("norm_x0", 12, 150, [32], 5, "x0", seed=14, k=10, norm=True)
     gen_lightgcn("small", 50, 40, 8, 3, 300, seed=0)
     gen_lightgcn("mid", 600, 400, 64, 3, 6000, seed=1)
+    gen_onehot()

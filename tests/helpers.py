@@ -10,6 +10,8 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TRAIN_CASES = ["tiny_x0", "tiny_eps", "ragged_x0", "ragged_eps_wd", "imp_T40", "deep_x0", "norm_x0", "cosine_eps",
                "binomial_x0", "deep_eps_norm"]
 SAMPLE_CASES = ["tiny_x0", "ragged_x0", "ragged_eps", "norm_x0"]
+ONEHOT_TRAIN_CASES = ["tiny_x0", "ragged_eps_wd", "deep_x0"]
+ONEHOT_SAMPLE_CASES = ["tiny_x0", "ragged_eps"]
 
 
 def load(name):
@@ -52,6 +54,37 @@ def step_inputs(fx, s):
     return dict(x=torch.from_numpy(fx[p + "x_start"].astype(np.float32)), ts=torch.from_numpy(fx[p + "ts"]),
                 pt=torch.from_numpy(fx[p + "pt"]), noise=torch.from_numpy(fx[p + "noise"]),
                 drop_mask=torch.from_numpy(fx[p + "drop_mask"].astype(np.float32)))
+
+
+def onehot_train_meta(fx):
+    f = str(fx["meta"][0]).split("|")
+    meta = train_meta({"meta": np.array(["|".join(f[:14])])})
+    meta["discrete"] = float(f[14])
+    return meta
+
+
+def onehot_sample_meta(fx):
+    B, I, dims, T, mt, scale, nmin, nmax, disc = str(fx["meta"][0]).split("|")
+    return dict(B=int(B), I=int(I), dims=[int(d) for d in dims.split(",")], T=int(T), mean_type=mt, scale=float(scale),
+                nmin=float(nmin), nmax=float(nmax), discrete=float(disc), norm=False, schedule="linear-var")
+
+
+def oracle_onehot_pair(meta, fx):
+    I, dims = meta["I"], meta["dims"]
+    m = O.DNNOneHot([I] + dims, dims[::-1] + [I], meta.get("emb", 10), norm=meta.get("norm", False))
+    m.load_state_dict(state_dict_from(fx))
+    mt = {"x0": O.ModelMeanType.START_X, "eps": O.ModelMeanType.EPSILON}[meta["mean_type"]]
+    d = O.GaussianDiffusionDiscrete(mt, meta.get("schedule", "linear-var"), meta["scale"], meta["nmin"], meta["nmax"],
+                                    meta["T"], discrete=meta["discrete"], CatOneHot=True)
+    return m, d
+
+
+def onehot_step_inputs(fx, s):
+    p = f"s{s}."
+    d = step_inputs(fx, s)
+    d.update(ts_U=torch.from_numpy(fx[p + "ts_U"]), sampled=torch.from_numpy(fx[p + "sampled"].astype(np.int64)),
+             drop_mask_U=torch.from_numpy(fx[p + "drop_mask_U"].astype(np.float32)))
+    return d
 
 
 def relerr(a, b):

@@ -139,3 +139,76 @@ def test_lightgcn_matches_reference(case):
         np.testing.assert_allclose(layers[l + 1], fx["layers"][l], rtol=0, atol=2e-7)
     np.testing.assert_allclose(fu, fx["final_user"], rtol=0, atol=2e-7)
     np.testing.assert_allclose(fi, fx["final_item"], rtol=0, atol=2e-7)
+
+
+# ---- one-hot / discrete-noise variant (first slice) ---------------------------------------------------
+@pytest.mark.parametrize("case", H.ONEHOT_TRAIN_CASES)
+def test_onehot_train_steps_match_reference(case):
+    """GaussianDiffusionDiscrete(CatOneHot=True) + DNNOneHot: same weights and the same randomness (both timestep
+    draws, the sampled classes, noise, both keep-masks) -> bit-identical transition probabilities, kept bits, model
+    output, loss vector, gradients, AdamW state and history."""
+    fx = H.load("onehot_train_" + case)
+    meta = H.onehot_train_meta(fx)
+    model, diff = H.oracle_onehot_pair(meta, fx)
+    opt = O.make_optimizer(model, meta["lr"], meta["wd"])
+    model.train()
+    for s in range(meta["n_steps"]):
+        inp = H.onehot_step_inputs(fx, s)
+        onehot = torch.nn.functional.one_hot(inp["x"].long(), num_classes=2).float()
+        _, probX = diff.apply_noise(inp["ts_U"], onehot, inp["sampled"])
+        np.testing.assert_array_equal(probX[..., 1].numpy(), fx[f"s{s}.prob1"])
+        cap = {}
+        opt.zero_grad()
+        terms = diff.training_losses(model, inp["x"], True, ts=inp["ts"], pt=inp["pt"], noise=inp["noise"],
+                                     drop_mask=inp["drop_mask"], capture=cap, ts_U=inp["ts_U"], sampled=inp["sampled"],
+                                     drop_mask_U=inp["drop_mask_U"])
+        loss = terms["loss"].mean()
+        loss.backward()
+        np.testing.assert_array_equal(cap["x_tU"].numpy().astype(np.uint8), fx[f"s{s}.x_tU"])
+        np.testing.assert_array_equal(cap["x_t"].numpy(), fx[f"s{s}.x_t"])
+        np.testing.assert_array_equal(cap["model_output"].detach().numpy(), fx[f"s{s}.model_output"])
+        np.testing.assert_array_equal(terms["loss"].detach().numpy(), fx[f"s{s}.loss_vec"])
+        np.testing.assert_array_equal(loss.detach().numpy(), fx[f"s{s}.loss"])
+        if s == 0:
+            for k, v in model.named_parameters():
+                np.testing.assert_array_equal(v.grad.numpy(), fx["g0." + k], err_msg=k)
+        opt.step()
+        np.testing.assert_array_equal(diff.Lt_history.numpy(), fx[f"s{s}.Lt_history"])
+        np.testing.assert_array_equal(diff.Lt_count.numpy(), fx[f"s{s}.Lt_count"])
+    for k, v in model.named_parameters():
+        np.testing.assert_array_equal(v.detach().numpy(), fx["pN." + k], err_msg=k)
+        np.testing.assert_array_equal(opt.state[v]["exp_avg"].numpy(), fx["m." + k])
+        np.testing.assert_array_equal(opt.state[v]["exp_avg_sq"].numpy(), fx["v." + k])
+
+
+@pytest.mark.parametrize("case", H.ONEHOT_SAMPLE_CASES)
+def test_onehot_p_sample_matches_reference(case):
+    fx = H.load("onehot_sample_" + case)
+    meta = H.onehot_sample_meta(fx)
+    model, diff = H.oracle_onehot_pair(meta, fx)
+    model.eval()
+    x = torch.from_numpy(fx["x_start"].astype(np.float32))
+    T = meta["T"]
+    with torch.no_grad():
+        np.testing.assert_array_equal(diff.p_sample(model, x, 0, False, sampled0=torch.zeros(1)).numpy(), fx["pred_steps0"])
+        got = diff.p_sample(model, x, T, False, noise0=torch.from_numpy(fx["noise_stepsT"]),
+                            sampled0=torch.from_numpy(fx["sampled_stepsT"].astype(np.int64)))
+        np.testing.assert_array_equal(got.numpy(), fx["pred_stepsT"])
+        got = diff.p_sample(model, x, 2, True, noise0=torch.from_numpy(fx["noise_noisy0"]),
+                            sampled0=torch.from_numpy(fx["sampled_noisy0"].astype(np.int64)),
+                            step_noise=[torch.from_numpy(n) for n in fx["noise_noisy_steps"]])
+        np.testing.assert_array_equal(got.numpy(), fx["pred_noisy"])
+
+
+def test_onehot_rng_call_order_matches_reference():
+    """Without injected randomness the oracle draws from torch's generator in the reference's order (timesteps, class
+    draw, timesteps, randn_like, dropout x, dropout x_U): seeding like the generator did reproduces its first step."""
+    fx = H.load("onehot_train_tiny_x0")
+    meta = H.onehot_train_meta(fx)
+    model, diff = H.oracle_onehot_pair(meta, fx)
+    model.train()
+    torch.manual_seed(31)
+    O.DNNOneHot([meta["I"]] + meta["dims"], meta["dims"][::-1] + [meta["I"]], 10)  # consumes the init draws like the generator
+    x = torch.from_numpy(fx["s0.x_start"].astype(np.float32))
+    terms = diff.training_losses(model, x, True)
+    np.testing.assert_array_equal(terms["loss"].detach().numpy(), fx["s0.loss_vec"])
