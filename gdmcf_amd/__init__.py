@@ -6,7 +6,8 @@ from .gaussian_diffusion import GaussianDiffusion, GaussianDiffusionDiscrete, Mo
 from .optim import FusedAdamW  # noqa: F401
 from .evaluate_utils import computeTopNAccuracy, computeTopNAccuracy_device, masked_topk, print_results  # noqa: F401
 from .lightgcn import LightGCN  # noqa: F401
+from .onehot import DNNOneHot  # noqa: F401
 from . import checkpoint, data_utils, driver, parallel  # noqa: F401
 
 __all__ = ["DNN", "timestep_embedding", "GaussianDiffusion", "GaussianDiffusionDiscrete", "ModelMeanType", "FusedAdamW", "computeTopNAccuracy",
-           "computeTopNAccuracy_device", "masked_topk", "print_results", "LightGCN"]
+           "computeTopNAccuracy_device", "masked_topk", "print_results", "LightGCN", "DNNOneHot"]

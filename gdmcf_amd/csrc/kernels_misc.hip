@@ -204,6 +204,48 @@ __global__ __launch_bounds__(256) void prep_input_kernel(const PrepArgs a) {
     }
 }
 
+// One-hot rows with discrete transition noise (reference gaussian_diffusion.py:770-831 with :597-614, :999-1038, and the
+// `x_tU & one_hot(x_start)` of :849 / :686): item i of row b has class c0 = x0[b,i]; a class s is drawn from row c0 of
+// Q = a*I + (1-a)*[[e,1-e],[e,1-e]], a = (float)ts[b] / B (the reference's own scaling, :775); the pair written is
+// (c0==0 && s==0, c0==1 && s==1), i.e. the true class's bit survives only where the draw reproduces it.
+// Four items per thread: one Philox block (stream 3) gives their four uniforms.
+__global__ __launch_bounds__(256) void onehot_noise_kernel(const float* __restrict__ x0, int64_t ldx,
+                                                          const int64_t* __restrict__ ts, int B, int I, float p1_off,
+                                                          const uint8_t* __restrict__ sampled, int64_t lds, uint64_t seed,
+                                                          uint64_t offset, float* __restrict__ xU, int64_t ldu,
+                                                          uint8_t* __restrict__ sampled_out, int64_t ldso) {
+    const int b = blockIdx.y;
+    const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i0 >= I) return;
+    uint32_t u[4] = {0u, 0u, 0u, 0u};
+    float a = 1.f;
+    if (!sampled) {
+        const uint4 r = philox4x32_10(make_uint4((uint32_t)(i0 >> 2), (uint32_t)b, 3u, (uint32_t)offset),
+                                      make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+        u[0] = r.x; u[1] = r.y; u[2] = r.z; u[3] = r.w;
+        a = __fdiv_rn((float)ts[b], (float)B);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = i0 + j;
+        if (i >= I) break;
+        const int c0 = x0[(int64_t)b * ldx + i] != 0.f;
+        int s;
+        if (sampled) {
+            s = sampled[(int64_t)b * lds + i] != 0;
+        } else {
+            // P(class 1) = a*[c0 == 1] + (1 - a)*(1 - e), each product and the sum rounded to f32 as torch does
+            const float p1 = __fadd_rn(c0 ? a : 0.f, __fmul_rn(__fsub_rn(1.f, a), p1_off));
+            s = ((float)(u[j] >> 8) * 5.9604644775390625e-8f) < p1;
+        }
+        if (sampled_out) sampled_out[(int64_t)b * ldso + i] = (uint8_t)s;
+        const float keep = (s == c0) ? 1.f : 0.f;
+        float* o = xU + (int64_t)b * ldu + 2 * (int64_t)i;
+        o[0] = c0 ? 0.f : keep;
+        o[1] = c0 ? keep : 0.f;
+    }
+}
+
 __global__ void emb_cols_kernel(const int64_t* __restrict__ ts, const float* __restrict__ emb_w,
                                 const float* __restrict__ emb_b, int E, int I, float* __restrict__ xin, int64_t ldxin,
                                 float* __restrict__ temb_out, unsigned short* __restrict__ xin16, int64_t ldxin16) {
@@ -673,6 +715,19 @@ int gdmcf_dnn_emb_cols_f32(const int64_t* ts, const float* emb_w, const float* e
     hipLaunchKernelGGL(emb_cols_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, ts, emb_w, emb_b, E, I, xin, ldxin,
                        temb_out, has16 ? (unsigned short*)sh.p16 : nullptr, has16 ? sh.ld16 : 0);
     return gd_launch_status("emb_cols");
+}
+
+int gdmcf_onehot_noise_f32(const float* x0, int64_t ldx, const int64_t* ts, int B, int I, float discrete,
+                           const uint8_t* sampled, int64_t lds, uint64_t seed, uint64_t offset, float* xU, int64_t ldu,
+                           uint8_t* sampled_out, int64_t ldso, void* stream) {
+    GD_CHECK_SHAPE(B > 0 && I > 0 && ldx >= I && ldu >= 2 * (int64_t)I, "onehot_noise: bad shape");
+    GD_CHECK_ARG(x0 && xU && (sampled ? lds >= I : ts != nullptr) && (!sampled_out || ldso >= I),
+                 "onehot_noise: null pointer / bad leading dimension");
+    // u_x = th.tensor([[e, 1 - e], ...]): 1 - e is formed in double and rounded to float32 once
+    const float p1_off = (float)(1.0 - (double)discrete);
+    hipLaunchKernelGGL(onehot_noise_kernel, dim3(gd_cdiv(I, 1024), B), dim3(256), 0, (hipStream_t)stream, x0, ldx, ts, B, I,
+                       p1_off, sampled, lds, seed, offset, xU, ldu, sampled_out, ldso);
+    return gd_launch_status("onehot_noise");
 }
 
 int gdmcf_rowscale_f32(const float* A, int64_t lda, const float* rowscale, int M, int K, float* out, int64_t ldo,

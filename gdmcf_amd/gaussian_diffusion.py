@@ -48,8 +48,9 @@ class GaussianDiffusion(nn.Module):
     def __init__(self, mean_type, noise_schedule, noise_scale, noise_min, noise_max, steps, device,
                  history_num_per_term=10, beta_fixed=True, discrete=0.99, CatOneHot=False, epps=None, args=None):
         super().__init__()
-        if CatOneHot:
-            raise NotImplementedError("CatOneHot (discrete one-hot branch) is outside the hot path (SURVEY 8f)")
+        if CatOneHot and not getattr(self, "_onehot_ok", False):
+            raise NotImplementedError("CatOneHot is built for GaussianDiffusionDiscrete only (SURVEY 8 f1); the base "
+                                      "class's own one-hot branch (:294-302) is not")
         self.mean_type = mean_type
         self.noise_schedule = noise_schedule
         self.noise_scale = noise_scale
@@ -274,11 +275,17 @@ class GaussianDiffusion(nn.Module):
 class GaussianDiffusionDiscrete(GaussianDiffusion):
     """The class the shipped main.py actually constructs (main.py:192-193; reference :552-1135).
 
-    With `CatOneHot=False` its `training_losses` is bit-identical to `GaussianDiffusion.training_losses`
-    (SURVEY F6), which is what runs here.  Its `p_sample` additionally samples a degree-guided one-hot graph per
-    step (:706-744) that only GCN backbones consume (`graph=` argument of DNNOneHotEmbeddingGCN, SURVEY 8f1);
-    the plain DNN denoiser never sees it, so with a `gdmcf_amd.DNN` model the result equals the continuous
-    reverse loop implemented by the parent class.  The one-hot / GCN variant itself is a "next" row (f1)."""
+    `CatOneHot=False`: its `training_losses` is bit-identical to `GaussianDiffusion.training_losses`, which
+    is what runs here; its `p_sample` additionally samples a degree-guided one-hot graph per step (:706-744) that only
+    GCN backbones consume (`graph=` of DNNOneHotEmbeddingGCN), so with a `gdmcf_amd.DNN` model the result equals the
+    continuous reverse loop of the parent class.
+
+    `CatOneHot=True` with a `gdmcf_amd.DNNOneHot` denoiser (`indexIn` False; SURVEY 8 f1, first slice): the rows are
+    handed to the model a second time as one-hot pairs under the discrete transition noise of :770-831
+    (`gdmcf_onehot_noise_f32`).  As in the reference, that noise uses its OWN timestep draw (:843) -- the model is
+    conditioned on the second one (:865).  The embedding/GCN backbones (`indexIn` True) are not built."""
+
+    _onehot_ok = True
 
     def __init__(self, mean_type, noise_schedule, noise_scale, noise_min, noise_max, steps, device,
                  history_num_per_term=10, beta_fixed=True, discrete=0.99, CatOneHot=False, epps=0.9995, args=None):
@@ -288,6 +295,96 @@ class GaussianDiffusionDiscrete(GaussianDiffusion):
         self.args = args
         self.discrete_noise = True
         self.indexIn = False
+
+    def _onehot_model(self, model):
+        from .onehot import DNNOneHot
+        if not isinstance(model, DNNOneHot):
+            raise TypeError("gdmcf_amd.GaussianDiffusionDiscrete(CatOneHot=True) needs a gdmcf_amd.DNNOneHot denoiser")
+        if self.indexIn:
+            raise NotImplementedError("indexIn (user/item embedding and GCN backbones) is not built (SURVEY 8 f1)")
+        return model
+
+    def training_losses(self, model, x_start, reweight=False, index=None, *, ts=None, pt=None, noise=None,
+                        drop_mask=None, ts_U=None, sampled=None, drop_mask_U=None):
+        if not self.CatOneHot:
+            return super().training_losses(model, x_start, reweight, index, ts=ts, pt=pt, noise=noise, drop_mask=drop_mask)
+        from .onehot import _OneHotTrainLoss
+        _lib.require_gpu(x_start, "x_start")
+        model = self._onehot_model(model)
+        batch_size, device = x_start.size(0), x_start.device
+        assert x_start.dim() == 2 and x_start.size(1) == model.in_dims[0], "x_start must be [B, n_items]"
+        if sampled is None and ts_U is None:
+            ts_U, _ = self.sample_timesteps(batch_size, device, "importance")  # first draw: the one-hot rows' noise level
+        if ts is None:
+            ts, pt = self.sample_timesteps(batch_size, device, "importance")  # second draw: what the model sees
+        ts = ts.to(device=device, dtype=torch.int64).contiguous()
+        pt = pt.to(device=device, dtype=torch.float64).contiguous()
+        eps_mode = self.mean_type == ModelMeanType.EPSILON
+        if self.mean_type not in (ModelMeanType.START_X, ModelMeanType.EPSILON):
+            raise NotImplementedError(self.mean_type)
+        ca = cb = None
+        if self.noise_scale != 0.0:
+            ca, cb = self._t32["sqrt_ab"], self._t32["sqrt_1mab"]
+            if noise is None and (eps_mode or self.rng == "torch"):
+                noise = torch.randn_like(x_start, dtype=torch.float32)
+        elif eps_mode:
+            raise NotImplementedError("noise_scale == 0 with mean_type EPSILON")
+        if reweight == True:  # noqa: E712
+            if self.noise_scale == 0.0:
+                raise AttributeError("GaussianDiffusionDiscrete has no schedule tables (noise_scale == 0)")
+            weight_t = self._weights["eps" if eps_mode else "x0"]
+        else:
+            weight_t = self._weights["one"]
+        spec = dict(x_start=x_start, ts=ts, pt=pt, ca=ca, cb=cb, noise=noise, drop_mask=drop_mask, eps_mode=eps_mode,
+                    weight_t=weight_t, T=self.steps, H=self.history_num_per_term, Lt_history=self.Lt_history,
+                    Lt_count=self.Lt_count, update_history=self.update_history, t0_likelihood=(reweight == True),  # noqa: E712
+                    ts_U=ts_U, sampled=sampled, drop_mask_U=drop_mask_U, discrete=self.discrete)
+        if eps_mode:
+            spec["r1_0"] = self._t32["r1"][0]
+            spec["r2_0"] = self._t32["r2"][0]
+        eng = model.engine
+        loss = _OneHotTrainLoss.apply(eng, spec, *model.param_list())
+        self.last_ts, self.last_loss_unscaled = ts, eng.buffers(batch_size, device).lu
+        return {"loss": loss}
+
+    def p_sample(self, model, x_start, steps, sampling_noise=False, index=None, *, noise0=None, step_noise=None,
+                 capture=None, sampled0=None):
+        if not self.CatOneHot:
+            return super().p_sample(model, x_start, steps, sampling_noise, index, noise0=noise0, step_noise=step_noise,
+                                    capture=capture)
+        assert steps <= self.steps, "Too much steps in inference."
+        _lib.require_gpu(x_start, "x_start")
+        model = self._onehot_model(model)
+        B, dev = x_start.shape[0], x_start.device
+        with torch.no_grad():
+            x0 = x_start.float().contiguous()
+            if steps == 0:
+                # the noiseless one-hot image: every true bit survives (sampled == the rows themselves)
+                x_tU, keep = model.engine.onehot_rows(x0, None, (x0 != 0).to(torch.uint8), self.discrete)
+                x_t = x0
+            else:
+                t = torch.full((B,), steps - 1, dtype=torch.int64, device=dev)
+                x_tU, keep = model.engine.onehot_rows(x0, t, sampled0, self.discrete)
+                x_t = self.q_sample(x0, t, noise0) if self.noise_scale != 0.0 else x0
+            for n, i in enumerate(list(range(self.steps))[::-1]):
+                t = torch.full((B,), i, dtype=torch.int64, device=dev)
+                if self.noise_scale == 0.0:
+                    x_t = model(x_t, t, x_tU)
+                    continue
+                out = model(x_t, t, x_tU)
+                pred = out if self.mean_type == ModelMeanType.START_X else self._predict_xstart_from_eps(x_t, t, eps=out)
+                mean, _, logvar = self.q_posterior_mean_variance(x_start=pred, x_t=x_t, t=t)
+                if capture is not None:
+                    capture.setdefault("pred_xstart", []).append(pred)
+                    capture.setdefault("mean", []).append(mean)
+                if sampling_noise:
+                    z = step_noise[n] if step_noise is not None else torch.randn_like(x_t)
+                    nz = (t != 0).float().view(-1, 1)
+                    x_t = mean + nz * torch.exp(0.5 * logvar) * z
+                else:
+                    x_t = mean
+            del keep
+            return x_t
 
 
 # ---- module-level helpers of the reference file (kept for API parity) -------------------------------

@@ -1,0 +1,410 @@
+"""One-hot backbone `DNNOneHot` (reference models/DNN.py:360-477) on the HIP path -- first slice of SURVEY 8 f1.
+
+The denoiser has two input branches: [x_t, emb] through `in_layers` and the flattened one-hot rows [x_U (two columns per
+item), emb] through `in_layers2`; their hidden activations are concatenated in front of `out_layers`.  It is driven by
+`GaussianDiffusionDiscrete(CatOneHot=True)` (gaussian_diffusion.py), whose discrete transition noise on the one-hot rows
+is `gdmcf_onehot_noise_f32`.  Everything else is the same C-ABI kernels as the plain DNN: the input builder (once per
+branch), the dense layers, the fused loss epilogue, the weight / input gradient GEMMs and the embedding-branch backward
+(once per branch, the two `emb_layer` gradients are added).  The concatenation costs nothing: the last layer of each
+branch writes straight into its column range of one [B, h1 + h2] buffer, and the gradient of that buffer is read back
+by column range.
+
+fp32 only (no bf16 shadows), single process (no gradient sink); constructor, parameter names and initialisation draw
+order are the reference's, so checkpoints interchange.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+def _ceil64(n):
+    return (int(n) + 63) // 64 * 64
+
+
+class _Bufs:
+    pass
+
+
+class _OneHotTrainLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, eng, spec, *params):
+        loss = eng.train_forward(spec)
+        ctx.eng, ctx.version = eng, eng.version
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        eng = ctx.eng
+        if ctx.version != eng.version:
+            raise RuntimeError("gdmcf_amd: activations were overwritten by a later forward; "
+                               "call backward before the next training_losses/forward")
+        return (None, None, *eng.train_backward(gloss))
+
+
+class OneHotEngine:
+    def __init__(self, model):
+        self.model = model
+        self.lib = _lib.load()
+        self.E = int(model.time_emb_dim)
+        self.I = int(model.in_dims[0])
+        self.version = 0
+        self.seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+        self.offset = 0
+        self._bufs = {}
+        self._saved = None
+
+    def manual_seed(self, seed):
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.offset = 0
+
+    # -- layers -------------------------------------------------------------------------------------------------------
+    def _chains(self):
+        m = self.model
+        br1 = [(l.weight, l.bias, 1) for l in m.in_layers]
+        br2 = [(l.weight, l.bias, 1) for l in m.in_layers2]
+        n_out = len(m.out_layers)
+        out = [(l.weight, l.bias, 1 if i != n_out - 1 else 0) for i, l in enumerate(m.out_layers)]
+        for w, b, _ in br1 + br2 + out:
+            _lib.require_gpu(w, "DNNOneHot parameters")
+            if not (w.is_contiguous() and b.is_contiguous() and w.dtype == torch.float32):
+                raise RuntimeError("gdmcf_amd: DNNOneHot parameters must be contiguous float32")
+        return br1, br2, out
+
+    def buffers(self, B, device):
+        key = (B, str(device))
+        b = self._bufs.get(key)
+        if b is not None:
+            return b
+        lib, I, E = self.lib, self.I, self.E
+        br1, br2, out = self._chains()
+        f32 = dict(dtype=torch.float32, device=device)
+        b = _Bufs()
+        b.ld1, b.ld2 = _ceil64(I + E), _ceil64(2 * I + E)
+        b.xin1 = torch.zeros(B, b.ld1, **f32)
+        b.xin2 = torch.zeros(B, b.ld2, **f32)
+        b.xU = torch.zeros(B, 2 * I, **f32)
+        b.temb = torch.zeros(B, max(E, 1), **f32)
+        b.rownorm = torch.zeros(B, **f32)
+        b.h1, b.h2 = br1[-1][0].shape[0], br2[-1][0].shape[0]
+        b.hcat = torch.zeros(B, _ceil64(b.h1 + b.h2), **f32)
+        b.dhcat = torch.zeros_like(b.hcat)
+        mk = lambda chain: [torch.zeros(B, _ceil64(w.shape[0]), **f32) for (w, _, _) in chain[:-1]]
+        b.acts1, b.acts2, b.acts_out = mk(br1), mk(br2), mk(out)
+        b.dz1, b.dz2, b.dz_out = mk(br1), mk(br2), mk(out)
+        b.hs = torch.zeros(B, _ceil64(out[-1][0].shape[1]), **f32)  # row-scaled input of the loss layer (its weight gradient)
+        b.ldi = _ceil64(I)
+        b.diff = torch.zeros(B, b.ldi, **f32)
+        b.xt = None
+        b.rowpart = torch.zeros(B, lib.gdmcf_loss_tiles(out[-1][0].shape[0]), **f32)
+        b.rowsum = torch.zeros(B, **f32)
+        b.gradcoef = torch.zeros(B, **f32)
+        b.rowdiv_mse = torch.full((B,), float(I), **f32)
+        b.lu = torch.zeros(B, dtype=torch.float64, device=device)
+        n_first = max(br1[0][0].shape[0], br2[0][0].shape[0])
+        b.demb = torch.zeros((B + n_first) * max(E, 1), **f32)
+        ws = 0
+        for chain in (br1, br2, out):
+            for (w, _, _) in chain:
+                ws = max(ws, lib.gdmcf_linear_ws_bytes(B, w.shape[0], w.shape[1]))
+        b.ws_bytes = int(ws)
+        b.ws = torch.empty(max(ws, 256), dtype=torch.uint8, device=device)
+        self._bufs[key] = b
+        return b
+
+    # -- input builders ---------------------------------------------------------------------------------------------
+    def _prep(self, bufs, x, I, xin, ts, ca, cb, noise, drop_mask, training, xt_out=None):
+        """gdmcf_dnn_prep_input_f32 on a [B, I] operand (the rows themselves, or their [B, 2I] one-hot image)."""
+        m, lib = self.model, self.lib
+        B = x.shape[0]
+        noise_mode = 0
+        if ca is not None:
+            noise_mode = 1 if noise is not None else 2
+            if noise is not None and (noise.dtype != torch.float32 or noise.stride(-1) != 1):
+                noise = noise.float().contiguous()
+        p = float(m.drop.p)
+        drop_mode, keep = 0, None
+        if drop_mask is not None:
+            drop_mode = 1
+            keep = drop_mask.reshape(B, -1)
+            keep = (keep if keep.dtype == torch.uint8 else (keep != 0).to(torch.uint8)).contiguous()
+        elif training and p > 0.0:
+            drop_mode = 2
+        self.offset += 1
+        _lib.check(lib.gdmcf_dnn_prep_input_f32(
+            x.data_ptr(), x.stride(0), _lib.ptr(ts), _lib.ptr(ca), _lib.ptr(cb), noise_mode, _lib.ptr(noise),
+            noise.stride(0) if noise is not None else 0, drop_mode, _lib.ptr(keep),
+            keep.stride(0) if keep is not None else 0, p, self.seed, self.offset, int(bool(m.norm)),
+            m.emb_layer.weight.data_ptr(), m.emb_layer.bias.data_ptr(), self.E, B, I, xin.data_ptr(), xin.stride(0),
+            _lib.ptr(xt_out), xt_out.stride(0) if xt_out is not None else 0, bufs.temb.data_ptr(),
+            bufs.rownorm.data_ptr(), _lib.stream_ptr()))
+        return noise, keep
+
+    def onehot_rows(self, x0, ts_U, sampled, discrete, out=None):
+        """x_tU of the reference (:841-849 / :672-686) as the [B, 2I] float image the second branch reads."""
+        B = x0.shape[0]
+        if x0.dtype != torch.float32 or x0.stride(-1) != 1:
+            x0 = x0.float().contiguous()
+        if out is None:
+            out = torch.empty(B, 2 * self.I, dtype=torch.float32, device=x0.device)
+        s8 = None
+        if sampled is not None:
+            s8 = (sampled if sampled.dtype == torch.uint8 else (sampled != 0).to(torch.uint8)).contiguous()
+        elif ts_U is not None:
+            ts_U = ts_U.to(device=x0.device, dtype=torch.int64).contiguous()
+        self.offset += 1
+        _lib.check(self.lib.gdmcf_onehot_noise_f32(
+            x0.data_ptr(), x0.stride(0), _lib.ptr(ts_U), B, self.I, float(discrete), _lib.ptr(s8),
+            s8.stride(0) if s8 is not None else 0, self.seed, self.offset, out.data_ptr(), out.stride(0), None, 0,
+            _lib.stream_ptr()))
+        return out, (x0, s8, ts_U)
+
+    def _chain_forward(self, bufs, chain, acts, A, lda, B, last_out, last_ld):
+        """All layers of one branch; the last one writes to (last_out pointer, last_ld)."""
+        lib, st = self.lib, _lib.stream_ptr()
+        for li, (w, bias, act) in enumerate(chain):
+            N, K = w.shape
+            last = li == len(chain) - 1
+            optr, old = (last_out, last_ld) if last else (acts[li].data_ptr(), acts[li].stride(0))
+            _lib.check(lib.gdmcf_linear_fwd_f32(A.data_ptr() if torch.is_tensor(A) else A, lda, w.data_ptr(), w.stride(0),
+                                                bias.data_ptr(), act, B, N, K, optr, old, bufs.ws.data_ptr(),
+                                                bufs.ws_bytes, st))
+            if not last:
+                A, lda = acts[li], acts[li].stride(0)
+
+    def _hidden(self, bufs, br1, br2, out, B):
+        """Both branches into hcat, then all out layers but the last; returns (A, lda) feeding the last layer."""
+        self._chain_forward(bufs, br1, bufs.acts1, bufs.xin1, bufs.ld1, B, bufs.hcat.data_ptr(), bufs.hcat.stride(0))
+        self._chain_forward(bufs, br2, bufs.acts2, bufs.xin2, bufs.ld2, B, bufs.hcat.data_ptr() + 4 * bufs.h1,
+                            bufs.hcat.stride(0))
+        A, lda = bufs.hcat, bufs.hcat.stride(0)
+        if len(out) > 1:
+            lib, st = self.lib, _lib.stream_ptr()
+            for li, (w, bias, act) in enumerate(out[:-1]):
+                N, K = w.shape
+                o = bufs.acts_out[li]
+                _lib.check(lib.gdmcf_linear_fwd_f32(A.data_ptr(), lda, w.data_ptr(), w.stride(0), bias.data_ptr(), act, B,
+                                                    N, K, o.data_ptr(), o.stride(0), bufs.ws.data_ptr(), bufs.ws_bytes, st))
+                A, lda = o, o.stride(0)
+        return A, lda
+
+    # -- fused training forward / backward ----------------------------------------------------------------------------
+    def train_forward(self, spec):
+        prev = self.lib.gdmcf_gemm_precision(0)
+        try:
+            return self._train_forward(spec)
+        finally:
+            self.lib.gdmcf_gemm_precision(prev)
+
+    def _train_forward(self, spec):
+        x0, ts = spec["x_start"], spec["ts"]
+        B, dev = x0.shape[0], x0.device
+        br1, br2, out = self._chains()
+        bufs = self.buffers(B, dev)
+        lib, st = self.lib, _lib.stream_ptr()
+        self.version += 1
+        if x0.dtype != torch.float32 or x0.stride(-1) != 1:
+            x0 = x0.float().contiguous()
+        eps_mode = spec["eps_mode"]
+        xt_out = None
+        if eps_mode:
+            if bufs.xt is None:
+                bufs.xt = torch.zeros(B, bufs.ldi, dtype=torch.float32, device=dev)
+            xt_out = bufs.xt
+        training = self.model.training
+        _, s8 = self.onehot_rows(x0, spec["ts_U"], spec["sampled"], spec["discrete"], out=bufs.xU)
+        noise, keep1 = self._prep(bufs, x0, self.I, bufs.xin1, ts, spec["ca"], spec["cb"], spec["noise"], spec["drop_mask"],
+                                  training, xt_out=xt_out)
+        _, keep2 = self._prep(bufs, bufs.xU, 2 * self.I, bufs.xin2, ts, None, None, None, spec["drop_mask_U"], training)
+        alpha = None
+        if eps_mode:
+            is0 = (ts == 0) if spec.get("t0_likelihood", True) else torch.zeros_like(ts, dtype=torch.bool)
+            target = torch.where(is0[:, None], spec["r1_0"] * bufs.xt[:, : self.I] - x0, noise)
+            alpha = torch.where(is0, spec["r2_0"], torch.ones((), dtype=torch.float32, device=dev)).float().contiguous()
+            rowdiv = torch.where(is0, 2.0 * self.I, 1.0 * self.I).float().contiguous()
+        else:
+            target, rowdiv = x0, bufs.rowdiv_mse
+        A, lda = self._hidden(bufs, br1, br2, out, B)
+        w, bias, _ = out[-1]
+        N, K = w.shape
+        _lib.check(lib.gdmcf_linear_loss_fwd_f32(A.data_ptr(), lda, w.data_ptr(), w.stride(0), bias.data_ptr(),
+                                                 target.data_ptr(), target.stride(0), _lib.ptr(alpha), B, N, K, None, 0,
+                                                 bufs.diff.data_ptr(), bufs.ldi, bufs.rowpart.data_ptr(),
+                                                 bufs.rowsum.data_ptr(), st))
+        loss = torch.empty(B, dtype=torch.float64, device=dev)
+        pt = spec["pt"]
+        _lib.check(lib.gdmcf_row_loss_finish_f64(bufs.rowsum.data_ptr(), rowdiv.data_ptr(), _lib.ptr(alpha), ts.data_ptr(),
+                                                 spec["weight_t"].data_ptr(), pt.data_ptr(), B, spec["T"], spec["H"],
+                                                 spec["Lt_history"].data_ptr(), spec["Lt_count"].data_ptr(),
+                                                 int(spec["update_history"]), bufs.lu.data_ptr(), loss.data_ptr(),
+                                                 bufs.gradcoef.data_ptr(), st))
+        self._saved = dict(B=B, bufs=bufs, chains=(br1, br2, out), keepalive=(x0, s8, noise, keep1, keep2, target, alpha,
+                                                                              rowdiv, pt))
+        return loss
+
+    def train_backward(self, gloss):
+        prev = self.lib.gdmcf_gemm_precision(0)
+        try:
+            return self._train_backward(gloss)
+        finally:
+            self.lib.gdmcf_gemm_precision(prev)
+
+    def _train_backward(self, gloss):
+        """Gradients in model.parameters() order: emb_layer (w, b), in_layers..., in_layers2..., out_layers..."""
+        sv = self._saved
+        if sv is None:
+            raise RuntimeError("gdmcf_amd: train_backward without a preceding training_losses")
+        lib, st = self.lib, _lib.stream_ptr()
+        bufs, B = sv["bufs"], sv["B"]
+        br1, br2, out = sv["chains"]
+        m = self.model
+        rowscale = (gloss.to(torch.float32) * bufs.gradcoef).contiguous()
+
+        def weight_grad(w, bias, dz_ptr, lddz, rs, A_ptr, lda):
+            N, K = w.shape
+            dW, db = torch.empty_like(w), torch.empty_like(bias)
+            if rs is not None:  # (rs . dZ)^T A == dZ^T (rs . A): scale the small activation instead of the big dZ
+                _lib.check(lib.gdmcf_rowscale_f32(A_ptr, lda, rs.data_ptr(), B, K, bufs.hs.data_ptr(), bufs.hs.stride(0), st))
+                A_ptr, lda = bufs.hs.data_ptr(), bufs.hs.stride(0)
+            _lib.check(lib.gdmcf_linear_bwd_weight_f32(dz_ptr, lddz, A_ptr, lda, _lib.ptr(rs), B, N, K, dW.data_ptr(),
+                                                       dW.stride(0), db.data_ptr(), 0, st))
+            return dW, db
+
+        def input_grad(w, dz_ptr, lddz, rs, A_ptr, lda, act_prev, d_ptr, ldd):
+            N, K = w.shape
+            _lib.check(lib.gdmcf_linear_bwd_input_f32(dz_ptr, lddz, w.data_ptr(), w.stride(0), _lib.ptr(rs), A_ptr, lda,
+                                                      act_prev, B, N, K, d_ptr, ldd, bufs.ws.data_ptr(), bufs.ws_bytes, st))
+
+        # ---- out layers: from the loss layer down to the concatenated hidden activation
+        g_out = [None] * len(out)
+        dz_ptr, lddz, rs = bufs.diff.data_ptr(), bufs.ldi, rowscale
+        for li in range(len(out) - 1, -1, -1):
+            w, bias, _ = out[li]
+            if li > 0:
+                A_prev, act_prev, dprev = bufs.acts_out[li - 1], out[li - 1][2], bufs.dz_out[li - 1]
+            else:
+                A_prev, act_prev, dprev = bufs.hcat, 1, bufs.dhcat  # both branches end in tanh
+            g_out[li] = weight_grad(w, bias, dz_ptr, lddz, rs, A_prev.data_ptr(), A_prev.stride(0))
+            input_grad(w, dz_ptr, lddz, rs, A_prev.data_ptr(), A_prev.stride(0), act_prev, dprev.data_ptr(), dprev.stride(0))
+            dz_ptr, lddz, rs = dprev.data_ptr(), dprev.stride(0), None
+
+        # ---- one input branch: hidden layers, then the timestep-embedding columns of its first layer
+        def branch(chain, acts, dzs, xin, ldx, I_cols, dz_ptr):
+            grads = [None] * len(chain)
+            lddz = bufs.dhcat.stride(0)
+            for li in range(len(chain) - 1, -1, -1):
+                w, bias, _ = chain[li]
+                if li > 0:
+                    A_prev = acts[li - 1]
+                    grads[li] = weight_grad(w, bias, dz_ptr, lddz, None, A_prev.data_ptr(), A_prev.stride(0))
+                    input_grad(w, dz_ptr, lddz, None, A_prev.data_ptr(), A_prev.stride(0), chain[li - 1][2],
+                               dzs[li - 1].data_ptr(), dzs[li - 1].stride(0))
+                    dz_ptr, lddz = dzs[li - 1].data_ptr(), dzs[li - 1].stride(0)
+                else:
+                    grads[li] = weight_grad(w, bias, dz_ptr, lddz, None, xin.data_ptr(), ldx)
+                    dWe, dbe = torch.empty_like(m.emb_layer.weight), torch.empty_like(m.emb_layer.bias)
+                    _lib.check(lib.gdmcf_emb_bwd_f32(dz_ptr, lddz, w.data_ptr(), w.stride(0), I_cols, self.E,
+                                                     bufs.temb.data_ptr(), B, w.shape[0], bufs.demb.data_ptr(),
+                                                     dWe.data_ptr(), dbe.data_ptr(), st))
+            return grads, dWe, dbe
+
+        g1, dWe1, dbe1 = branch(br1, bufs.acts1, bufs.dz1, bufs.xin1, bufs.ld1, self.I, bufs.dhcat.data_ptr())
+        g2, dWe2, dbe2 = branch(br2, bufs.acts2, bufs.dz2, bufs.xin2, bufs.ld2, 2 * self.I,
+                                bufs.dhcat.data_ptr() + 4 * bufs.h1)
+        res = [dWe1 + dWe2, dbe1 + dbe2]
+        for g in g1 + g2 + g_out:
+            res += [g[0], g[1]]
+        return res
+
+    # -- plain forward (evaluation / reverse loop) ----------------------------------------------------------------------
+    def forward_plain(self, x, timesteps, x_U, training, drop_mask=None, drop_mask_U=None):
+        prev = self.lib.gdmcf_gemm_precision(0)
+        try:
+            B, dev = x.shape[0], x.device
+            br1, br2, out = self._chains()
+            bufs = self.buffers(B, dev)
+            lib, st = self.lib, _lib.stream_ptr()
+            self.version += 1
+            self._saved = None
+            ts = timesteps.to(device=dev, dtype=torch.int64).contiguous()
+            if x.dtype != torch.float32 or x.stride(-1) != 1:
+                x = x.float().contiguous()
+            xu = x_U.reshape(B, -1)
+            if xu.shape[1] != 2 * self.I:
+                raise RuntimeError("gdmcf_amd.DNNOneHot: x_U must hold two columns per item")
+            if xu.dtype != torch.float32 or xu.stride(-1) != 1:
+                xu = xu.float().contiguous()
+            keep = (self._prep(bufs, x, self.I, bufs.xin1, ts, None, None, None, drop_mask, training),
+                    self._prep(bufs, xu, 2 * self.I, bufs.xin2, ts, None, None, None, drop_mask_U, training))
+            A, lda = self._hidden(bufs, br1, br2, out, B)
+            w, bias, act = out[-1]
+            N, K = w.shape
+            res = torch.empty(B, N, dtype=torch.float32, device=dev)
+            _lib.check(lib.gdmcf_linear_fwd_f32(A.data_ptr(), lda, w.data_ptr(), w.stride(0), bias.data_ptr(), act, B, N, K,
+                                                res.data_ptr(), res.stride(0), bufs.ws.data_ptr(), bufs.ws_bytes, st))
+            del keep
+            return res
+        finally:
+            self.lib.gdmcf_gemm_precision(prev)
+
+
+class DNNOneHot(nn.Module):
+    """Drop-in for the reference DNNOneHot (models/DNN.py:360-477).  As there, `out_dims[0]` of the CALLER's list grows
+    by the width of the second branch (the reference aliases and mutates it, :384-385)."""
+
+    def __init__(self, in_dims, out_dims, emb_size, time_type="cat", norm=False, dropout=0.5):
+        super().__init__()
+        self.in_dims = in_dims
+        self.in_dims2 = list(in_dims)
+        self.in_dims2[0] *= 2
+        self.out_dims = out_dims
+        assert out_dims[0] == in_dims[-1], "In and out dimensions must equal to each other."
+        self.time_type = time_type
+        self.time_emb_dim = emb_size
+        self.norm = norm
+        self.emb_layer = nn.Linear(self.time_emb_dim, self.time_emb_dim)
+        if self.time_type == "cat":
+            in_dims_temp = [self.in_dims[0] + self.time_emb_dim] + list(self.in_dims[1:])
+            in_dims_temp2 = [self.in_dims2[0] + self.time_emb_dim] + list(self.in_dims2[1:])
+        else:
+            raise ValueError("Unimplemented timestep embedding type %s" % self.time_type)
+        out_dims_temp = self.out_dims
+        out_dims_temp[0] += self.in_dims2[-1]
+        self.in_layers = nn.ModuleList([nn.Linear(a, b) for a, b in zip(in_dims_temp[:-1], in_dims_temp[1:])])
+        self.in_layers2 = nn.ModuleList([nn.Linear(a, b) for a, b in zip(in_dims_temp2[:-1], in_dims_temp2[1:])])
+        self.out_layers = nn.ModuleList([nn.Linear(a, b) for a, b in zip(out_dims_temp[:-1], out_dims_temp[1:])])
+        self.drop = nn.Dropout(dropout)  # holds p; the masks are applied inside the HIP input kernel
+        self.init_weights()
+        self.lrelu = torch.nn.LeakyReLU(0.1)  # present (and unused) in the reference; kept for pickling parity
+        self._engine = None
+
+    def init_weights(self):
+        for layer in list(self.in_layers) + list(self.in_layers2) + list(self.out_layers) + [self.emb_layer]:
+            fan_out, fan_in = layer.weight.size()
+            layer.weight.data.normal_(0.0, np.sqrt(2.0 / (fan_in + fan_out)))
+            layer.bias.data.normal_(0.0, 0.001)
+
+    @property
+    def engine(self):
+        if self._engine is None:
+            self._engine = OneHotEngine(self)
+        return self._engine
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_engine"] = None
+        return state
+
+    def param_list(self):
+        return list(self.parameters())
+
+    def forward(self, x, timesteps, x_U, drop_mask=None, drop_mask_U=None):
+        """model(x_t, t, x_tU) of the reference's evaluation path.  Training goes through
+        GaussianDiffusionDiscrete.training_losses (fused forward + loss with its own backward); this plain forward
+        carries no autograd graph."""
+        _lib.require_gpu(x, "DNNOneHot input")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
+            raise RuntimeError("gdmcf_amd.DNNOneHot: the plain forward is not differentiable; train through "
+                               "GaussianDiffusionDiscrete.training_losses (or call under torch.no_grad())")
+        return self.engine.forward_plain(x, timesteps, x_U, self.training, drop_mask, drop_mask_U)

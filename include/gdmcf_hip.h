@@ -97,6 +97,20 @@ int gdmcf_dnn_prep_input_f32(const float* x, int64_t ldx, const int64_t* ts, con
                              float* xt_out, int64_t ldxt, float* temb_out, float* rownorm_ws,
                              void* stream);
 
+/* ---- one-hot rows with discrete transition noise (first slice) -------------------
+ * replaces GaussianDiffusionDiscrete.apply_noise (gaussian_diffusion.py:770-831: get_Qt_bar :597-614,
+ * sample_discrete_features :999-1038) together with F.one_hot(x_start) and the `x_tU & one_hot(x_start)` that
+ * follows it (:841-849 in training_losses, :672-686 in p_sample), and the x_U.reshape of DNNOneHot.forward
+ * (models/DNN.py:444):
+ *   c0 = x0[b,i] != 0 ; s ~ row c0 of Q = a*I + (1-a)*[[e,1-e],[e,1-e]], a = (float)ts[b]/B (:775), e = discrete ;
+ *   xU[b, 2i + c] = (c == c0 && s == c0) ? 1 : 0          (float32, the [B, 2I] input of the second MLP branch)
+ * sampled (optional, uint8 [B,lds]): the drawn classes s are given (parity runs; ts may be NULL then); otherwise
+ * s = (u < P(1)) with u the Philox4x32-10 uniform of element (b,i): component i&3 of the block with counter
+ * (i>>2, b, 3, offset), key seed.  sampled_out (optional) receives s.                                        */
+int gdmcf_onehot_noise_f32(const float* x0, int64_t ldx, const int64_t* ts, int B, int I, float discrete,
+                           const uint8_t* sampled, int64_t lds, uint64_t seed, uint64_t offset,
+                           float* xU, int64_t ldu, uint8_t* sampled_out, int64_t ldso, void* stream);
+
 /* Rewrites only the embedding + padding columns [I, ldxin) of xin for new timesteps (reverse
  * loop: x_t already sits in xin[:, 0:I], written by gdmcf_linear_posterior_fwd_f32).          */
 int gdmcf_dnn_emb_cols_f32(const int64_t* ts, const float* emb_w, const float* emb_b, int E, int B,

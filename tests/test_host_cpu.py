@@ -65,9 +65,30 @@ def test_diffusion_object_surface_and_weights():
     dd = gdmcf_amd.GaussianDiffusionDiscrete(gdmcf_amd.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, 5, "cpu",
                                              discrete=0.99, CatOneHot=False, epps=0.9995, args=None).to("cpu")
     np.testing.assert_array_equal(dd.betas.numpy(), d.betas.numpy())
+    # CatOneHot: built for the Discrete class (with a DNNOneHot denoiser), not for the base class's own one-hot branch
+    dd1 = gdmcf_amd.GaussianDiffusionDiscrete(gdmcf_amd.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, 5, "cpu",
+                                              CatOneHot=True)
+    assert dd1.CatOneHot and dd1.indexIn is False and dd1.discrete == 0.99
     with pytest.raises(NotImplementedError):
-        gdmcf_amd.GaussianDiffusionDiscrete(gdmcf_amd.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, 5, "cpu",
-                                            CatOneHot=True)
+        gdmcf_amd.GaussianDiffusion(gdmcf_amd.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, 5, "cpu",
+                                    CatOneHot=True)
+
+
+def test_onehot_backbone_surface_matches_reference_init_and_names():
+    """DNNOneHot: same state_dict names / shapes and the same initialisation draws as the reference (the fixture's
+    weights were drawn by the reference class under the same seed), incl. the growth of the caller's out_dims[0]."""
+    fx = H.load("onehot_train_deep_x0")
+    meta = H.onehot_train_meta(fx)
+    torch.manual_seed(33)
+    I, dims = meta["I"], meta["dims"]
+    out_dims = dims[::-1] + [I]
+    m = gdmcf_amd.DNNOneHot([I] + dims, out_dims, 10)
+    assert out_dims[0] == 2 * dims[-1]
+    sd = m.state_dict()
+    ref = H.state_dict_from(fx)
+    assert list(sd.keys()) == list(ref.keys())
+    for k in ref:
+        assert torch.equal(sd[k], ref[k]), k
 
 
 def test_dnn_surface_matches_reference_init_and_names():
