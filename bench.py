@@ -38,7 +38,7 @@ PEAK_F32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_* = 64 FLOP/cl
 PEAK_BF16_MATRIX_TFLOPS = 2516.6  # dense bf16 MFMA = 16 x the f32 matrix rate (same guide)
 PEAK_HBM_GBPS = 8000.0
 TAGS = {1: "linear_fwd_gemm", 2: "loss_fwd_gemm", 3: "posterior_gemm", 4: "bwd_input_gemm", 5: "bwd_weight_gemm",
-        6: "adamw", 7: "prep_input", 8: "spmm_csr", 9: "topk"}
+        6: "adamw", 7: "prep_input", 8: "spmm_csr", 9: "topk", 10: "onehot_noise"}
 GEMM_TAGS = (1, 2, 3, 4, 5)
 # rocprofv3 kernel names of the tagged launches at the Yelp-shape workload (for the PMC traffic lookup)
 TRAFFIC_KERNEL = {"bwd_weight_gemm": "gemm_f32_spec_kernel<1, 1, 128, 128, 16, 2, 2, 4, 2>",
@@ -85,6 +85,9 @@ def parse():
                     help="single GPU: update the two large weights inside the weight-gradient GEMM epilogue "
                          "(FusedAdamW.fuse_into_backward); same update rule, gradient never materialised")
     ap.add_argument("--bpr", action="store_true", help="also time a LightGCN BPR training step (reported under 'bpr')")
+    ap.add_argument("--backbone", default="dnn", choices=["dnn", "onehot"],
+                    help="dnn: the plain denoiser (BASELINE configs); onehot: GaussianDiffusionDiscrete(CatOneHot=True) + "
+                         "DNNOneHot (SURVEY 8 f1, first slice; fp32, all-reduce data parallelism)")
     ap.add_argument("--rehearse-dp", action="store_true",
                     help="N = 1 only: create a one-rank RCCL group and run every data-parallel collective through it "
                          "(rehearsal of the N > 1 code path on a single-GPU box)")
@@ -115,8 +118,12 @@ def cpu_baseline(args, I, x_batches, seconds):
     """The oracle's train step on the host cores, same shape / same rows (bounded sample)."""
     from oracle import gdmcf_oracle as O
     torch.manual_seed(0)
-    om = O.DNN([I, args.hidden], [args.hidden, I], 10)
-    od = O.GaussianDiffusion(O.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, args.T)
+    if args.backbone == "onehot":
+        om = O.DNNOneHot([I, args.hidden], [args.hidden, I], 10)
+        od = O.GaussianDiffusionDiscrete(O.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, args.T, CatOneHot=True)
+    else:
+        om = O.DNN([I, args.hidden], [args.hidden, I], 10)
+        od = O.GaussianDiffusion(O.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, args.T)
     opt = O.make_optimizer(om, 1e-5)
     om.train()
     xs = [torch.from_numpy(b) for b in x_batches[:2]]
@@ -177,8 +184,15 @@ def main():
     x_dev = torch.from_numpy(x_host[:1]).to(dev)
 
     torch.manual_seed(0)
-    model = gdmcf_amd.DNN([I, hid], [hid, I], 10, time_type="cat", norm=False, gemm_dtype=args.gemm_dtype).to(dev)
-    diffusion = gdmcf_amd.GaussianDiffusion(gdmcf_amd.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, T, dev)
+    if args.backbone == "onehot":
+        if args.gemm_dtype != "f32" or args.fuse_optimizer or args.shard_optimizer:
+            raise SystemExit("--backbone onehot: fp32, separate AdamW pass, all-reduce data parallelism only")
+        model = gdmcf_amd.DNNOneHot([I, hid], [hid, I], 10, time_type="cat", norm=False).to(dev)
+        diffusion = gdmcf_amd.GaussianDiffusionDiscrete(gdmcf_amd.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, T,
+                                                        dev, CatOneHot=True)
+    else:
+        model = gdmcf_amd.DNN([I, hid], [hid, I], 10, time_type="cat", norm=False, gemm_dtype=args.gemm_dtype).to(dev)
+        diffusion = gdmcf_amd.GaussianDiffusion(gdmcf_amd.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, T, dev)
     opt = gdmcf_amd.FusedAdamW(model.parameters(), lr=1e-5, weight_decay=0.0)
     if args.fuse_optimizer and world == 1:
         opt.fuse_into_backward(model)
@@ -186,7 +200,7 @@ def main():
     torch.manual_seed(1234 + rank)
     # N > 1: the same bytes cross xGMI either way (reduce-scatter + all-gather == all-reduce), but the sharded
     # optimiser touches 1/N of the AdamW state per GPU and its all-gathers overlap the next step's first GEMMs
-    sharded = (args.shard_optimizer or world > 1) and not args.allreduce_optimizer
+    sharded = (args.shard_optimizer or world > 1) and not args.allreduce_optimizer and args.backbone == "dnn"
     step = DataParallelStep(diffusion, model, opt, shard_optimizer=sharded, force_exchange=args.rehearse_dp)
 
     def sync():
@@ -290,8 +304,10 @@ def main():
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": args.gemm_dtype, "data": "synthetic",
             "config": {"workload": f"{args.workload}-shape synthetic rows, batch={B}/GPU, dims=[{hid}], T={T}, "
                                    f"noise_scale=0.01, linear-var, mean_type=x0, reweight, AdamW lr=1e-5"
+                                   + (", backbone DNNOneHot under GaussianDiffusionDiscrete(CatOneHot) (SURVEY 8 f1a)"
+                                      if args.backbone == "onehot" else "")
                                    + (" (BASELINE configs[1])" if args.workload == "yelp" and T == 5 and hid == 1000
-                                      and args.gemm_dtype == "f32" else "")
+                                      and args.gemm_dtype == "f32" and args.backbone == "dnn" else "")
                                    + (" (BASELINE configs[2]: bf16 denoiser GEMM inputs, f32 accumulate/state)"
                                       if args.workload == "amazon-book" and args.gemm_dtype == "bf16" else ""),
                        "n_items": I, "global_batch": world * B, "parallelism": f"dp{world}"},

@@ -225,25 +225,52 @@ __global__ __launch_bounds__(256) void onehot_noise_kernel(const float* __restri
         u[0] = r.x; u[1] = r.y; u[2] = r.z; u[3] = r.w;
         a = __fdiv_rn((float)ts[b], (float)B);
     }
+    typedef f32x4 f32x4_u4 __attribute__((aligned(4)));
+    const bool full = i0 + 3 < I;
+    float xv[4] = {0.f, 0.f, 0.f, 0.f};
+    uint32_t sv = 0;  // given classes of the four items, one per byte
+    if (full) {  // rows are only 4-byte aligned when I is odd: gfx950 takes unaligned 16-byte accesses
+        const f32x4 t4 = *reinterpret_cast<const f32x4_u4*>(x0 + (int64_t)b * ldx + i0);
+        xv[0] = t4.x; xv[1] = t4.y; xv[2] = t4.z; xv[3] = t4.w;
+    } else {
+        for (int j = 0; j < 4; ++j)
+            if (i0 + j < I) xv[j] = x0[(int64_t)b * ldx + i0 + j];
+    }
+    if (sampled)
+        for (int j = 0; j < 4; ++j)
+            if (i0 + j < I) sv |= (uint32_t)(sampled[(int64_t)b * lds + i0 + j] != 0) << (8 * j);
+    float o[8];
+    uint32_t so = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int i = i0 + j;
-        if (i >= I) break;
-        const int c0 = x0[(int64_t)b * ldx + i] != 0.f;
+        const int c0 = xv[j] != 0.f;
         int s;
         if (sampled) {
-            s = sampled[(int64_t)b * lds + i] != 0;
+            s = (sv >> (8 * j)) & 1;
         } else {
             // P(class 1) = a*[c0 == 1] + (1 - a)*(1 - e), each product and the sum rounded to f32 as torch does
             const float p1 = __fadd_rn(c0 ? a : 0.f, __fmul_rn(__fsub_rn(1.f, a), p1_off));
             s = ((float)(u[j] >> 8) * 5.9604644775390625e-8f) < p1;
         }
-        if (sampled_out) sampled_out[(int64_t)b * ldso + i] = (uint8_t)s;
+        so |= (uint32_t)s << (8 * j);
         const float keep = (s == c0) ? 1.f : 0.f;
-        float* o = xU + (int64_t)b * ldu + 2 * (int64_t)i;
-        o[0] = c0 ? 0.f : keep;
-        o[1] = c0 ? keep : 0.f;
+        o[2 * j] = c0 ? 0.f : keep;
+        o[2 * j + 1] = c0 ? keep : 0.f;
     }
+    float* op = xU + (int64_t)b * ldu + 2 * (int64_t)i0;
+    if (full) {
+        *reinterpret_cast<f32x4_u4*>(op) = f32x4{o[0], o[1], o[2], o[3]};
+        *reinterpret_cast<f32x4_u4*>(op + 4) = f32x4{o[4], o[5], o[6], o[7]};
+    } else {
+        for (int j = 0; j < 4; ++j)
+            if (i0 + j < I) {
+                op[2 * j] = o[2 * j];
+                op[2 * j + 1] = o[2 * j + 1];
+            }
+    }
+    if (sampled_out)
+        for (int j = 0; j < 4; ++j)
+            if (i0 + j < I) sampled_out[(int64_t)b * ldso + i0 + j] = (uint8_t)((so >> (8 * j)) & 1);
 }
 
 __global__ void emb_cols_kernel(const int64_t* __restrict__ ts, const float* __restrict__ emb_w,
@@ -725,8 +752,12 @@ int gdmcf_onehot_noise_f32(const float* x0, int64_t ldx, const int64_t* ts, int 
                  "onehot_noise: null pointer / bad leading dimension");
     // u_x = th.tensor([[e, 1 - e], ...]): 1 - e is formed in double and rounded to float32 once
     const float p1_off = (float)(1.0 - (double)discrete);
-    hipLaunchKernelGGL(onehot_noise_kernel, dim3(gd_cdiv(I, 1024), B), dim3(256), 0, (hipStream_t)stream, x0, ldx, ts, B, I,
-                       p1_off, sampled, lds, seed, offset, xU, ldu, sampled_out, ldso);
+    {
+        // algorithmic bytes: read x0 (+ the given classes), write the [B, 2I] image
+        GdProfScope prof(10, (double)B * I * (4.0 + 8.0 + (sampled ? 1.0 : 0.0)), (hipStream_t)stream);
+        hipLaunchKernelGGL(onehot_noise_kernel, dim3(gd_cdiv(I, 1024), B), dim3(256), 0, (hipStream_t)stream, x0, ldx, ts, B,
+                           I, p1_off, sampled, lds, seed, offset, xU, ldu, sampled_out, ldso);
+    }
     return gd_launch_status("onehot_noise");
 }
 

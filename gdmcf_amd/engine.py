@@ -44,6 +44,8 @@ def _with_precision(fn):
 
 
 class DenoiserEngine:
+    supports_grad_sink = True  # parallel.DataParallelStep may install `grad_sink` (overlapped gradient exchange)
+
     def __init__(self, model):
         self.model = model
         self.lib = _lib.load()

@@ -44,6 +44,9 @@ class _OneHotTrainLoss(torch.autograd.Function):
 
 
 class OneHotEngine:
+    supports_grad_sink = False  # data parallel: gradients are all-reduced after the backward (parallel.allreduce_grads)
+    fused_opt = None
+
     def __init__(self, model):
         self.model = model
         self.lib = _lib.load()
@@ -259,7 +262,10 @@ class OneHotEngine:
         bufs, B = sv["bufs"], sv["B"]
         br1, br2, out = sv["chains"]
         m = self.model
-        rowscale = (gloss.to(torch.float32) * bufs.gradcoef).contiguous()
+        if isinstance(gloss, float):  # mean reduction: the same upstream gradient 1/B on every row
+            rowscale = bufs.gradcoef * gloss
+        else:
+            rowscale = (gloss.to(torch.float32) * bufs.gradcoef).contiguous()
 
         def weight_grad(w, bias, dz_ptr, lddz, rs, A_ptr, lda):
             N, K = w.shape

@@ -162,7 +162,8 @@ class DataParallelStep:
         self.diffusion, self.model, self.optimizer, self.group = diffusion, model, optimizer, group
         self.direct_backward = direct_backward
         self.defer_gather = bool(defer_gather)
-        self.shard_optimizer = bool(shard_optimizer) and overlap and hasattr(optimizer, "step_rows")
+        self.shard_optimizer = (bool(shard_optimizer) and overlap and hasattr(optimizer, "step_rows")
+                                and getattr(model.engine, "supports_grad_sink", False))
         self._sharded = []
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._handles, self._small = [], []
@@ -176,8 +177,8 @@ class DataParallelStep:
             model.engine.fused_opt = None  # gradients must be all-reduced before the update
             if hasattr(optimizer, "_fused_ids"):
                 optimizer._fused_ids = set()
-            if overlap:
-                model.engine.grad_sink = self._sink
+            if overlap and getattr(model.engine, "supports_grad_sink", False):
+                model.engine.grad_sink = self._sink  # (other engines: gradients are exchanged after the backward)
             if self.shard_optimizer and self.defer_gather:
                 model.register_state_dict_pre_hook(lambda *a, **k: self.flush())  # complete weights in checkpoints
         elif (early_update and hasattr(optimizer, "step_subset") and getattr(model.engine, "fused_opt", None) is None
@@ -314,7 +315,7 @@ class DataParallelStep:
             loss.backward()
         if self.exchange:
             d = self.diffusion
-            if self.model.engine.grad_sink is not None:
+            if getattr(self.model.engine, "grad_sink", None) is not None:
                 ts_all, lu_all = self._finish_exchange()
             else:
                 allreduce_grads(self.model.parameters(), self.group, force=True)
@@ -345,5 +346,5 @@ class DataParallelStep:
         """Wait (on the current stream) for every all-gather of updated weight rows still in flight.  The engine does
         this by itself before any forward; call it before reading the parameters directly (checkpoints, copies)."""
         eng = getattr(self.model, "engine", None)
-        if eng is not None:
+        if eng is not None and hasattr(eng, "flush_weight_waiters"):
             eng.flush_weight_waiters()

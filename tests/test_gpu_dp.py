@@ -301,3 +301,64 @@ def test_bench_data_parallel_path_in_a_one_rank_rccl_group():
     assert "row-sharded" in sh["optimizer"] and "all-reduce" in ar["optimizer"]
     assert sh["final_loss"] == ar["final_loss"] == plain["final_loss"]
     assert sh["n_gpus"] == 1 and sh["scaling"] == "weak"
+
+
+def _onehot_inputs(step, B2, I2):
+    g = torch.Generator().manual_seed(300 + step)
+    return dict(x=(torch.rand(B2, I2, generator=g) < 0.05).float(), ts=torch.randint(0, T, (B2,), generator=g),
+                sampled=(torch.rand(B2, I2, generator=g) < 0.03).to(torch.uint8), noise=torch.randn(B2, I2, generator=g),
+                drop_mask=(torch.rand(B2, I2, generator=g) < 0.5).to(torch.uint8),
+                drop_mask_U=(torch.rand(B2, 2 * I2, generator=g) < 0.5).to(torch.uint8))
+
+
+def _onehot_build(dev, I2, H2):
+    import gdmcf_amd
+    torch.manual_seed(9)
+    m = gdmcf_amd.DNNOneHot([I2, H2], [H2, I2], 10).to(dev).train()
+    d = gdmcf_amd.GaussianDiffusionDiscrete(gdmcf_amd.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, T, dev,
+                                            CatOneHot=True)
+    return m, d, gdmcf_amd.FusedAdamW(m.parameters(), lr=1e-3, weight_decay=0.0)
+
+
+def _onehot_worker(rank, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    from gdmcf_amd.parallel import DataParallelStep
+    dev, I2, H2, B2 = "cuda:0", 257, 48, 32
+    m, d, o = _onehot_build(dev, I2, H2)
+    step = DataParallelStep(d, m, o)
+    lo, hi = rank * B2 // WORLD, (rank + 1) * B2 // WORLD
+    losses = []
+    for s in range(3):
+        inp = {k: v[lo:hi].to(dev) for k, v in _onehot_inputs(s, B2, I2).items()}
+        x = inp.pop("x")
+        losses.append(float(step(x, True, pt=torch.ones(hi - lo, device=dev), **inp)))
+    torch.cuda.synchronize()
+    torch.save(dict(losses=losses, params=[p.detach().cpu() for p in m.parameters()], hist=d.Lt_history.cpu()),
+               os.path.join(out_dir, f"o{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_onehot_backbone_two_ranks_equal_one_process(tmp_path):
+    """The one-hot backbone has no gradient sink: DataParallelStep all-reduces its gradients after the backward.  Two
+    ranks on half batches reproduce one process on the global batch (sampled classes injected -- the reference's noise
+    level a = ts / batch_size would otherwise depend on the LOCAL batch size)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_onehot_worker, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
+    r0, r1 = torch.load(tmp_path / "o0.pt"), torch.load(tmp_path / "o1.pt")
+    from gdmcf_amd.parallel import DataParallelStep
+    dev, I2, H2, B2 = "cuda:0", 257, 48, 32
+    m, d, o = _onehot_build(dev, I2, H2)
+    step = DataParallelStep(d, m, o)
+    ref = []
+    for s in range(3):
+        inp = {k: v.to(dev) for k, v in _onehot_inputs(s, B2, I2).items()}
+        x = inp.pop("x")
+        ref.append(float(step(x, True, pt=torch.ones(B2, device=dev), **inp)))
+    np.testing.assert_allclose(0.5 * (np.array(r0["losses"]) + np.array(r1["losses"])), ref, rtol=1e-5)
+    for a, b, p in zip(r0["params"], r1["params"], m.parameters()):
+        assert torch.equal(a, b)
+        assert float((a - p.detach().cpu()).abs().max()) < 0.05 * 1e-3 * 3
+    np.testing.assert_allclose(r0["hist"].numpy(), d.Lt_history.cpu().numpy(), rtol=1e-5)
