@@ -94,3 +94,52 @@ for dtype in ("f32", "bf16"):
     eg = max(H.relerr(p.grad.cpu().numpy(), q.grad.numpy()) for p, q in zip(m.parameters(), om.parameters()))
     print(f"{dtype:5s} loss {float(gl.detach()):.8f} (oracle {float(oloss):.8f}, rel {abs(float(gl.detach()) - float(oloss)) / float(oloss):.2e});  "
           f"worst gradient rel-L2 {eg:.2e}")
+
+print("\n== one-hot variant (GaussianDiffusionDiscrete(CatOneHot=True) + DNNOneHot) vs the reference (golden fixtures) ==")
+print(f"{'case':16s} {'steps':>5s} {'max rel err loss':>18s} {'max rel err row loss':>22s} {'grad rel-L2 (step 0)':>22s} {'kept bits':>10s}")
+for case in H.ONEHOT_TRAIN_CASES:
+    fx = H.load("onehot_train_" + case)
+    meta = H.onehot_train_meta(fx)
+    I, dims = meta["I"], meta["dims"]
+    model = gdmcf_amd.DNNOneHot([I] + dims, dims[::-1] + [I], 10)
+    model.load_state_dict(H.state_dict_from(fx))
+    model = model.to(DEV).train()
+    mt = {"x0": ModelMeanType.START_X, "eps": ModelMeanType.EPSILON}[meta["mean_type"]]
+    diff = gdmcf_amd.GaussianDiffusionDiscrete(mt, meta["schedule"], meta["scale"], meta["nmin"], meta["nmax"], meta["T"], DEV,
+                                               discrete=meta["discrete"], CatOneHot=True)
+    opt = gdmcf_amd.FusedAdamW(model.parameters(), lr=meta["lr"], weight_decay=meta["wd"])
+    e_loss = e_row = e_grad = 0.0
+    bits = True
+    for s in range(meta["n_steps"]):
+        inp = H.onehot_step_inputs(fx, s)
+        xU, _ = model.engine.onehot_rows(cu(inp["x"]), None, cu(inp["sampled"]), meta["discrete"])
+        bits = bits and np.array_equal(xU.cpu().numpy().reshape(meta["B"], I, 2).astype(np.uint8), fx[f"s{s}.x_tU"])
+        opt.zero_grad()
+        terms = diff.training_losses(model, cu(inp["x"]), True, ts=cu(inp["ts"]), pt=cu(inp["pt"]), noise=cu(inp["noise"]),
+                                     drop_mask=cu(inp["drop_mask"]), ts_U=cu(inp["ts_U"]), sampled=cu(inp["sampled"]),
+                                     drop_mask_U=cu(inp["drop_mask_U"]))
+        loss = terms["loss"].mean()
+        loss.backward()
+        lv = terms["loss"].detach().cpu().numpy()
+        e_loss = max(e_loss, abs(float(loss.detach()) - float(fx[f"s{s}.loss"])) / abs(float(fx[f"s{s}.loss"])))
+        e_row = max(e_row, float(np.max(np.abs(lv - fx[f"s{s}.loss_vec"]) / np.abs(fx[f"s{s}.loss_vec"]))))
+        if s == 0:
+            e_grad = max(H.relerr(v.grad.cpu().numpy(), fx["g0." + k]) for k, v in model.named_parameters())
+        opt.step()
+    print(f"{case:16s} {meta['n_steps']:5d} {e_loss:18.2e} {e_row:22.2e} {e_grad:22.2e} {'bit-exact' if bits else 'DIFFER':>10s}")
+for case in H.ONEHOT_SAMPLE_CASES:
+    fx = H.load("onehot_sample_" + case)
+    meta = H.onehot_sample_meta(fx)
+    I, dims = meta["I"], meta["dims"]
+    model = gdmcf_amd.DNNOneHot([I] + dims, dims[::-1] + [I], 10)
+    model.load_state_dict(H.state_dict_from(fx))
+    model = model.to(DEV).eval()
+    mt = {"x0": ModelMeanType.START_X, "eps": ModelMeanType.EPSILON}[meta["mean_type"]]
+    diff = gdmcf_amd.GaussianDiffusionDiscrete(mt, "linear-var", meta["scale"], meta["nmin"], meta["nmax"], meta["T"], DEV,
+                                               discrete=meta["discrete"], CatOneHot=True)
+    x = cu(torch.from_numpy(fx["x_start"].astype(np.float32)))
+    p0 = diff.p_sample(model, x, 0, False)
+    pT = diff.p_sample(model, x, meta["T"], False, noise0=cu(torch.from_numpy(fx["noise_stepsT"])),
+                       sampled0=cu(torch.from_numpy(fx["sampled_stepsT"])))
+    print(f"{case:12s} p_sample rel err: steps=0 {H.relerr(p0.cpu().numpy(), fx['pred_steps0']):.2e}, "
+          f"steps=T {H.relerr(pT.cpu().numpy(), fx['pred_stepsT']):.2e}")
