@@ -465,6 +465,7 @@ def gen_onehot():
     gen_train_onehot("tiny_x0", 8, 64, [16], 5, "x0", seed=31)
     gen_train_onehot("ragged_eps_wd", 12, 131, [24], 5, "eps", seed=32, density=0.05, wd=0.01, schedule="linear", scale=0.1)
     gen_train_onehot("deep_x0", 10, 90, [32, 16], 5, "x0", seed=33, density=0.06)
+    gen_train_onehot("norm_eps", 9, 77, [20], 6, "eps", seed=34, density=0.08, norm=True, schedule="cosine", scale=0.05)
     gen_sample_onehot("tiny_x0", 8, 64, [16], 5, "x0", seed=41)
     gen_sample_onehot("ragged_eps", 10, 131, [24], 5, "eps", seed=42, scale=50.0)
 

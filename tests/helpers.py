@@ -10,7 +10,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TRAIN_CASES = ["tiny_x0", "tiny_eps", "ragged_x0", "ragged_eps_wd", "imp_T40", "deep_x0", "norm_x0", "cosine_eps",
                "binomial_x0", "deep_eps_norm"]
 SAMPLE_CASES = ["tiny_x0", "ragged_x0", "ragged_eps", "norm_x0"]
-ONEHOT_TRAIN_CASES = ["tiny_x0", "ragged_eps_wd", "deep_x0"]
+ONEHOT_TRAIN_CASES = ["tiny_x0", "ragged_eps_wd", "deep_x0", "norm_eps"]
 ONEHOT_SAMPLE_CASES = ["tiny_x0", "ragged_eps"]
 
 

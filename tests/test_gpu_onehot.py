@@ -145,7 +145,7 @@ def test_onehot_rng_path_trains_and_matches_oracle_on_its_own_draws():
         loss = diff.training_losses(model, x, True, ts=ts0, pt=pt)["loss"].mean()
         loss.backward()
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     assert np.isfinite(losses).all() and losses[-1] < 0.7 * losses[0], losses[::5]
     assert [k for k, _ in model.named_parameters()][:6] == ["emb_layer.weight", "emb_layer.bias", "in_layers.0.weight",
                                                             "in_layers.0.bias", "in_layers2.0.weight", "in_layers2.0.bias"]
