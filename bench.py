@@ -17,8 +17,9 @@ Besides the contract fields the JSON line carries
 
 Other legs / variants (not part of the default line): --gemm-dtype bf16 (BASELINE configs[2]), --workload
 amazon-book|stress, --fuse-optimizer (AdamW inside the weight-gradient GEMM epilogues, N = 1), --allreduce-optimizer (N > 1: plain
-all-reduce + full AdamW on every rank instead of the default reduce-scatter + AdamW on 1/N of the rows + deferred
-all-gather), --rehearse-dp (N = 1: every collective through a one-rank RCCL group), --global-batch G (strong scaling), --spmm (LightGCN
+all-reduce + full AdamW on every rank) / --shard-optimizer (reduce-scatter + AdamW on 1/N of the rows + deferred
+all-gather); with neither, N > 1 times both for a few untimed steps after the warm-up and keeps the faster one
+(`dp_autotune` in the output), --rehearse-dp (N = 1: every collective through a one-rank RCCL group), --global-batch G (strong scaling), --spmm (LightGCN
 propagation; row-sharded when N > 1), --bpr (LightGCN BPR training step), --sampling (p_sample + masked top-k).
 """
 import argparse
@@ -94,6 +95,9 @@ def parse():
     ap.add_argument("--shard-optimizer", action="store_true",
                     help="reduce-scatter + AdamW on 1/N of the rows + all-gather (the default when N > 1; with "
                          "--rehearse-dp it selects that path at N = 1)")
+    ap.add_argument("--autotune-dp", action="store_true",
+                    help="with --rehearse-dp: time both exchange variants during warm-up and keep the faster one (what "
+                         "happens by default when N > 1 and neither variant is requested)")
     ap.add_argument("--allreduce-optimizer", action="store_true",
                     help="N > 1: all-reduce of the gradients + full AdamW on every rank instead of the sharded optimiser")
     ap.add_argument("--sampling", action="store_true", help="also time p_sample + masked top-k (reported under 'sampling')")
@@ -201,6 +205,8 @@ def main():
     # N > 1: the same bytes cross xGMI either way (reduce-scatter + all-gather == all-reduce), but the sharded
     # optimiser touches 1/N of the AdamW state per GPU and its all-gathers overlap the next step's first GEMMs
     sharded = (args.shard_optimizer or world > 1) and not args.allreduce_optimizer and args.backbone == "dnn"
+    # neither flag given at N > 1: both variants are timed during warm-up (untimed region) and the faster one runs
+    autotune = (world > 1 or args.autotune_dp) and not (args.shard_optimizer or args.allreduce_optimizer) and args.backbone == "dnn"
     step = DataParallelStep(diffusion, model, opt, shard_optimizer=sharded, force_exchange=args.rehearse_dp)
 
     def sync():
@@ -213,6 +219,27 @@ def main():
     for i in range(args.warmup):
         loss = step(dcsr.rows(row_ids[i % n_pool], out=x_buf), True)
     sync()
+    dp_autotune = None
+    if autotune and step.exchange:
+        # untimed: a few steps of each exchange variant on this node's links, max over ranks, keep the faster one
+        trial = {}
+        for name, flag in (("allreduce", False), ("sharded", True)):
+            step.set_shard_optimizer(flag)
+            for i in range(2):
+                step(dcsr.rows(row_ids[i % n_pool], out=x_buf), True)
+            sync()
+            t1 = time.perf_counter()
+            for i in range(6):
+                step(dcsr.rows(row_ids[i % n_pool], out=x_buf), True)
+            sync()
+            tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            trial[name] = float(tt) / 6 * 1e3
+        sharded = trial["sharded"] <= trial["allreduce"]
+        step.set_shard_optimizer(sharded)
+        sync()
+        dp_autotune = dict(allreduce_ms_per_step=round(trial["allreduce"], 4), sharded_ms_per_step=round(trial["sharded"], 4),
+                           chosen="sharded" if sharded else "allreduce")
     prof = not args.no_prof
     every = max(1, args.prof_every)
     n_profiled = len(range(0, args.steps, every)) if prof else 0
@@ -313,7 +340,7 @@ def main():
                        "n_items": I, "global_batch": world * B, "parallelism": f"dp{world}"},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": klist, "final_loss": final_loss,
             "host_enqueue_ms_per_step": round(1e3 * host_el / args.steps, 4),
-            "replicas_in_sync": in_sync,
+            "replicas_in_sync": in_sync, "dp_autotune": dp_autotune,
             "optimizer": "FusedAdamW" + (" fused into the dW GEMM epilogues" if (args.fuse_optimizer and world == 1) else
                                          " (row-sharded over the ranks: reduce-scatter, AdamW on 1/N rows, deferred all-gather)"
                                          if (sharded and step.exchange) else

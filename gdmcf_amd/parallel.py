@@ -179,7 +179,7 @@ class DataParallelStep:
                 optimizer._fused_ids = set()
             if overlap and getattr(model.engine, "supports_grad_sink", False):
                 model.engine.grad_sink = self._sink  # (other engines: gradients are exchanged after the backward)
-            if self.shard_optimizer and self.defer_gather:
+            if getattr(model.engine, "supports_grad_sink", False):
                 model.register_state_dict_pre_hook(lambda *a, **k: self.flush())  # complete weights in checkpoints
         elif (early_update and hasattr(optimizer, "step_subset") and getattr(model.engine, "fused_opt", None) is None
               and next(model.parameters()).is_cuda):
@@ -206,6 +206,16 @@ class DataParallelStep:
             self._handles.append((param, _all_reduce(g, self.group, async_op=True)))
         else:
             self._small.append(g)
+
+    def set_shard_optimizer(self, flag):
+        """Switch between the sharded optimiser and the plain all-reduce path between steps (bench.py times both during
+        warm-up and keeps the faster one).  Leaving the sharded mode first completes weights and moments on every rank."""
+        flag = (bool(flag) and hasattr(self.optimizer, "step_rows") and self.exchange
+                and getattr(self.model.engine, "grad_sink", None) is not None)
+        if self.shard_optimizer and not flag:
+            self.gather_optimizer_state()
+        self.shard_optimizer = flag
+        return flag
 
     def gather_optimizer_state(self):
         """Sharded optimiser: make exp_avg / exp_avg_sq of the sharded weights complete on every rank (checkpoints)."""

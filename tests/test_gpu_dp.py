@@ -290,13 +290,19 @@ def test_bench_data_parallel_path_in_a_one_rank_rccl_group():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for extra in (["--rehearse-dp", "--shard-optimizer"], ["--rehearse-dp", "--allreduce-optimizer"], []):
+    for extra in (["--rehearse-dp", "--shard-optimizer"], ["--rehearse-dp", "--allreduce-optimizer"], [],
+                  ["--rehearse-dp", "--autotune-dp"]):
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "2",
                             "--no-cpu-baseline"] + extra, capture_output=True, text=True, cwd=root, timeout=600,
                            env=dict(os.environ, MASTER_PORT="29571"))
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1]))
-    sh, ar, plain = outs
+    sh, ar, plain, auto = outs
+    # neither variant requested: both are timed for a few untimed steps after the warm-up, the faster one runs, and the
+    # switch between them (moments of the sharded weights gathered first) leaves the replicas consistent
+    tune = auto["dp_autotune"]
+    assert tune["chosen"] in ("sharded", "allreduce") and tune["allreduce_ms_per_step"] > 0 and tune["sharded_ms_per_step"] > 0
+    assert auto["replicas_in_sync"] is True and sh["dp_autotune"] is None
     assert sh["replicas_in_sync"] is True and ar["replicas_in_sync"] is True and plain["replicas_in_sync"] is None
     assert "row-sharded" in sh["optimizer"] and "all-reduce" in ar["optimizer"]
     assert sh["final_loss"] == ar["final_loss"] == plain["final_loss"]
