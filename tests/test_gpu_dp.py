@@ -176,9 +176,11 @@ def _shard_worker(rank, port, out_dir):
         m = gdmcf_amd.DNN([I2, H2], [H2, I2], 10).to(dev).train()
         d = gdmcf_amd.GaussianDiffusion(gdmcf_amd.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, T, dev)
         o = gdmcf_amd.FusedAdamW(m.parameters(), lr=1e-3, weight_decay=0.01)
-        step = DataParallelStep(d, m, o, shard_optimizer=shard)
+        step = DataParallelStep(d, m, o, shard_optimizer=bool(shard))
         losses = []
         for s in range(4):
+            if shard == "toggle":  # bench.py's warm-up autotune: sharded, all-reduce, sharded, all-reduce
+                assert step.set_shard_optimizer(s % 2 == 0) == (s % 2 == 0)
             g = torch.Generator().manual_seed(50 + s)
             x = (torch.rand(2 * B2, I2, generator=g) < 0.03).float()[rank * B2:(rank + 1) * B2].to(dev)
             ts = torch.randint(0, T, (2 * B2,), generator=g)[rank * B2:(rank + 1) * B2].to(dev)
@@ -191,10 +193,13 @@ def _shard_worker(rank, port, out_dir):
 
     m0, o0, l0, _ = run(False)
     m1, o1, l1, st1 = run(True)
-    ok = st1.shard_optimizer and l0 == l1
-    for a, b in zip(m0.parameters(), m1.parameters()):
+    m2, o2, l2, st2 = run("toggle")
+    ok = st1.shard_optimizer and l0 == l1 and l0 == l2
+    for a, b, c in zip(m0.parameters(), m1.parameters(), m2.parameters()):
         ok = ok and torch.equal(a, b) and torch.equal(o0.state[a]["exp_avg"], o1.state[b]["exp_avg"]) \
             and torch.equal(o0.state[a]["exp_avg_sq"], o1.state[b]["exp_avg_sq"]) and o0.state[a]["step"] == o1.state[b]["step"]
+        ok = ok and torch.equal(a, c) and torch.equal(o0.state[a]["exp_avg"], o2.state[c]["exp_avg"]) \
+            and torch.equal(o0.state[a]["exp_avg_sq"], o2.state[c]["exp_avg_sq"])
     torch.save(dict(ok=bool(ok), params=[p.detach().cpu() for p in m1.parameters()]), os.path.join(out_dir, f"s{rank}.pt"))
     dist.destroy_process_group()
 
