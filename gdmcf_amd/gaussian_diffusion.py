@@ -296,6 +296,31 @@ class GaussianDiffusionDiscrete(GaussianDiffusion):
         self.discrete_noise = True
         self.indexIn = False
 
+    # -- the reference's public pieces of the discrete noise, for callers that use them directly -------------------
+    def get_Qt_bar(self, alpha_bar_t):
+        """[B, 2, 2] transition matrices a*I + (1-a)*[[e,1-e],[e,1-e]], e = `discrete` (reference :597-614)."""
+        dev = alpha_bar_t.device
+        e = self.discrete
+        u_x = torch.tensor([[e, 1 - e], [e, 1 - e]], device=dev).unsqueeze(0)
+        a = alpha_bar_t.unsqueeze(1).unsqueeze(1)
+        return a * torch.eye(2, device=dev).unsqueeze(0) + (1 - a) * u_x
+
+    def apply_noise(self, ts, x_start, x_base=None):
+        """One-hot [B, I, 2] (int64) of a class drawn per item from row c0 of Q_bar(ts / batch_size) (reference
+        :770-831); the draw runs inside gdmcf_onehot_noise_f32 (Philox), x_start is the one-hot [B, I, 2] input."""
+        _lib.require_gpu(x_start, "x_start")
+        B, I = x_start.shape[0], x_start.shape[1]
+        x0 = x_start[..., 1].float().contiguous()  # class index of a one-hot pair
+        ts = ts.to(device=x0.device, dtype=torch.int64).contiguous()
+        scratch = torch.empty(B, 2 * I, dtype=torch.float32, device=x0.device)
+        sampled = torch.empty(B, I, dtype=torch.uint8, device=x0.device)
+        self._noise_calls = getattr(self, "_noise_calls", 0) + 1
+        _lib.check(_lib.load().gdmcf_onehot_noise_f32(
+            x0.data_ptr(), x0.stride(0), ts.data_ptr(), B, I, float(self.discrete), None, 0,
+            int(torch.initial_seed()) & (2 ** 63 - 1), (1 << 41) + self._noise_calls, scratch.data_ptr(), scratch.stride(0),
+            sampled.data_ptr(), sampled.stride(0), _lib.stream_ptr()))
+        return torch.nn.functional.one_hot(sampled.long(), num_classes=2)
+
     def _onehot_model(self, model):
         from .onehot import DNNOneHot
         if not isinstance(model, DNNOneHot):

@@ -181,3 +181,26 @@ def test_onehot_full_width_step_matches_oracle():
     np.testing.assert_allclose(gt["loss"].detach().cpu().numpy(), ot["loss"].detach().numpy(), rtol=1e-4, atol=0)
     for (k, a), (_, b) in zip(gm.named_parameters(), om.named_parameters()):
         assert H.relerr(a.grad.cpu().numpy(), b.grad.numpy()) < 3e-4, k
+
+
+def test_apply_noise_and_qt_bar_by_name():
+    """The reference's public methods of the discrete noise: get_Qt_bar equals the oracle's matrices exactly; apply_noise
+    returns one-hot int64 [B, I, 2] whose class-1 rate follows row c0 of Q_bar(ts / B) (4 sigma on 10^5 draws per row)."""
+    B, I, T = 8, 100_000, 5
+    d = gdmcf_amd.GaussianDiffusionDiscrete(ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, T, DEV, discrete=0.8,
+                                            CatOneHot=True)
+    od = O.GaussianDiffusionDiscrete(O.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, T, discrete=0.8, CatOneHot=True)
+    ts = torch.tensor([0, 1, 2, 3, 4, 4, 2, 0])
+    Q = d.get_Qt_bar(cu(ts).float() / B)
+    np.testing.assert_array_equal(Q.cpu().numpy(), od.get_Qt_bar(ts.float() / B).numpy())
+    g = torch.Generator().manual_seed(4)
+    x = (torch.rand(B, I, generator=g) < 0.4).long()
+    out = d.apply_noise(cu(ts), cu(torch.nn.functional.one_hot(x, 2).float()))
+    assert out.shape == (B, I, 2) and out.dtype == torch.int64 and bool((out.sum(-1) == 1).all())
+    s = out[..., 1].cpu()
+    for b in range(B):
+        for c in (0, 1):
+            sel = x[b] == c
+            p, n = float(Q[b, c, 1]), int(sel.sum())
+            assert abs(float(s[b][sel].float().mean()) - p) < 4 * np.sqrt(p * (1 - p) / n) + 1e-6, (b, c)
+    assert not torch.equal(out, d.apply_noise(cu(ts), cu(torch.nn.functional.one_hot(x, 2).float())))  # a new draw per call
