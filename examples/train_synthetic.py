@@ -2,6 +2,7 @@
 
     python examples/train_synthetic.py --users 8000 --epochs 3            # fp32
     python examples/train_synthetic.py --users 8000 --epochs 3 --bf16     # bf16 GEMM inputs
+    python examples/train_synthetic.py --users 8000 --epochs 3 --backbone onehot   # one-hot variant (DNNOneHot)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         examples/train_synthetic.py --users 64000 --epochs 3               # data parallel: one process per GPU (RCCL)
 
@@ -33,6 +34,8 @@ def main():
     ap.add_argument("--T", type=int, default=5)
     ap.add_argument("--lr", type=float, default=1e-4)
     ap.add_argument("--bf16", action="store_true")
+    ap.add_argument("--backbone", default="dnn", choices=["dnn", "onehot"],
+                    help="onehot: GaussianDiffusionDiscrete(CatOneHot=True) + DNNOneHot (fp32)")
     args = ap.parse_args()
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
     dev = torch.device(f"cuda:{local}")
@@ -54,9 +57,14 @@ def main():
     n_dp = (U // (world * args.batch)) * world * args.batch  # every rank must run the same number of steps
     my_train = train[:n_dp][rank::world] if world > 1 else train
     torch.manual_seed(0)
-    model = gdmcf_amd.DNN([I, args.hidden], [args.hidden, I], 10, time_type="cat", norm=False,
-                          gemm_dtype="bf16" if args.bf16 else "f32").to(dev)
-    diffusion = gdmcf_amd.GaussianDiffusion(gdmcf_amd.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, args.T, dev)
+    if args.backbone == "onehot":  # what main.py builds for CatOneHot with args.backbone == 'DNNOneHot' (:192-193, :216-217)
+        model = gdmcf_amd.DNNOneHot([I, args.hidden], [args.hidden, I], 10, time_type="cat", norm=False).to(dev)
+        diffusion = gdmcf_amd.GaussianDiffusionDiscrete(gdmcf_amd.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01,
+                                                        args.T, dev, CatOneHot=True)
+    else:
+        model = gdmcf_amd.DNN([I, args.hidden], [args.hidden, I], 10, time_type="cat", norm=False,
+                              gemm_dtype="bf16" if args.bf16 else "f32").to(dev)
+        diffusion = gdmcf_amd.GaussianDiffusion(gdmcf_amd.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, args.T, dev)
     opt = gdmcf_amd.FusedAdamW(model.parameters(), lr=args.lr, weight_decay=0.0)
     gen = torch.Generator().manual_seed(0)
     from gdmcf_amd.parallel import DataParallelStep
