@@ -88,7 +88,7 @@ def parse():
     ap.add_argument("--bpr", action="store_true", help="also time a LightGCN BPR training step (reported under 'bpr')")
     ap.add_argument("--backbone", default="dnn", choices=["dnn", "onehot"],
                     help="dnn: the plain denoiser (BASELINE configs); onehot: GaussianDiffusionDiscrete(CatOneHot=True) + "
-                         "DNNOneHot (SURVEY 8 f1, first slice; fp32, all-reduce data parallelism)")
+                         "DNNOneHot (SURVEY 8 f1, first slice; fp32)")
     ap.add_argument("--rehearse-dp", action="store_true",
                     help="N = 1 only: create a one-rank RCCL group and run every data-parallel collective through it "
                          "(rehearsal of the N > 1 code path on a single-GPU box)")
@@ -189,8 +189,8 @@ def main():
 
     torch.manual_seed(0)
     if args.backbone == "onehot":
-        if args.gemm_dtype != "f32" or args.fuse_optimizer or args.shard_optimizer:
-            raise SystemExit("--backbone onehot: fp32, separate AdamW pass, all-reduce data parallelism only")
+        if args.gemm_dtype != "f32" or args.fuse_optimizer:
+            raise SystemExit("--backbone onehot: fp32 with a separate AdamW pass only")
         model = gdmcf_amd.DNNOneHot([I, hid], [hid, I], 10, time_type="cat", norm=False).to(dev)
         diffusion = gdmcf_amd.GaussianDiffusionDiscrete(gdmcf_amd.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, T,
                                                         dev, CatOneHot=True)
@@ -204,9 +204,9 @@ def main():
     torch.manual_seed(1234 + rank)
     # N > 1: the same bytes cross xGMI either way (reduce-scatter + all-gather == all-reduce), but the sharded
     # optimiser touches 1/N of the AdamW state per GPU and its all-gathers overlap the next step's first GEMMs
-    sharded = (args.shard_optimizer or world > 1) and not args.allreduce_optimizer and args.backbone == "dnn"
+    sharded = (args.shard_optimizer or world > 1) and not args.allreduce_optimizer
     # neither flag given at N > 1: both variants are timed during warm-up (untimed region) and the faster one runs
-    autotune = (world > 1 or args.autotune_dp) and not (args.shard_optimizer or args.allreduce_optimizer) and args.backbone == "dnn"
+    autotune = (world > 1 or args.autotune_dp) and not (args.shard_optimizer or args.allreduce_optimizer)
     step = DataParallelStep(diffusion, model, opt, shard_optimizer=sharded, force_exchange=args.rehearse_dp)
 
     def sync():

@@ -9,8 +9,9 @@ branch), the dense layers, the fused loss epilogue, the weight / input gradient 
 branch writes straight into its column range of one [B, h1 + h2] buffer, and the gradient of that buffer is read back
 by column range.
 
-fp32 only (no bf16 shadows), single process (no gradient sink); constructor, parameter names and initialisation draw
-order are the reference's, so checkpoints interchange.
+fp32 only (no bf16 shadows).  Data parallel: the engine hands every gradient to `DataParallelStep`'s sink as soon as its
+kernels are enqueued (overlapped all-reduce, or the sharded optimiser with its all-gathers waited for at the end of the
+step).  Constructor, parameter names and initialisation draw order are the reference's, so checkpoints interchange.
 """
 import numpy as np
 import torch
@@ -44,7 +45,7 @@ class _OneHotTrainLoss(torch.autograd.Function):
 
 
 class OneHotEngine:
-    supports_grad_sink = False  # data parallel: gradients are all-reduced after the backward (parallel.allreduce_grads)
+    supports_grad_sink = True  # parallel.DataParallelStep may install `grad_sink` (overlapped gradient exchange)
     fused_opt = None
 
     def __init__(self, model):
@@ -57,6 +58,9 @@ class OneHotEngine:
         self.offset = 0
         self._bufs = {}
         self._saved = None
+        # data parallel: called as grad_sink(param, grad) the moment a gradient's kernels are enqueued (see
+        # engine.DenoiserEngine.grad_sink); the backward then returns None for that parameter
+        self.grad_sink = None
 
     def manual_seed(self, seed):
         self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
@@ -275,6 +279,10 @@ class OneHotEngine:
                 A_ptr, lda = bufs.hs.data_ptr(), bufs.hs.stride(0)
             _lib.check(lib.gdmcf_linear_bwd_weight_f32(dz_ptr, lddz, A_ptr, lda, _lib.ptr(rs), B, N, K, dW.data_ptr(),
                                                        dW.stride(0), db.data_ptr(), 0, st))
+            if self.grad_sink is not None:
+                self.grad_sink(w, dW)
+                self.grad_sink(bias, db)
+                return None, None
             return dW, db
 
         def input_grad(w, dz_ptr, lddz, rs, A_ptr, lda, act_prev, d_ptr, ldd):
@@ -318,7 +326,12 @@ class OneHotEngine:
         g1, dWe1, dbe1 = branch(br1, bufs.acts1, bufs.dz1, bufs.xin1, bufs.ld1, self.I, bufs.dhcat.data_ptr())
         g2, dWe2, dbe2 = branch(br2, bufs.acts2, bufs.dz2, bufs.xin2, bufs.ld2, 2 * self.I,
                                 bufs.dhcat.data_ptr() + 4 * bufs.h1)
-        res = [dWe1 + dWe2, dbe1 + dbe2]
+        dWe, dbe = dWe1 + dWe2, dbe1 + dbe2
+        if self.grad_sink is not None:
+            self.grad_sink(m.emb_layer.weight, dWe)
+            self.grad_sink(m.emb_layer.bias, dbe)
+            dWe = dbe = None
+        res = [dWe, dbe]
         for g in g1 + g2 + g_out:
             res += [g[0], g[1]]
         return res

@@ -338,7 +338,7 @@ class DataParallelStep:
             self._side_busy = False
         self.optimizer.step()
         for param, h in getattr(self, "_gathers", []):  # updated row blocks of the other ranks
-            if self.defer_gather and eng is not None:
+            if self.defer_gather and eng is not None and hasattr(eng, "weight_waiters"):
                 # still on the wire: the engine waits right before the first GEMM of the next forward that reads it
                 eng.weight_waiters[id(param)] = functools.partial(self._arrived, param, h)
             else:
