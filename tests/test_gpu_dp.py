@@ -351,7 +351,7 @@ def _onehot_worker(rank, port, out_dir):
 
 
 def test_onehot_backbone_two_ranks_equal_one_process(tmp_path):
-    """The one-hot backbone has no gradient sink: DataParallelStep all-reduces its gradients after the backward.  Two
+    """The one-hot backbone under DataParallelStep (gradients handed to the sink as their kernels are enqueued): two
     ranks on half batches reproduce one process on the global batch (sampled classes injected -- the reference's noise
     level a = ts / batch_size would otherwise depend on the LOCAL batch size)."""
     with socket.socket() as s:
