@@ -401,6 +401,70 @@ class DNNOneHot(nn.Module):
         return h
 
 
+def nt_xent_loss(z1, z2, temperature=0.1, eps=1e-5):  # reference DNN.py:479-508 (returns its `loss2`)
+    n = z1.size(0)
+    sim = torch.softmax(torch.mm(z1, z2.t()) / temperature, dim=-1)
+    mask = torch.eye(n, device=z1.device).bool()
+    negatives = sim.masked_select(~mask).view(n, -1)
+    return -torch.log((torch.diag(sim) + eps) / negatives.sum(dim=1)).mean()
+
+
+class DNNOneHotEmbedding(DNNOneHot):
+    """`indexIn` backbone of the one-hot variant (reference models/DNN.py:510-682): the two hidden activations and the
+    user's embedding row are concatenated and scored against every item embedding by cosine similarity (:655, :667-682);
+    `out_layers` exist (and are initialised, :582-592) but are never applied.  With RCloss the NT-Xent term between the
+    two hidden activations is returned as well (:641-643)."""
+
+    def __init__(self, in_dims, out_dims, emb_size, time_type="cat", norm=False, dropout=0.5, item_num=2810, user_num=5949):
+        nn.Module.__init__(self)
+        self.in_dims = in_dims
+        self.in_dims2 = list(in_dims)
+        self.in_dims2[0] *= 2
+        self.out_dims = out_dims
+        assert out_dims[0] == in_dims[-1], "In and out dimensions must equal to each other."
+        if time_type != "cat":
+            raise ValueError("Unimplemented timestep embedding type %s" % time_type)
+        self.time_type, self.time_emb_dim, self.norm, self.p = time_type, emb_size, norm, dropout
+        self.emb_layer = nn.Linear(emb_size, emb_size)
+        ind = [in_dims[0] + emb_size] + list(in_dims[1:])
+        ind2 = [self.in_dims2[0] + emb_size] + list(self.in_dims2[1:])
+        out_dims[0] += self.in_dims2[-1]
+        self.in_layers = nn.ModuleList([nn.Linear(a, b) for a, b in zip(ind[:-1], ind[1:])])
+        self.in_layers2 = nn.ModuleList([nn.Linear(a, b) for a, b in zip(ind2[:-1], ind2[1:])])
+        self.out_layers = nn.ModuleList([nn.Linear(a, b) for a, b in zip(out_dims[:-1], out_dims[1:])])
+        self.drop = nn.Dropout(dropout)
+        eu = ind[-1]
+        self.embedding_item = nn.Embedding(item_num, ind[-1] + eu + ind2[-1])  # :548-551
+        self.embedding_user = nn.Embedding(user_num, eu)
+        self.init_weights()
+        nn.init.xavier_uniform_(self.embedding_item.weight)  # :599-600, after the layers' draws
+        nn.init.xavier_uniform_(self.embedding_user.weight)
+
+    def forward(self, x, timesteps, x_U, index=None, graph=None, RCloss=False, drop_mask=None, drop_mask_U=None):
+        x_U = x_U.reshape(x_U.shape[0], -1)
+        emb = self.emb_layer(timestep_embedding(timesteps, self.time_emb_dim).to(x.device))
+        if self.norm:
+            x = torch.nn.functional.normalize(x)
+            x_U = torch.nn.functional.normalize(x_U)
+        if drop_mask is not None:
+            x = x * (drop_mask.to(x.dtype) / (1.0 - self.p))
+            x_U = x_U * (drop_mask_U.reshape(x_U.shape).to(x.dtype) / (1.0 - self.p))
+        else:
+            x = self.drop(x)
+            x_U = self.drop(x_U)
+        h = torch.cat([x, emb], dim=-1)
+        for layer in self.in_layers:
+            h = torch.tanh(layer(h))
+        h_U = torch.cat([x_U, emb], dim=-1)
+        for layer in self.in_layers2:
+            h_U = torch.tanh(layer(h_U))
+        closs = nt_xent_loss(h, h_U) if RCloss else None
+        items = self.embedding_item.weight
+        u = torch.cat([h, h_U, self.embedding_user(index)], dim=1)
+        out = torch.mm(u, items.t()) / (torch.norm(u, dim=1, keepdim=True) * torch.norm(items, dim=1).t())
+        return (out, closs) if RCloss else out
+
+
 class GaussianDiffusionDiscrete(GaussianDiffusion):
     """CatOneHot path of the reference's GaussianDiffusionDiscrete (gaussian_diffusion.py:552-1135), indexIn False:
     the rows are additionally handed to the model as one-hot pairs whose bits survive only where a draw from
@@ -412,6 +476,7 @@ class GaussianDiffusionDiscrete(GaussianDiffusion):
         super().__init__(mean_type, noise_schedule, noise_scale, noise_min, noise_max, steps, history_num_per_term,
                          beta_fixed)
         self.discrete, self.CatOneHot, self.user_guided = discrete, CatOneHot, user_guided
+        self.indexIn = False  # main.py:241 sets it for the embedding backbones
         self.u_x = torch.tensor([[discrete, 1 - discrete], [discrete, 1 - discrete]]).unsqueeze(0)
         self.u_x_eye = torch.eye(2).unsqueeze(0)
 
@@ -429,7 +494,7 @@ class GaussianDiffusionDiscrete(GaussianDiffusion):
         return torch.nn.functional.one_hot(sampled.long(), num_classes=2), probX
 
     def training_losses(self, model, x_start, reweight=False, ts=None, pt=None, noise=None, drop_mask=None,
-                        capture=None, ts_U=None, sampled=None, drop_mask_U=None):  # reference :834-957
+                        capture=None, ts_U=None, sampled=None, drop_mask_U=None, index=None):  # reference :834-957
         if not self.CatOneHot:
             return super().training_losses(model, x_start, reweight, ts, pt, noise, drop_mask, capture)
         B = x_start.size(0)
@@ -443,7 +508,12 @@ class GaussianDiffusionDiscrete(GaussianDiffusion):
         if noise is None:
             noise = torch.randn_like(x_start)
         x_t = self.q_sample(x_start, ts, noise) if self.noise_scale != 0.0 else x_start
-        out = model(x_t, ts, x_tU, drop_mask, drop_mask_U) if drop_mask is not None else model(x_t, ts, x_tU)
+        closs = None
+        if self.indexIn:  # :886-889: NT-Xent term of the backbone, added to every row's loss at the very end (:952-953)
+            kw = dict(drop_mask=drop_mask, drop_mask_U=drop_mask_U) if drop_mask is not None else {}
+            out, closs = model(x_t, ts, x_tU, index=index, graph=x_tU.long(), RCloss=True, **kw)
+        else:
+            out = model(x_t, ts, x_tU, drop_mask, drop_mask_U) if drop_mask is not None else model(x_t, ts, x_tU)
         target = {ModelMeanType.START_X: x_start, ModelMeanType.EPSILON: noise}[self.mean_type]
         assert out.shape == target.shape == x_start.shape
         mse = mean_flat((target - out) ** 2)
@@ -462,12 +532,14 @@ class GaussianDiffusionDiscrete(GaussianDiffusion):
         terms = {"loss": weight * loss}
         self.update_history(ts, terms["loss"])
         terms["loss"] = terms["loss"] / pt
+        if closs is not None:
+            terms["loss"] = terms["loss"] + closs * 0.1
         if capture is not None:
-            capture.update(ts=ts, pt=pt, noise=noise, x_t=x_t, x_tU=x_tU, model_output=out, mse=mse, weight=weight)
+            capture.update(ts=ts, pt=pt, noise=noise, x_t=x_t, x_tU=x_tU, model_output=out, mse=mse, weight=weight, closs=closs)
         return terms
 
     def p_sample(self, model, x_start, steps, sampling_noise=False, noise0=None, step_noise=None, capture=None,
-                 sampled0=None):  # reference :668-768
+                 sampled0=None, index=None):  # reference :668-768
         if not self.CatOneHot:
             return super().p_sample(model, x_start, steps, sampling_noise, noise0, step_noise, capture)
         assert steps <= self.steps, "Too much steps in inference."
@@ -486,6 +558,7 @@ class GaussianDiffusionDiscrete(GaussianDiffusion):
             for i in indices:
                 x_t = model(x_t, torch.tensor([i] * B), x_tU)
             return x_t
+        graph = None
         zero = torch.nn.functional.one_hot(torch.zeros_like(x_start.long()), num_classes=2)
         for n, i in enumerate(indices):
             t = torch.tensor([i] * B)
@@ -498,8 +571,8 @@ class GaussianDiffusionDiscrete(GaussianDiffusion):
                 pick = torch.cat([1 - deg, deg], dim=1).multinomial(1).repeat_interleave(x_start.shape[1], dim=1)
                 if self.user_guided:
                     g_i = g_i & torch.nn.functional.one_hot(pick, num_classes=2)
-                zero = torch.nn.functional.one_hot(g_i.argmax(dim=2) | zero.argmax(dim=2), num_classes=2)
-            out = self._p_mean_variance_onehot(model, x_t, t, x_tU)
+                zero = graph = torch.nn.functional.one_hot(g_i.argmax(dim=2) | zero.argmax(dim=2), num_classes=2)
+            out = self._p_mean_variance_onehot(model, x_t, t, x_tU, index, graph)
             if capture is not None:
                 capture.setdefault("pred_xstart", []).append(out["pred_xstart"])
                 capture.setdefault("mean", []).append(out["mean"])
@@ -511,9 +584,9 @@ class GaussianDiffusionDiscrete(GaussianDiffusion):
                 x_t = out["mean"]
         return x_t
 
-    def _p_mean_variance_onehot(self, model, x, t, x_tU):  # reference :1063-1103, CatOneHot and not indexIn
+    def _p_mean_variance_onehot(self, model, x, t, x_tU, index=None, graph=None):  # reference :1063-1103, CatOneHot
         assert t.shape == (x.shape[0],)
-        out = model(x, t, x_tU)
+        out = model(x, t, x_tU, index=index, graph=graph) if self.indexIn else model(x, t, x_tU)
         if self.mean_type == ModelMeanType.START_X:
             pred = out
         elif self.mean_type == ModelMeanType.EPSILON:

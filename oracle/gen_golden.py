@@ -48,6 +48,7 @@ RefDNN, ref_timestep_embedding = _extract(f"{REF}/models/DNN.py", ["DNN", "times
 import copy  # noqa: E402
 _ns["copy"] = copy
 (RefDNNOneHot,) = _extract(f"{REF}/models/DNN.py", ["DNNOneHot"], _ns)
+RefDNNOneHotEmbedding, _ref_nt_xent = _extract(f"{REF}/models/DNN.py", ["DNNOneHotEmbedding", "nt_xent_loss"], _ns)
 (ref_topn,) = _extract(f"{REF}/evaluate_utils.py", ["computeTopNAccuracy"], dict(math=math, np=np, torch=torch))
 
 
@@ -461,11 +462,131 @@ def gen_data_load():
     print("data_load:", nu, ni, t.max())
 
 
+class _IndexT:  # training_losses / p_sample call index.cuda() (:888, :744); the model then does index.to(x.device)
+    def __init__(self, t):
+        self.t = t
+
+    def cuda(self):
+        return self.t
+
+
+def gen_train_onehot_emb(name, B, I, U, dims, T, mean_type, schedule="linear-var", scale=0.01, nmin=0.001, nmax=0.01, n_steps=2,
+                         lr=1e-3, wd=0.0, seed=0, density=0.1):
+    """indexIn backbone DNNOneHotEmbedding (main.py:239-242) under GaussianDiffusionDiscrete(CatOneHot=True)."""
+    import contextlib
+    import io
+    torch.manual_seed(seed)
+    g = torch.Generator().manual_seed(seed + 100)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = RefDNNOneHotEmbedding([I] + dims, dims[::-1] + [I], 10, time_type="cat", norm=False, item_num=I, user_num=U)
+        mt = {"x0": gd.ModelMeanType.START_X, "eps": gd.ModelMeanType.EPSILON}[mean_type]
+        diff = gd.GaussianDiffusionDiscrete(mt, schedule, scale, nmin, nmax, T, "cpu", discrete=0.99, CatOneHot=True,
+                                            args=_Args())
+    diff.indexIn = True
+    opt = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=wd)
+    out = dict(sd_np(model))
+    out["meta"] = np.array([f"{B}|{I}|{','.join(map(str, dims))}|{T}|{mean_type}|{schedule}|{scale}|{nmin}|{nmax}|"
+                            f"{n_steps}|{lr}|{wd}|10|0|0.99|{U}"])
+    cap = {"st": [], "drops": []}
+    orig_st, orig_q, orig_sd = diff.sample_timesteps, diff.q_sample, diff.sample_discrete_features
+
+    def st(*a, **k):
+        cap["depth"] = cap.get("depth", 0) + 1
+        t, pt = orig_st(*a, **k)
+        cap["depth"] -= 1
+        if cap["depth"] == 0:
+            cap["st"].append((t.clone(), pt.clone()))
+        return t, pt
+
+    def q(x, t, noise=None):
+        cap["noise"] = noise.clone()
+        r = orig_q(x, t, noise)
+        cap["x_t"] = r.clone()
+        return r
+
+    def sd(probX):
+        r = orig_sd(probX)
+        cap["sampled"] = r.clone()
+        return r
+
+    diff.sample_timesteps, diff.q_sample, diff.sample_discrete_features = st, q, sd
+    model.drop.register_forward_hook(lambda m, i, o: cap["drops"].append((i[0].clone(), o.clone())))
+    model.register_forward_hook(lambda m, i, o: cap.update(model_output=o[0].clone(), closs=o[1].clone()))
+    model.train()
+    for s in range(n_steps):
+        x = make_rows(B, I, density, g)
+        index = torch.randperm(U, generator=g)[:B]
+        cap["st"].clear()
+        cap["drops"].clear()
+        opt.zero_grad()
+        terms = diff.training_losses(model, x, True, index=_IndexT(index))
+        loss = terms["loss"].mean()
+        loss.backward()
+        assert len(cap["st"]) == 2 and len(cap["drops"]) == 2
+        (din, dout), (din_u, dout_u) = cap["drops"]
+        mask, mask_u = (dout != 0), (dout_u != 0)
+        p = f"s{s}."
+        out[p + "x_start"] = npy(x).astype(np.uint8)
+        out[p + "index"] = npy(index)
+        out[p + "ts_U"] = npy(cap["st"][0][0])
+        out[p + "ts"], out[p + "pt"] = npy(cap["st"][1][0]), npy(cap["st"][1][1])
+        out[p + "sampled"] = npy(cap["sampled"]).astype(np.uint8)
+        out[p + "noise"] = npy(cap["noise"])
+        out[p + "drop_mask"] = npy(mask).astype(np.uint8)
+        out[p + "drop_mask_U"] = npy(mask_u).astype(np.uint8)
+        out[p + "x_t"] = npy(cap["x_t"])
+        out[p + "model_output"] = npy(cap["model_output"])
+        out[p + "closs"] = npy(cap["closs"])
+        out[p + "loss_vec"] = npy(terms["loss"])
+        out[p + "loss"] = npy(loss)
+        if s == 0:
+            for k, v in model.named_parameters():
+                if v.grad is not None:  # out_layers take no part in this backbone's forward
+                    out["g0." + k] = npy(v.grad)
+        opt.step()
+        out[p + "Lt_history"], out[p + "Lt_count"] = npy(diff.Lt_history), npy(diff.Lt_count)
+    for k, v in model.named_parameters():
+        out["pN." + k] = npy(v)
+        if v in opt.state and "exp_avg" in opt.state[v]:
+            out["m." + k], out["v." + k] = npy(opt.state[v]["exp_avg"]), npy(opt.state[v]["exp_avg_sq"])
+    # evaluation path on the trained weights: steps = 0 and steps = T with injected noise / classes
+    diff.q_sample = orig_q
+    model.eval()
+    x = make_rows(B, I, density, g)
+    index = torch.randperm(U, generator=g)[:B]
+    cap2 = {"noises": [], "sampled": []}
+    orig_randn = gd.th.randn_like
+
+    def rl(t):
+        n = orig_randn(t)
+        cap2["noises"].append(n.clone())
+        return n
+
+    def sd2(probX):
+        r = orig_sd(probX)
+        cap2["sampled"].append(r.clone())
+        return r
+
+    gd.th.randn_like, diff.sample_discrete_features = rl, sd2
+    with torch.no_grad():
+        out["e.x_start"], out["e.index"] = npy(x).astype(np.uint8), npy(index)
+        out["e.pred_steps0"] = npy(diff.p_sample(model, x, 0, False, index=_IndexT(index)))
+        cap2["noises"].clear()
+        cap2["sampled"].clear()
+        out["e.pred_stepsT"] = npy(diff.p_sample(model, x, T, False, index=_IndexT(index)))
+        out["e.noise_stepsT"], out["e.sampled_stepsT"] = npy(cap2["noises"][0]), npy(cap2["sampled"][0]).astype(np.uint8)
+    gd.th.randn_like = orig_randn
+    np.savez_compressed(os.path.join(OUT, f"onehot_emb_{name}.npz"), **out)
+    print(f"onehot_emb_{name}: loss0={float(out['s0.loss']):.6g} closs0={float(out['s0.closs']):.4g}")
+
+
 def gen_onehot():
     gen_train_onehot("tiny_x0", 8, 64, [16], 5, "x0", seed=31)
     gen_train_onehot("ragged_eps_wd", 12, 131, [24], 5, "eps", seed=32, density=0.05, wd=0.01, schedule="linear", scale=0.1)
     gen_train_onehot("deep_x0", 10, 90, [32, 16], 5, "x0", seed=33, density=0.06)
     gen_train_onehot("norm_eps", 9, 77, [20], 6, "eps", seed=34, density=0.08, norm=True, schedule="cosine", scale=0.05)
+    gen_train_onehot_emb("tiny_x0", 8, 64, 40, [16], 5, "x0", seed=51)
+    gen_train_onehot_emb("ragged_eps_wd", 12, 131, 90, [24], 5, "eps", seed=52, density=0.05, wd=0.01, schedule="linear", scale=0.1)
     gen_sample_onehot("tiny_x0", 8, 64, [16], 5, "x0", seed=41)
     gen_sample_onehot("ragged_eps", 10, 131, [24], 5, "eps", seed=42, scale=50.0)
 

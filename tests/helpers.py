@@ -12,6 +12,7 @@ TRAIN_CASES = ["tiny_x0", "tiny_eps", "ragged_x0", "ragged_eps_wd", "imp_T40", "
 SAMPLE_CASES = ["tiny_x0", "ragged_x0", "ragged_eps", "norm_x0"]
 ONEHOT_TRAIN_CASES = ["tiny_x0", "ragged_eps_wd", "deep_x0", "norm_eps"]
 ONEHOT_SAMPLE_CASES = ["tiny_x0", "ragged_eps"]
+ONEHOT_EMB_CASES = ["tiny_x0", "ragged_eps_wd"]
 
 
 def load(name):
@@ -76,6 +77,24 @@ def oracle_onehot_pair(meta, fx):
     mt = {"x0": O.ModelMeanType.START_X, "eps": O.ModelMeanType.EPSILON}[meta["mean_type"]]
     d = O.GaussianDiffusionDiscrete(mt, meta.get("schedule", "linear-var"), meta["scale"], meta["nmin"], meta["nmax"],
                                     meta["T"], discrete=meta["discrete"], CatOneHot=True)
+    return m, d
+
+
+def onehot_emb_meta(fx):
+    f = str(fx["meta"][0]).split("|")
+    meta = train_meta({"meta": np.array(["|".join(f[:14])])})
+    meta["discrete"], meta["U"] = float(f[14]), int(f[15])
+    return meta
+
+
+def oracle_onehot_emb_pair(meta, fx):
+    I, dims = meta["I"], meta["dims"]
+    m = O.DNNOneHotEmbedding([I] + dims, dims[::-1] + [I], 10, item_num=I, user_num=meta["U"])
+    m.load_state_dict(state_dict_from(fx))
+    mt = {"x0": O.ModelMeanType.START_X, "eps": O.ModelMeanType.EPSILON}[meta["mean_type"]]
+    d = O.GaussianDiffusionDiscrete(mt, meta["schedule"], meta["scale"], meta["nmin"], meta["nmax"], meta["T"],
+                                    discrete=meta["discrete"], CatOneHot=True)
+    d.indexIn = True
     return m, d
 
 

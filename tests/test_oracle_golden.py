@@ -212,3 +212,44 @@ def test_onehot_rng_call_order_matches_reference():
     x = torch.from_numpy(fx["s0.x_start"].astype(np.float32))
     terms = diff.training_losses(model, x, True)
     np.testing.assert_array_equal(terms["loss"].detach().numpy(), fx["s0.loss_vec"])
+
+
+@pytest.mark.parametrize("case", H.ONEHOT_EMB_CASES)
+def test_onehot_embedding_backbone_matches_reference(case):
+    """indexIn backbone DNNOneHotEmbedding (user / item embedding tables, cosine scores, NT-Xent term x 0.1) under
+    GaussianDiffusionDiscrete(CatOneHot=True): training steps and p_sample bit-identical to the reference."""
+    fx = H.load("onehot_emb_" + case)
+    meta = H.onehot_emb_meta(fx)
+    model, diff = H.oracle_onehot_emb_pair(meta, fx)
+    opt = O.make_optimizer(model, meta["lr"], meta["wd"])
+    model.train()
+    for s in range(meta["n_steps"]):
+        inp = H.onehot_step_inputs(fx, s)
+        cap = {}
+        opt.zero_grad()
+        terms = diff.training_losses(model, inp["x"], True, ts=inp["ts"], pt=inp["pt"], noise=inp["noise"],
+                                     drop_mask=inp["drop_mask"], capture=cap, ts_U=inp["ts_U"], sampled=inp["sampled"],
+                                     drop_mask_U=inp["drop_mask_U"], index=torch.from_numpy(fx[f"s{s}.index"]))
+        loss = terms["loss"].mean()
+        loss.backward()
+        np.testing.assert_array_equal(cap["model_output"].detach().numpy(), fx[f"s{s}.model_output"])
+        np.testing.assert_array_equal(cap["closs"].detach().numpy(), fx[f"s{s}.closs"])
+        np.testing.assert_array_equal(terms["loss"].detach().numpy(), fx[f"s{s}.loss_vec"])
+        if s == 0:
+            for k, v in model.named_parameters():
+                if v.grad is None:
+                    assert k.startswith("out_layers") and "g0." + k not in fx
+                else:
+                    np.testing.assert_array_equal(v.grad.numpy(), fx["g0." + k], err_msg=k)
+        opt.step()
+        np.testing.assert_array_equal(diff.Lt_history.numpy(), fx[f"s{s}.Lt_history"])
+    for k, v in model.named_parameters():
+        np.testing.assert_array_equal(v.detach().numpy(), fx["pN." + k], err_msg=k)
+    model.eval()
+    x, idx = torch.from_numpy(fx["e.x_start"].astype(np.float32)), torch.from_numpy(fx["e.index"])
+    with torch.no_grad():
+        np.testing.assert_array_equal(diff.p_sample(model, x, 0, False, sampled0=torch.zeros(1), index=idx).numpy(),
+                                      fx["e.pred_steps0"])
+        got = diff.p_sample(model, x, meta["T"], False, noise0=torch.from_numpy(fx["e.noise_stepsT"]),
+                            sampled0=torch.from_numpy(fx["e.sampled_stepsT"].astype(np.int64)), index=idx)
+        np.testing.assert_array_equal(got.numpy(), fx["e.pred_stepsT"])
