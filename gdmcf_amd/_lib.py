@@ -56,6 +56,11 @@ _SIGNATURES = {
     "gdmcf_lt_history_update": (c_int, [P, P, c_int, c_int, c_int, P, P, P]),
     "gdmcf_onehot_noise_f32": (c_int, [P, c_int64, P, c_int, c_int, c_float, P, c_int64, c_uint64, c_uint64, P, c_int64, P,
                                      c_int64, P]),
+    "gdmcf_row_norms_f32": (c_int, [P, c_int64, c_int, c_int, P, P, P]),
+    "gdmcf_normalize_rows_bwd_f32": (c_int, [P, c_int64, P, c_int64, P, c_int, c_int, P, c_int64, P]),
+    "gdmcf_tanh_bwd_f32": (c_int, [P, c_int64, P, c_int64, P, c_int64, P, c_int, c_int, P, c_int64, P]),
+    "gdmcf_gather_rows_f32": (c_int, [P, c_int64, P, c_int, c_int, P, c_int64, P]),
+    "gdmcf_scatter_add_rows_f32": (c_int, [P, c_int64, P, c_int, c_int, P, c_int64, P]),
     "gdmcf_dp_pack_f64": (c_int, [P, P, c_int, P, P, c_int, c_int, c_int, P, P]),
     "gdmcf_dp_unpack_f64": (c_int, [P, P, P, c_int, c_int, c_int, P, P, P]),
     "gdmcf_sample_timesteps": (c_int, [P, P, c_int, c_int, c_int, c_double, c_uint64, c_uint64, P, P, P, P]),

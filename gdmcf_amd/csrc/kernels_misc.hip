@@ -273,6 +273,77 @@ __global__ __launch_bounds__(256) void onehot_noise_kernel(const float* __restri
             if (i0 + j < I) sampled_out[(int64_t)b * ldso + i0 + j] = (uint8_t)((so >> (8 * j)) & 1);
 }
 
+// ---------------------------------------------------------------------------------------------
+// pieces of the indexIn backbone (reference models/DNN.py:510-682): embedding-row gather / scatter, row norms and
+// the backward of x / |x| for the cosine scores, tanh' on a gradient with an extra addend.  All HBM-bound, one
+// workgroup per row (16-byte accesses along the row), reductions in a fixed order (deterministic).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void row_norms_kernel(const float* __restrict__ X, int64_t ld, int cols,
+                                                       float* __restrict__ norm, float* __restrict__ inv_norm) {
+    __shared__ float red[4];
+    const float* x = X + (int64_t)blockIdx.x * ld;
+    float ss = 0.f;
+    for (int c = threadIdx.x; c < cols; c += 256) ss += x[c] * x[c];
+    const float n = sqrtf(block_sum_256(ss, red));
+    if (threadIdx.x == 0) {
+        if (norm) norm[blockIdx.x] = n;
+        if (inv_norm) inv_norm[blockIdx.x] = 1.f / n;
+    }
+}
+
+// dX = (dY - Y * <dY, Y>) * inv_norm  for Y = X / |X| (row-wise); dX may alias dY
+__global__ __launch_bounds__(256) void normalize_rows_bwd_kernel(const float* __restrict__ dY, int64_t lddy,
+                                                                const float* __restrict__ Y, int64_t ldy,
+                                                                const float* __restrict__ inv_norm, int cols,
+                                                                float* __restrict__ dX, int64_t lddx) {
+    __shared__ float red[4];
+    const float* dy = dY + (int64_t)blockIdx.x * lddy;
+    const float* y = Y + (int64_t)blockIdx.x * ldy;
+    float dot = 0.f;
+    for (int c = threadIdx.x; c < cols; c += 256) dot += dy[c] * y[c];
+    dot = block_sum_256(dot, red);
+    const float rn = inv_norm[blockIdx.x];
+    float* dx = dX + (int64_t)blockIdx.x * lddx;
+    for (int c = threadIdx.x; c < cols; c += 256) dx[c] = (dy[c] - y[c] * dot) * rn;
+}
+
+__global__ __launch_bounds__(256) void tanh_bwd_kernel(const float* __restrict__ dA, int64_t ldd, const float* __restrict__ A,
+                                                      int64_t lda, const float* __restrict__ extra, int64_t lde,
+                                                      const float* __restrict__ scale, int N, float* __restrict__ out,
+                                                      int64_t ldo) {
+    const int m = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float g = dA[(int64_t)m * ldd + n];
+    if (extra) g += scale[0] * extra[(int64_t)m * lde + n];
+    const float a = A[(int64_t)m * lda + n];
+    out[(int64_t)m * ldo + n] = g * (1.f - a * a);
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, int64_t lds,
+                                                         const int64_t* __restrict__ index, int cols,
+                                                         float* __restrict__ dst, int64_t ldd) {
+    const float* s = src + index[blockIdx.x] * lds;
+    float* d = dst + (int64_t)blockIdx.x * ldd;
+    for (int c = threadIdx.x; c < cols; c += 256) d[c] = s[c];
+}
+
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __restrict__ src, int64_t lds,
+                                                              const int64_t* __restrict__ index, int cols,
+                                                              float* __restrict__ dst, int64_t ldd) {
+    const float* s = src + (int64_t)blockIdx.x * lds;
+    float* d = dst + index[blockIdx.x] * ldd;
+    for (int c = threadIdx.x; c < cols; c += 256) atomicAdd(d + c, s[c]);  // (rows of one batch are distinct users)
+}
+
 __global__ void emb_cols_kernel(const int64_t* __restrict__ ts, const float* __restrict__ emb_w,
                                 const float* __restrict__ emb_b, int E, int I, float* __restrict__ xin, int64_t ldxin,
                                 float* __restrict__ temb_out, unsigned short* __restrict__ xin16, int64_t ldxin16) {
@@ -759,6 +830,47 @@ int gdmcf_onehot_noise_f32(const float* x0, int64_t ldx, const int64_t* ts, int 
                            I, p1_off, sampled, lds, seed, offset, xU, ldu, sampled_out, ldso);
     }
     return gd_launch_status("onehot_noise");
+}
+
+int gdmcf_row_norms_f32(const float* X, int64_t ld, int rows, int cols, float* norm, float* inv_norm, void* stream) {
+    GD_CHECK_SHAPE(rows > 0 && cols > 0 && ld >= cols, "row_norms: bad shape");
+    GD_CHECK_ARG(X && (norm || inv_norm), "row_norms: null pointer");
+    hipLaunchKernelGGL(row_norms_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, X, ld, cols, norm, inv_norm);
+    return gd_launch_status("row_norms");
+}
+
+int gdmcf_normalize_rows_bwd_f32(const float* dY, int64_t lddy, const float* Y, int64_t ldy, const float* inv_norm, int rows,
+                                 int cols, float* dX, int64_t lddx, void* stream) {
+    GD_CHECK_SHAPE(rows > 0 && cols > 0 && lddy >= cols && ldy >= cols && lddx >= cols, "normalize_rows_bwd: bad shape");
+    GD_CHECK_ARG(dY && Y && inv_norm && dX, "normalize_rows_bwd: null pointer");
+    hipLaunchKernelGGL(normalize_rows_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, dY, lddy, Y, ldy, inv_norm,
+                       cols, dX, lddx);
+    return gd_launch_status("normalize_rows_bwd");
+}
+
+int gdmcf_tanh_bwd_f32(const float* dA, int64_t ldd, const float* A, int64_t lda, const float* extra, int64_t lde,
+                       const float* scale, int M, int N, float* out, int64_t ldo, void* stream) {
+    GD_CHECK_SHAPE(M > 0 && N > 0 && ldd >= N && lda >= N && ldo >= N && (!extra || lde >= N), "tanh_bwd: bad shape");
+    GD_CHECK_ARG(dA && A && out && (!extra || scale), "tanh_bwd: null pointer");
+    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(gd_cdiv(N, 256), M), dim3(256), 0, (hipStream_t)stream, dA, ldd, A, lda, extra, lde,
+                       scale, N, out, ldo);
+    return gd_launch_status("tanh_bwd");
+}
+
+int gdmcf_gather_rows_f32(const float* src, int64_t lds, const int64_t* index, int n, int cols, float* dst, int64_t ldd,
+                          void* stream) {
+    GD_CHECK_SHAPE(n > 0 && cols > 0 && lds >= cols && ldd >= cols, "gather_rows: bad shape");
+    GD_CHECK_ARG(src && index && dst, "gather_rows: null pointer");
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, src, lds, index, cols, dst, ldd);
+    return gd_launch_status("gather_rows");
+}
+
+int gdmcf_scatter_add_rows_f32(const float* src, int64_t lds, const int64_t* index, int n, int cols, float* dst, int64_t ldd,
+                               void* stream) {
+    GD_CHECK_SHAPE(n > 0 && cols > 0 && lds >= cols && ldd >= cols, "scatter_add_rows: bad shape");
+    GD_CHECK_ARG(src && index && dst, "scatter_add_rows: null pointer");
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, src, lds, index, cols, dst, ldd);
+    return gd_launch_status("scatter_add_rows");
 }
 
 int gdmcf_rowscale_f32(const float* A, int64_t lda, const float* rowscale, int M, int K, float* out, int64_t ldo,

@@ -204,13 +204,11 @@ class OneHotEngine:
         finally:
             self.lib.gdmcf_gemm_precision(prev)
 
-    def _train_forward(self, spec):
+    def _train_inputs(self, spec, bufs):
+        """Both branch inputs (xin1: noised rows, xin2: one-hot image; dropout, normalize, embedding columns) and the
+        loss target.  Returns (x0, target, alpha, rowdiv, keepalive)."""
         x0, ts = spec["x_start"], spec["ts"]
         B, dev = x0.shape[0], x0.device
-        br1, br2, out = self._chains()
-        bufs = self.buffers(B, dev)
-        lib, st = self.lib, _lib.stream_ptr()
-        self.version += 1
         if x0.dtype != torch.float32 or x0.stride(-1) != 1:
             x0 = x0.float().contiguous()
         eps_mode = spec["eps_mode"]
@@ -232,22 +230,34 @@ class OneHotEngine:
             rowdiv = torch.where(is0, 2.0 * self.I, 1.0 * self.I).float().contiguous()
         else:
             target, rowdiv = x0, bufs.rowdiv_mse
-        A, lda = self._hidden(bufs, br1, br2, out, B)
-        w, bias, _ = out[-1]
-        N, K = w.shape
-        _lib.check(lib.gdmcf_linear_loss_fwd_f32(A.data_ptr(), lda, w.data_ptr(), w.stride(0), bias.data_ptr(),
-                                                 target.data_ptr(), target.stride(0), _lib.ptr(alpha), B, N, K, None, 0,
-                                                 bufs.diff.data_ptr(), bufs.ldi, bufs.rowpart.data_ptr(),
-                                                 bufs.rowsum.data_ptr(), st))
-        loss = torch.empty(B, dtype=torch.float64, device=dev)
-        pt = spec["pt"]
+        return x0, target, alpha, rowdiv, (s8, noise, keep1, keep2)
+
+    def _loss_layer(self, spec, bufs, B, A_ptr, lda, W_ptr, ldw, bias_ptr, N, K, target, alpha, rowdiv):
+        """Last product fused with the per-row loss, then the float64 loss tail (weights, history FIFO, 1/pt)."""
+        lib, st = self.lib, _lib.stream_ptr()
+        ts, pt = spec["ts"], spec["pt"]
+        _lib.check(lib.gdmcf_linear_loss_fwd_f32(A_ptr, lda, W_ptr, ldw, bias_ptr, target.data_ptr(), target.stride(0),
+                                                 _lib.ptr(alpha), B, N, K, None, 0, bufs.diff.data_ptr(), bufs.ldi,
+                                                 bufs.rowpart.data_ptr(), bufs.rowsum.data_ptr(), st))
+        loss = torch.empty(B, dtype=torch.float64, device=ts.device)
         _lib.check(lib.gdmcf_row_loss_finish_f64(bufs.rowsum.data_ptr(), rowdiv.data_ptr(), _lib.ptr(alpha), ts.data_ptr(),
                                                  spec["weight_t"].data_ptr(), pt.data_ptr(), B, spec["T"], spec["H"],
                                                  spec["Lt_history"].data_ptr(), spec["Lt_count"].data_ptr(),
                                                  int(spec["update_history"]), bufs.lu.data_ptr(), loss.data_ptr(),
                                                  bufs.gradcoef.data_ptr(), st))
-        self._saved = dict(B=B, bufs=bufs, chains=(br1, br2, out), keepalive=(x0, s8, noise, keep1, keep2, target, alpha,
-                                                                              rowdiv, pt))
+        return loss
+
+    def _train_forward(self, spec):
+        B, dev = spec["x_start"].shape[0], spec["x_start"].device
+        br1, br2, out = self._chains()
+        bufs = self.buffers(B, dev)
+        self.version += 1
+        x0, target, alpha, rowdiv, keep = self._train_inputs(spec, bufs)
+        A, lda = self._hidden(bufs, br1, br2, out, B)
+        w, bias, _ = out[-1]
+        loss = self._loss_layer(spec, bufs, B, A.data_ptr(), lda, w.data_ptr(), w.stride(0), bias.data_ptr(), w.shape[0],
+                                w.shape[1], target, alpha, rowdiv)
+        self._saved = dict(B=B, bufs=bufs, chains=(br1, br2, out), keepalive=(x0, keep, target, alpha, rowdiv, spec["pt"]))
         return loss
 
     def train_backward(self, gloss):
@@ -257,82 +267,97 @@ class OneHotEngine:
         finally:
             self.lib.gdmcf_gemm_precision(prev)
 
-    def _train_backward(self, gloss):
-        """Gradients in model.parameters() order: emb_layer (w, b), in_layers..., in_layers2..., out_layers..."""
-        sv = self._saved
-        if sv is None:
-            raise RuntimeError("gdmcf_amd: train_backward without a preceding training_losses")
-        lib, st = self.lib, _lib.stream_ptr()
-        bufs, B = sv["bufs"], sv["B"]
-        br1, br2, out = sv["chains"]
-        m = self.model
+    # -- backward building blocks -------------------------------------------------------------------------------------
+    def _rowscale_of(self, bufs, gloss):
         if isinstance(gloss, float):  # mean reduction: the same upstream gradient 1/B on every row
-            rowscale = bufs.gradcoef * gloss
-        else:
-            rowscale = (gloss.to(torch.float32) * bufs.gradcoef).contiguous()
+            return bufs.gradcoef * gloss
+        return (gloss.to(torch.float32) * bufs.gradcoef).contiguous()
 
-        def weight_grad(w, bias, dz_ptr, lddz, rs, A_ptr, lda):
+    def _weight_grad(self, bufs, B, w, bias, dz_ptr, lddz, rs, A_ptr, lda):
+        """(dW, db) of one layer -- or (None, None) once handed to the data-parallel gradient sink."""
+        lib, st = self.lib, _lib.stream_ptr()
+        N, K = w.shape
+        dW = torch.empty_like(w)
+        db = torch.empty_like(bias) if bias is not None else None
+        if rs is not None:  # (rs . dZ)^T A == dZ^T (rs . A): scale the small activation instead of the big dZ
+            _lib.check(lib.gdmcf_rowscale_f32(A_ptr, lda, rs.data_ptr(), B, K, bufs.hs.data_ptr(), bufs.hs.stride(0), st))
+            A_ptr, lda = bufs.hs.data_ptr(), bufs.hs.stride(0)
+        _lib.check(lib.gdmcf_linear_bwd_weight_f32(dz_ptr, lddz, A_ptr, lda, _lib.ptr(rs), B, N, K, dW.data_ptr(),
+                                                   dW.stride(0), _lib.ptr(db), 0, st))
+        if self.grad_sink is not None and bias is not None:
+            self.grad_sink(w, dW)
+            self.grad_sink(bias, db)
+            return None, None
+        return dW, db
+
+    def _input_grad(self, bufs, B, W_ptr, ldw, N, K, dz_ptr, lddz, rs, A_ptr, lda, act_prev, d_ptr, ldd):
+        _lib.check(self.lib.gdmcf_linear_bwd_input_f32(dz_ptr, lddz, W_ptr, ldw, _lib.ptr(rs), A_ptr, lda, act_prev, B, N, K,
+                                                       d_ptr, ldd, bufs.ws.data_ptr(), bufs.ws_bytes, _lib.stream_ptr()))
+
+    def _branch_backward(self, bufs, B, chain, acts, dzs, xin, ldx, I_cols, dz_ptr, lddz):
+        """One input branch from d(pre-activation of its last layer): hidden layers, then the timestep-embedding columns
+        of its first layer.  Returns ([(dW, db)...], dWe, dbe)."""
+        m = self.model
+        grads = [None] * len(chain)
+        dWe = dbe = None
+        for li in range(len(chain) - 1, -1, -1):
+            w, bias, _ = chain[li]
             N, K = w.shape
-            dW, db = torch.empty_like(w), torch.empty_like(bias)
-            if rs is not None:  # (rs . dZ)^T A == dZ^T (rs . A): scale the small activation instead of the big dZ
-                _lib.check(lib.gdmcf_rowscale_f32(A_ptr, lda, rs.data_ptr(), B, K, bufs.hs.data_ptr(), bufs.hs.stride(0), st))
-                A_ptr, lda = bufs.hs.data_ptr(), bufs.hs.stride(0)
-            _lib.check(lib.gdmcf_linear_bwd_weight_f32(dz_ptr, lddz, A_ptr, lda, _lib.ptr(rs), B, N, K, dW.data_ptr(),
-                                                       dW.stride(0), db.data_ptr(), 0, st))
-            if self.grad_sink is not None:
-                self.grad_sink(w, dW)
-                self.grad_sink(bias, db)
-                return None, None
-            return dW, db
-
-        def input_grad(w, dz_ptr, lddz, rs, A_ptr, lda, act_prev, d_ptr, ldd):
-            N, K = w.shape
-            _lib.check(lib.gdmcf_linear_bwd_input_f32(dz_ptr, lddz, w.data_ptr(), w.stride(0), _lib.ptr(rs), A_ptr, lda,
-                                                      act_prev, B, N, K, d_ptr, ldd, bufs.ws.data_ptr(), bufs.ws_bytes, st))
-
-        # ---- out layers: from the loss layer down to the concatenated hidden activation
-        g_out = [None] * len(out)
-        dz_ptr, lddz, rs = bufs.diff.data_ptr(), bufs.ldi, rowscale
-        for li in range(len(out) - 1, -1, -1):
-            w, bias, _ = out[li]
             if li > 0:
-                A_prev, act_prev, dprev = bufs.acts_out[li - 1], out[li - 1][2], bufs.dz_out[li - 1]
+                A_prev = acts[li - 1]
+                grads[li] = self._weight_grad(bufs, B, w, bias, dz_ptr, lddz, None, A_prev.data_ptr(), A_prev.stride(0))
+                self._input_grad(bufs, B, w.data_ptr(), w.stride(0), N, K, dz_ptr, lddz, None, A_prev.data_ptr(),
+                                 A_prev.stride(0), chain[li - 1][2], dzs[li - 1].data_ptr(), dzs[li - 1].stride(0))
+                dz_ptr, lddz = dzs[li - 1].data_ptr(), dzs[li - 1].stride(0)
             else:
-                A_prev, act_prev, dprev = bufs.hcat, 1, bufs.dhcat  # both branches end in tanh
-            g_out[li] = weight_grad(w, bias, dz_ptr, lddz, rs, A_prev.data_ptr(), A_prev.stride(0))
-            input_grad(w, dz_ptr, lddz, rs, A_prev.data_ptr(), A_prev.stride(0), act_prev, dprev.data_ptr(), dprev.stride(0))
-            dz_ptr, lddz, rs = dprev.data_ptr(), dprev.stride(0), None
+                grads[li] = self._weight_grad(bufs, B, w, bias, dz_ptr, lddz, None, xin.data_ptr(), ldx)
+                dWe, dbe = torch.empty_like(m.emb_layer.weight), torch.empty_like(m.emb_layer.bias)
+                _lib.check(self.lib.gdmcf_emb_bwd_f32(dz_ptr, lddz, w.data_ptr(), w.stride(0), I_cols, self.E,
+                                                      bufs.temb.data_ptr(), B, N, bufs.demb.data_ptr(), dWe.data_ptr(),
+                                                      dbe.data_ptr(), _lib.stream_ptr()))
+        return grads, dWe, dbe
 
-        # ---- one input branch: hidden layers, then the timestep-embedding columns of its first layer
-        def branch(chain, acts, dzs, xin, ldx, I_cols, dz_ptr):
-            grads = [None] * len(chain)
-            lddz = bufs.dhcat.stride(0)
-            for li in range(len(chain) - 1, -1, -1):
-                w, bias, _ = chain[li]
-                if li > 0:
-                    A_prev = acts[li - 1]
-                    grads[li] = weight_grad(w, bias, dz_ptr, lddz, None, A_prev.data_ptr(), A_prev.stride(0))
-                    input_grad(w, dz_ptr, lddz, None, A_prev.data_ptr(), A_prev.stride(0), chain[li - 1][2],
-                               dzs[li - 1].data_ptr(), dzs[li - 1].stride(0))
-                    dz_ptr, lddz = dzs[li - 1].data_ptr(), dzs[li - 1].stride(0)
-                else:
-                    grads[li] = weight_grad(w, bias, dz_ptr, lddz, None, xin.data_ptr(), ldx)
-                    dWe, dbe = torch.empty_like(m.emb_layer.weight), torch.empty_like(m.emb_layer.bias)
-                    _lib.check(lib.gdmcf_emb_bwd_f32(dz_ptr, lddz, w.data_ptr(), w.stride(0), I_cols, self.E,
-                                                     bufs.temb.data_ptr(), B, w.shape[0], bufs.demb.data_ptr(),
-                                                     dWe.data_ptr(), dbe.data_ptr(), st))
-            return grads, dWe, dbe
-
-        g1, dWe1, dbe1 = branch(br1, bufs.acts1, bufs.dz1, bufs.xin1, bufs.ld1, self.I, bufs.dhcat.data_ptr())
-        g2, dWe2, dbe2 = branch(br2, bufs.acts2, bufs.dz2, bufs.xin2, bufs.ld2, 2 * self.I,
-                                bufs.dhcat.data_ptr() + 4 * bufs.h1)
+    def _branches_backward(self, bufs, B, br1, br2):
+        """Both branches from bufs.dhcat (gradient of the pre-activations behind hcat[:, :h1+h2]); emb_layer's two
+        gradients are added.  Returns the list [dWe, dbe, in_layers..., in_layers2...]."""
+        m = self.model
+        lddz = bufs.dhcat.stride(0)
+        g1, dWe1, dbe1 = self._branch_backward(bufs, B, br1, bufs.acts1, bufs.dz1, bufs.xin1, bufs.ld1, self.I,
+                                               bufs.dhcat.data_ptr(), lddz)
+        g2, dWe2, dbe2 = self._branch_backward(bufs, B, br2, bufs.acts2, bufs.dz2, bufs.xin2, bufs.ld2, 2 * self.I,
+                                               bufs.dhcat.data_ptr() + 4 * bufs.h1, lddz)
         dWe, dbe = dWe1 + dWe2, dbe1 + dbe2
         if self.grad_sink is not None:
             self.grad_sink(m.emb_layer.weight, dWe)
             self.grad_sink(m.emb_layer.bias, dbe)
             dWe = dbe = None
         res = [dWe, dbe]
-        for g in g1 + g2 + g_out:
+        for g in g1 + g2:
+            res += [g[0], g[1]]
+        return res
+
+    def _train_backward(self, gloss):
+        """Gradients in model.parameters() order: emb_layer (w, b), in_layers..., in_layers2..., out_layers..."""
+        sv = self._saved
+        if sv is None:
+            raise RuntimeError("gdmcf_amd: train_backward without a preceding training_losses")
+        bufs, B = sv["bufs"], sv["B"]
+        br1, br2, out = sv["chains"]
+        # ---- out layers: from the loss layer down to the concatenated hidden activation
+        g_out = [None] * len(out)
+        dz_ptr, lddz, rs = bufs.diff.data_ptr(), bufs.ldi, self._rowscale_of(bufs, gloss)
+        for li in range(len(out) - 1, -1, -1):
+            w, bias, _ = out[li]
+            if li > 0:
+                A_prev, act_prev, dprev = bufs.acts_out[li - 1], out[li - 1][2], bufs.dz_out[li - 1]
+            else:
+                A_prev, act_prev, dprev = bufs.hcat, 1, bufs.dhcat  # both branches end in tanh
+            g_out[li] = self._weight_grad(bufs, B, w, bias, dz_ptr, lddz, rs, A_prev.data_ptr(), A_prev.stride(0))
+            self._input_grad(bufs, B, w.data_ptr(), w.stride(0), w.shape[0], w.shape[1], dz_ptr, lddz, rs, A_prev.data_ptr(),
+                             A_prev.stride(0), act_prev, dprev.data_ptr(), dprev.stride(0))
+            dz_ptr, lddz, rs = dprev.data_ptr(), dprev.stride(0), None
+        res = self._branches_backward(bufs, B, br1, br2)
+        for g in g_out:
             res += [g[0], g[1]]
         return res
 

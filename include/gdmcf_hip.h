@@ -193,6 +193,29 @@ int gdmcf_linear_bwd_weight_adamw_f32(const float* dZ, int64_t lddz, const float
                                       float grad_scale, void* stream);
 int gdmcf_rowscale_f32(const float* A, int64_t lda, const float* rowscale, int M, int K, float* out,
                        int64_t ldo, void* stream);
+/* ---- pieces of the indexIn backbone DNNOneHotEmbedding (models/DNN.py:510-682) ----------------
+ * Its output layer is a cosine similarity (:655, :667-682): scores = (u @ V^T) / (|u| |v|^T) with u = [h, h_U,
+ * embedding_user(index)] and V = embedding_item.weight.  The products run on gdmcf_linear_* with the row-normalised
+ * operands (gdmcf_rowscale_f32 by the inverse norms); these entries are the HBM-bound glue around them:
+ *   row_norms:          norm[r] = |X[r,:]|, inv_norm[r] = 1/|X[r,:]|                     (torch.norm(dim=1), :675-676)
+ *   normalize_rows_bwd: dX = (dY - Y * <dY, Y>) * inv_norm for Y = X/|X| (backward of the division; dX may alias dY)
+ *   tanh_bwd:           out = (dA + scale[0] * extra) * (1 - A^2)   (tanh' of the two hidden activations whose
+ *                       gradient also receives the NT-Xent term's, DNN.py:641-643; extra NULL -> no addend;
+ *                       scale is a device scalar)
+ *   gather_rows:        dst[j,:] = src[index[j],:]                                        (nn.Embedding lookup, :650)
+ *   scatter_add_rows:   dst[index[j],:] += src[j,:]                                       (its backward)            */
+int gdmcf_row_norms_f32(const float* X, int64_t ld, int rows, int cols, float* norm, float* inv_norm,
+                        void* stream);
+int gdmcf_normalize_rows_bwd_f32(const float* dY, int64_t lddy, const float* Y, int64_t ldy,
+                                 const float* inv_norm, int rows, int cols, float* dX, int64_t lddx,
+                                 void* stream);
+int gdmcf_tanh_bwd_f32(const float* dA, int64_t ldd, const float* A, int64_t lda, const float* extra,
+                       int64_t lde, const float* scale, int M, int N, float* out, int64_t ldo,
+                       void* stream);
+int gdmcf_gather_rows_f32(const float* src, int64_t lds, const int64_t* index, int n, int cols, float* dst,
+                          int64_t ldd, void* stream);
+int gdmcf_scatter_add_rows_f32(const float* src, int64_t lds, const int64_t* index, int n, int cols,
+                               float* dst, int64_t ldd, void* stream);
 /* Gradients of the timestep-embedding branch (models/DNN.py:73-74,78):
  *   demb[m,e] = sum_n dZ1[m,n]*W1[n, I+e] ;  dWe = demb^T @ temb ;  dbe = sum_m demb
  * demb_ws: float32 scratch of (M + N) * E elements.                                         */
