@@ -7,7 +7,8 @@ from .optim import FusedAdamW  # noqa: F401
 from .evaluate_utils import computeTopNAccuracy, computeTopNAccuracy_device, masked_topk, print_results  # noqa: F401
 from .lightgcn import LightGCN  # noqa: F401
 from .onehot import DNNOneHot  # noqa: F401
+from .onehot_embedding import DNNOneHotEmbedding  # noqa: F401
 from . import checkpoint, data_utils, driver, parallel  # noqa: F401
 
 __all__ = ["DNN", "timestep_embedding", "GaussianDiffusion", "GaussianDiffusionDiscrete", "ModelMeanType", "FusedAdamW", "computeTopNAccuracy",
-           "computeTopNAccuracy_device", "masked_topk", "print_results", "LightGCN", "DNNOneHot"]
+           "computeTopNAccuracy_device", "masked_topk", "print_results", "LightGCN", "DNNOneHot", "DNNOneHotEmbedding"]

@@ -283,7 +283,9 @@ class GaussianDiffusionDiscrete(GaussianDiffusion):
     `CatOneHot=True` with a `gdmcf_amd.DNNOneHot` denoiser (`indexIn` False; SURVEY 8 f1, first slice): the rows are
     handed to the model a second time as one-hot pairs under the discrete transition noise of :770-831
     (`gdmcf_onehot_noise_f32`).  As in the reference, that noise uses its OWN timestep draw (:843) -- the model is
-    conditioned on the second one (:865).  The embedding/GCN backbones (`indexIn` True) are not built."""
+    conditioned on the second one (:865).  `indexIn = True` (set by main.py:241) selects the embedding backbone
+    `gdmcf_amd.DNNOneHotEmbedding`, which needs the users' ids (`index=`) and adds 0.1 x its NT-Xent term to every row's
+    loss (:886-889, :952-953); the GCN backbones are not built."""
 
     _onehot_ok = True
 
@@ -323,10 +325,14 @@ class GaussianDiffusionDiscrete(GaussianDiffusion):
 
     def _onehot_model(self, model):
         from .onehot import DNNOneHot
-        if not isinstance(model, DNNOneHot):
-            raise TypeError("gdmcf_amd.GaussianDiffusionDiscrete(CatOneHot=True) needs a gdmcf_amd.DNNOneHot denoiser")
-        if self.indexIn:
-            raise NotImplementedError("indexIn (user/item embedding and GCN backbones) is not built (SURVEY 8 f1)")
+        from .onehot_embedding import DNNOneHotEmbedding
+        if self.indexIn:  # main.py:239-242 sets it together with the embedding backbones
+            if not isinstance(model, DNNOneHotEmbedding):
+                raise NotImplementedError("indexIn is built for gdmcf_amd.DNNOneHotEmbedding only; the GCN backbones "
+                                          "(DNNOneHotEmbeddingGCN*) are not (SURVEY 8 f1: un-vendored torch_geometric)")
+        elif not isinstance(model, DNNOneHot) or isinstance(model, DNNOneHotEmbedding):
+            raise TypeError("gdmcf_amd.GaussianDiffusionDiscrete(CatOneHot=True) needs a gdmcf_amd.DNNOneHot denoiser "
+                            "(DNNOneHotEmbedding with indexIn = True)")
         return model
 
     def training_losses(self, model, x_start, reweight=False, index=None, *, ts=None, pt=None, noise=None,
@@ -363,7 +369,7 @@ class GaussianDiffusionDiscrete(GaussianDiffusion):
         spec = dict(x_start=x_start, ts=ts, pt=pt, ca=ca, cb=cb, noise=noise, drop_mask=drop_mask, eps_mode=eps_mode,
                     weight_t=weight_t, T=self.steps, H=self.history_num_per_term, Lt_history=self.Lt_history,
                     Lt_count=self.Lt_count, update_history=self.update_history, t0_likelihood=(reweight == True),  # noqa: E712
-                    ts_U=ts_U, sampled=sampled, drop_mask_U=drop_mask_U, discrete=self.discrete)
+                    ts_U=ts_U, sampled=sampled, drop_mask_U=drop_mask_U, discrete=self.discrete, index=index)
         if eps_mode:
             spec["r1_0"] = self._t32["r1"][0]
             spec["r2_0"] = self._t32["r2"][0]
@@ -393,10 +399,11 @@ class GaussianDiffusionDiscrete(GaussianDiffusion):
                 x_t = self.q_sample(x0, t, noise0) if self.noise_scale != 0.0 else x0
             for n, i in enumerate(list(range(self.steps))[::-1]):
                 t = torch.full((B,), i, dtype=torch.int64, device=dev)
+                kw = dict(index=index) if self.indexIn else {}
                 if self.noise_scale == 0.0:
-                    x_t = model(x_t, t, x_tU)
+                    x_t = model(x_t, t, x_tU, **kw)
                     continue
-                out = model(x_t, t, x_tU)
+                out = model(x_t, t, x_tU, **kw)
                 pred = out if self.mean_type == ModelMeanType.START_X else self._predict_xstart_from_eps(x_t, t, eps=out)
                 mean, _, logvar = self.q_posterior_mean_variance(x_start=pred, x_t=x_t, t=t)
                 if capture is not None:

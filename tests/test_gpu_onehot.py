@@ -204,3 +204,95 @@ def test_apply_noise_and_qt_bar_by_name():
             p, n = float(Q[b, c, 1]), int(sel.sum())
             assert abs(float(s[b][sel].float().mean()) - p) < 4 * np.sqrt(p * (1 - p) / n) + 1e-6, (b, c)
     assert not torch.equal(out, d.apply_noise(cu(ts), cu(torch.nn.functional.one_hot(x, 2).float())))  # a new draw per call
+
+
+# ---- indexIn backbone DNNOneHotEmbedding ---------------------------------------------------------------------------
+def gpu_emb_pair(meta, fx):
+    I, dims = meta["I"], meta["dims"]
+    m = gdmcf_amd.DNNOneHotEmbedding([I] + dims, dims[::-1] + [I], 10, item_num=I, user_num=meta["U"])
+    m.load_state_dict(H.state_dict_from(fx))
+    mt = {"x0": ModelMeanType.START_X, "eps": ModelMeanType.EPSILON}[meta["mean_type"]]
+    d = gdmcf_amd.GaussianDiffusionDiscrete(mt, meta["schedule"], meta["scale"], meta["nmin"], meta["nmax"], meta["T"], DEV,
+                                            discrete=meta["discrete"], CatOneHot=True)
+    d.indexIn = True  # main.py:241
+    return m.to(DEV), d
+
+
+@pytest.mark.parametrize("case", H.ONEHOT_EMB_CASES)
+def test_onehot_embedding_backbone_matches_reference(case):
+    """DNNOneHotEmbedding (cosine scores against the item table, user rows, NT-Xent term x 0.1) under
+    GaussianDiffusionDiscrete(CatOneHot=True, indexIn): training steps with the reference's randomness injected, then
+    p_sample on the trained weights, against the reference's own numbers."""
+    fx = H.load("onehot_emb_" + case)
+    meta = H.onehot_emb_meta(fx)
+    model, diff = gpu_emb_pair(meta, fx)
+    opt = gdmcf_amd.FusedAdamW(model.parameters(), lr=meta["lr"], weight_decay=meta["wd"])
+    model.train()
+    for s in range(meta["n_steps"]):
+        inp = H.onehot_step_inputs(fx, s)
+        opt.zero_grad()
+        terms = diff.training_losses(model, cu(inp["x"]), True, index=torch.from_numpy(fx[f"s{s}.index"]), ts=cu(inp["ts"]),
+                                     pt=cu(inp["pt"]), noise=cu(inp["noise"]), drop_mask=cu(inp["drop_mask"]),
+                                     ts_U=cu(inp["ts_U"]), sampled=cu(inp["sampled"]), drop_mask_U=cu(inp["drop_mask_U"]))
+        loss = terms["loss"].mean()
+        loss.backward()
+        assert abs(float(model.engine.last_closs) - float(fx[f"s{s}.closs"])) <= 2e-5 * abs(float(fx[f"s{s}.closs"]))
+        np.testing.assert_allclose(terms["loss"].detach().cpu().numpy(), fx[f"s{s}.loss_vec"], rtol=1e-4, atol=0)
+        assert abs(float(loss.detach()) - float(fx[f"s{s}.loss"])) <= 1e-4 * abs(float(fx[f"s{s}.loss"]))
+        if s == 0:
+            for k, v in model.named_parameters():
+                if k.startswith("out_layers"):
+                    assert v.grad is None  # never applied by this backbone (reference: no gradient either)
+                else:
+                    assert H.relerr(v.grad.cpu().numpy(), fx["g0." + k]) < 3e-4, k
+        opt.step()
+        np.testing.assert_array_equal(diff.Lt_count.cpu().numpy(), fx[f"s{s}.Lt_count"])
+        np.testing.assert_allclose(diff.Lt_history.cpu().numpy(), fx[f"s{s}.Lt_history"], rtol=1e-4, atol=0)
+    for k, v in model.named_parameters():
+        d = np.abs(v.detach().cpu().numpy() - fx["pN." + k]).max()
+        assert d < 0.02 * meta["lr"] * meta["n_steps"], (k, d)
+    model.eval()
+    x, idx = cu(torch.from_numpy(fx["e.x_start"].astype(np.float32))), torch.from_numpy(fx["e.index"])
+    p0 = diff.p_sample(model, x, 0, False, index=idx)
+    # (weights after two AdamW steps differ by ~1e-5 relative from the reference's: compare on that scale)
+    assert H.relerr(p0.cpu().numpy(), fx["e.pred_steps0"]) < 2e-4
+    pT = diff.p_sample(model, x, meta["T"], False, index=idx, noise0=cu(torch.from_numpy(fx["e.noise_stepsT"])),
+                       sampled0=cu(torch.from_numpy(fx["e.sampled_stepsT"])))
+    assert H.relerr(pT.cpu().numpy(), fx["e.pred_stepsT"]) < 2e-4
+    with pytest.raises(RuntimeError):  # the embedding backbone cannot run without the users' ids
+        diff.p_sample(model, x, 0, False)
+
+
+def test_onehot_embedding_full_width_step_matches_oracle():
+    """Yelp-width item table (I = 34 395, three 1000-wide blocks) and 54 574 users at a small batch: one training step
+    against the CPU oracle on the same injected randomness."""
+    torch.manual_seed(3)
+    I, hid, B, T, U = 34395, 1000, 32, 5, 54574
+    om = O.DNNOneHotEmbedding([I, hid], [hid, I], 10, item_num=I, user_num=U)
+    gm = gdmcf_amd.DNNOneHotEmbedding([I, hid], [hid, I], 10, item_num=I, user_num=U)
+    gm.load_state_dict(om.state_dict())
+    gm = gm.to(DEV).train()
+    om.train()
+    od = O.GaussianDiffusionDiscrete(O.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, T, CatOneHot=True)
+    gd_ = gdmcf_amd.GaussianDiffusionDiscrete(ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, T, DEV, CatOneHot=True)
+    od.indexIn = gd_.indexIn = True
+    g = torch.Generator().manual_seed(6)
+    x = (torch.rand(B, I, generator=g) < 0.001).float()
+    ts, ts_U = torch.randint(0, T, (B,), generator=g), torch.randint(0, T, (B,), generator=g)
+    sampled = (torch.rand(B, I, generator=g) < 0.02).long()
+    noise = torch.randn(B, I, generator=g)
+    keep, keep_U = (torch.rand(B, I, generator=g) < 0.5).float(), (torch.rand(B, 2 * I, generator=g) < 0.5).float()
+    index = torch.randperm(U, generator=g)[:B]
+    pt = torch.ones(B, dtype=torch.float64)
+    ot = od.training_losses(om, x, True, ts=ts, pt=pt, noise=noise, drop_mask=keep, ts_U=ts_U, sampled=sampled,
+                            drop_mask_U=keep_U, index=index)
+    ot["loss"].mean().backward()
+    gt = gd_.training_losses(gm, cu(x), True, index=index, ts=cu(ts), pt=cu(pt), noise=cu(noise), drop_mask=cu(keep),
+                             ts_U=cu(ts_U), sampled=cu(sampled), drop_mask_U=cu(keep_U))
+    gt["loss"].mean().backward()
+    np.testing.assert_allclose(gt["loss"].detach().cpu().numpy(), ot["loss"].detach().numpy(), rtol=1e-4, atol=0)
+    for (k, a), (_, b) in zip(gm.named_parameters(), om.named_parameters()):
+        if b.grad is None:
+            assert a.grad is None, k
+        else:
+            assert H.relerr(a.grad.cpu().numpy(), b.grad.numpy()) < 5e-4, k
