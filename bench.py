@@ -86,9 +86,9 @@ def parse():
                     help="single GPU: update the two large weights inside the weight-gradient GEMM epilogue "
                          "(FusedAdamW.fuse_into_backward); same update rule, gradient never materialised")
     ap.add_argument("--bpr", action="store_true", help="also time a LightGCN BPR training step (reported under 'bpr')")
-    ap.add_argument("--backbone", default="dnn", choices=["dnn", "onehot"],
+    ap.add_argument("--backbone", default="dnn", choices=["dnn", "onehot", "onehot-emb"],
                     help="dnn: the plain denoiser (BASELINE configs); onehot: GaussianDiffusionDiscrete(CatOneHot=True) + "
-                         "DNNOneHot (SURVEY 8 f1, first slice; fp32)")
+                         "DNNOneHot; onehot-emb: the indexIn backbone DNNOneHotEmbedding (SURVEY 8 f1; fp32)")
     ap.add_argument("--rehearse-dp", action="store_true",
                     help="N = 1 only: create a one-rank RCCL group and run every data-parallel collective through it "
                          "(rehearsal of the N > 1 code path on a single-GPU box)")
@@ -122,9 +122,15 @@ def cpu_baseline(args, I, x_batches, seconds):
     """The oracle's train step on the host cores, same shape / same rows (bounded sample)."""
     from oracle import gdmcf_oracle as O
     torch.manual_seed(0)
-    if args.backbone == "onehot":
-        om = O.DNNOneHot([I, args.hidden], [args.hidden, I], 10)
+    from gdmcf_amd import data as _data
+    n_users = _data.SHAPES[args.workload]["n_users"]
+    if args.backbone in ("onehot", "onehot-emb"):
+        if args.backbone == "onehot":
+            om = O.DNNOneHot([I, args.hidden], [args.hidden, I], 10)
+        else:
+            om = O.DNNOneHotEmbedding([I, args.hidden], [args.hidden, I], 10, item_num=I, user_num=n_users)
         od = O.GaussianDiffusionDiscrete(O.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, args.T, CatOneHot=True)
+        od.indexIn = args.backbone == "onehot-emb"
     else:
         om = O.DNN([I, args.hidden], [args.hidden, I], 10)
         od = O.GaussianDiffusion(O.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, args.T)
@@ -132,10 +138,11 @@ def cpu_baseline(args, I, x_batches, seconds):
     om.train()
     xs = [torch.from_numpy(b) for b in x_batches[:2]]
     Bc = xs[0].shape[0]
-    O.train_step(od, om, opt, xs[0], True)  # warm-up (allocations, thread pool)
+    extra = dict(index=torch.arange(Bc)) if args.backbone == "onehot-emb" else {}
+    O.train_step(od, om, opt, xs[0], True, **extra)  # warm-up (allocations, thread pool)
     n, t0 = 0, time.perf_counter()
     while True:
-        O.train_step(od, om, opt, xs[n % len(xs)], True)
+        O.train_step(od, om, opt, xs[n % len(xs)], True, **extra)
         n += 1
         el = time.perf_counter() - t0
         if (el >= seconds and n >= 3) or n >= 50:
@@ -188,12 +195,17 @@ def main():
     x_dev = torch.from_numpy(x_host[:1]).to(dev)
 
     torch.manual_seed(0)
-    if args.backbone == "onehot":
+    if args.backbone in ("onehot", "onehot-emb"):
         if args.gemm_dtype != "f32" or args.fuse_optimizer:
-            raise SystemExit("--backbone onehot: fp32 with a separate AdamW pass only")
-        model = gdmcf_amd.DNNOneHot([I, hid], [hid, I], 10, time_type="cat", norm=False).to(dev)
+            raise SystemExit("--backbone onehot / onehot-emb: fp32 with a separate AdamW pass only")
+        if args.backbone == "onehot":
+            model = gdmcf_amd.DNNOneHot([I, hid], [hid, I], 10, time_type="cat", norm=False).to(dev)
+        else:
+            model = gdmcf_amd.DNNOneHotEmbedding([I, hid], [hid, I], 10, time_type="cat", norm=False, item_num=I,
+                                                 user_num=data.SHAPES[args.workload]["n_users"]).to(dev)
         diffusion = gdmcf_amd.GaussianDiffusionDiscrete(gdmcf_amd.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, T,
                                                         dev, CatOneHot=True)
+        diffusion.indexIn = args.backbone == "onehot-emb"  # main.py:241
     else:
         model = gdmcf_amd.DNN([I, hid], [hid, I], 10, time_type="cat", norm=False, gemm_dtype=args.gemm_dtype).to(dev)
         diffusion = gdmcf_amd.GaussianDiffusion(gdmcf_amd.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, T, dev)
@@ -209,6 +221,8 @@ def main():
     autotune = (world > 1 or args.autotune_dp) and not (args.shard_optimizer or args.allreduce_optimizer)
     step = DataParallelStep(diffusion, model, opt, shard_optimizer=sharded, force_exchange=args.rehearse_dp)
 
+    step_kw = [dict(index=r + lo) if args.backbone == "onehot-emb" else {} for r in row_ids]  # the rows' user ids
+
     def sync():
         torch.cuda.synchronize()
         if dist.is_initialized():
@@ -217,7 +231,7 @@ def main():
 
     loss = None
     for i in range(args.warmup):
-        loss = step(dcsr.rows(row_ids[i % n_pool], out=x_buf), True)
+        loss = step(dcsr.rows(row_ids[i % n_pool], out=x_buf), True, **step_kw[i % n_pool])
     sync()
     dp_autotune = None
     if autotune and step.exchange:
@@ -226,11 +240,11 @@ def main():
         for name, flag in (("allreduce", False), ("sharded", True)):
             step.set_shard_optimizer(flag)
             for i in range(2):
-                step(dcsr.rows(row_ids[i % n_pool], out=x_buf), True)
+                step(dcsr.rows(row_ids[i % n_pool], out=x_buf), True, **step_kw[i % n_pool])
             sync()
             t1 = time.perf_counter()
             for i in range(6):
-                step(dcsr.rows(row_ids[i % n_pool], out=x_buf), True)
+                step(dcsr.rows(row_ids[i % n_pool], out=x_buf), True, **step_kw[i % n_pool])
             sync()
             tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -247,7 +261,7 @@ def main():
     for i in range(args.steps):
         if prof:
             lib.gdmcf_prof_enable(1 if i % every == 0 else 2)  # 2 = pause, records kept
-        loss = step(dcsr.rows(row_ids[i % n_pool], out=x_buf), True)
+        loss = step(dcsr.rows(row_ids[i % n_pool], out=x_buf), True, **step_kw[i % n_pool])
     host_el = time.perf_counter() - t0  # enqueue time only: well below `el` when the host runs ahead of the GPU
     sync()
     el = time.perf_counter() - t0
@@ -331,8 +345,10 @@ def main():
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": args.gemm_dtype, "data": "synthetic",
             "config": {"workload": f"{args.workload}-shape synthetic rows, batch={B}/GPU, dims=[{hid}], T={T}, "
                                    f"noise_scale=0.01, linear-var, mean_type=x0, reweight, AdamW lr=1e-5"
-                                   + (", backbone DNNOneHot under GaussianDiffusionDiscrete(CatOneHot) (SURVEY 8 f1a)"
-                                      if args.backbone == "onehot" else "")
+                                   + (", backbone DNNOneHot under GaussianDiffusionDiscrete(CatOneHot) (SURVEY 8 f1)"
+                                      if args.backbone == "onehot" else
+                                      ", backbone DNNOneHotEmbedding under GaussianDiffusionDiscrete(CatOneHot, indexIn) "
+                                      "(SURVEY 8 f1)" if args.backbone == "onehot-emb" else "")
                                    + (" (BASELINE configs[1])" if args.workload == "yelp" and T == 5 and hid == 1000
                                       and args.gemm_dtype == "f32" and args.backbone == "dnn" else "")
                                    + (" (BASELINE configs[2]: bf16 denoiser GEMM inputs, f32 accumulate/state)"

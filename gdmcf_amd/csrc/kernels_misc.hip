@@ -289,10 +289,16 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 
 __global__ __launch_bounds__(256) void row_norms_kernel(const float* __restrict__ X, int64_t ld, int cols,
                                                        float* __restrict__ norm, float* __restrict__ inv_norm) {
+    typedef f32x4 f32x4_u4 __attribute__((aligned(4)));
     __shared__ float red[4];
     const float* x = X + (int64_t)blockIdx.x * ld;
     float ss = 0.f;
-    for (int c = threadIdx.x; c < cols; c += 256) ss += x[c] * x[c];
+    const int c4 = cols & ~3;
+    for (int c = threadIdx.x * 4; c < c4; c += 1024) {
+        const f32x4 t = *reinterpret_cast<const f32x4_u4*>(x + c);
+        ss += t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w;
+    }
+    if (threadIdx.x < cols - c4) ss += x[c4 + threadIdx.x] * x[c4 + threadIdx.x];
     const float n = sqrtf(block_sum_256(ss, red));
     if (threadIdx.x == 0) {
         if (norm) norm[blockIdx.x] = n;
@@ -300,7 +306,8 @@ __global__ __launch_bounds__(256) void row_norms_kernel(const float* __restrict_
     }
 }
 
-// dX = (dY - Y * <dY, Y>) * inv_norm  for Y = X / |X| (row-wise); dX may alias dY
+// dX = (dY - Y * <dY, Y>) * inv_norm  for Y = X / |X| (row-wise); dX may alias dY.  Rows of up to 4096 columns stay in
+// registers between the dot product and the update (each operand is read once); longer rows are read twice.
 __global__ __launch_bounds__(256) void normalize_rows_bwd_kernel(const float* __restrict__ dY, int64_t lddy,
                                                                 const float* __restrict__ Y, int64_t ldy,
                                                                 const float* __restrict__ inv_norm, int cols,
@@ -308,11 +315,33 @@ __global__ __launch_bounds__(256) void normalize_rows_bwd_kernel(const float* __
     __shared__ float red[4];
     const float* dy = dY + (int64_t)blockIdx.x * lddy;
     const float* y = Y + (int64_t)blockIdx.x * ldy;
+    float* dx = dX + (int64_t)blockIdx.x * lddx;
+    const float rn = inv_norm[blockIdx.x];
+    if (cols <= 4096 && (cols & 3) == 0) {
+        typedef f32x4 f32x4_u4 __attribute__((aligned(4)));
+        f32x4 a[4], b[4];
+        float dot = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = (threadIdx.x + 256 * k) * 4;
+            a[k] = b[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (c < cols) {
+                a[k] = *reinterpret_cast<const f32x4_u4*>(dy + c);
+                b[k] = *reinterpret_cast<const f32x4_u4*>(y + c);
+            }
+            dot += a[k].x * b[k].x + a[k].y * b[k].y + a[k].z * b[k].z + a[k].w * b[k].w;
+        }
+        dot = block_sum_256(dot, red);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = (threadIdx.x + 256 * k) * 4;
+            if (c < cols) *reinterpret_cast<f32x4_u4*>(dx + c) = (a[k] - b[k] * dot) * rn;
+        }
+        return;
+    }
     float dot = 0.f;
     for (int c = threadIdx.x; c < cols; c += 256) dot += dy[c] * y[c];
     dot = block_sum_256(dot, red);
-    const float rn = inv_norm[blockIdx.x];
-    float* dx = dX + (int64_t)blockIdx.x * lddx;
     for (int c = threadIdx.x; c < cols; c += 256) dx[c] = (dy[c] - y[c] * dot) * rn;
 }
 
@@ -392,16 +421,29 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     if (out16) out16[(int64_t)m * ldo16 + n] = gd_bf16_bits(s);
 }
 
+// out[m, k] = A[m, k] * rs[m]; four columns per thread (16-byte accesses; rows need only 4-byte alignment on gfx950)
 __global__ __launch_bounds__(256) void rowscale_kernel(const float* __restrict__ A, int64_t lda,
                                                        const float* __restrict__ rs, int M, int K,
                                                        float* __restrict__ out, int64_t ldo,
                                                        unsigned short* __restrict__ out16, int64_t ldo16) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= (int64_t)M * K) return;
-    const int m = (int)(e / K), k = (int)(e % K);
-    const float v = A[(int64_t)m * lda + k] * rs[m];
-    out[(int64_t)m * ldo + k] = v;
-    if (out16) out16[(int64_t)m * ldo16 + k] = gd_bf16_bits(v);
+    typedef f32x4 f32x4_u4 __attribute__((aligned(4)));
+    const int m = blockIdx.y, k = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (k >= K) return;
+    const float r = rs[m];
+    const float* a = A + (int64_t)m * lda + k;
+    float* o = out + (int64_t)m * ldo + k;
+    float v[4];
+    if (k + 3 < K) {
+        const f32x4 t = *reinterpret_cast<const f32x4_u4*>(a);
+        v[0] = t.x * r; v[1] = t.y * r; v[2] = t.z * r; v[3] = t.w * r;
+        *reinterpret_cast<f32x4_u4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+    } else {
+        for (int j = 0; j < 4; ++j)
+            if (k + j < K) o[j] = v[j] = a[j] * r;
+    }
+    if (out16)
+        for (int j = 0; j < 4; ++j)
+            if (k + j < K) out16[(int64_t)m * ldo16 + k + j] = gd_bf16_bits(v[j]);
 }
 
 // db[n] = sum_m rs[m]*dZ[m,n].  One workgroup per 64 columns; wave w sums rows w, w+4, ... (each row read
@@ -879,7 +921,8 @@ int gdmcf_rowscale_f32(const float* A, int64_t lda, const float* rowscale, int M
     const int64_t n = (int64_t)M * K;
     GdShadow sh;
     const bool has16 = gd_shadow_lookup(out, &sh) && sh.rows == M && sh.cols == K;
-    hipLaunchKernelGGL(rowscale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, A, lda,
+    (void)n;
+    hipLaunchKernelGGL(rowscale_kernel, dim3(gd_cdiv(K, 1024), M), dim3(256), 0, (hipStream_t)stream, A, lda,
                        rowscale, M, K, out, ldo, has16 ? (unsigned short*)sh.p16 : nullptr, has16 ? sh.ld16 : 0);
     return gd_launch_status("rowscale");
 }
