@@ -34,8 +34,9 @@ def main():
     ap.add_argument("--T", type=int, default=5)
     ap.add_argument("--lr", type=float, default=1e-4)
     ap.add_argument("--bf16", action="store_true")
-    ap.add_argument("--backbone", default="dnn", choices=["dnn", "onehot"],
-                    help="onehot: GaussianDiffusionDiscrete(CatOneHot=True) + DNNOneHot (fp32)")
+    ap.add_argument("--backbone", default="dnn", choices=["dnn", "onehot", "onehot-emb"],
+                    help="onehot: GaussianDiffusionDiscrete(CatOneHot=True) + DNNOneHot; onehot-emb: + user / item embedding "
+                         "tables (DNNOneHotEmbedding, indexIn); both fp32")
     args = ap.parse_args()
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
     dev = torch.device(f"cuda:{local}")
@@ -57,10 +58,15 @@ def main():
     n_dp = (U // (world * args.batch)) * world * args.batch  # every rank must run the same number of steps
     my_train = train[:n_dp][rank::world] if world > 1 else train
     torch.manual_seed(0)
-    if args.backbone == "onehot":  # what main.py builds for CatOneHot with args.backbone == 'DNNOneHot' (:192-193, :216-217)
-        model = gdmcf_amd.DNNOneHot([I, args.hidden], [args.hidden, I], 10, time_type="cat", norm=False).to(dev)
+    if args.backbone != "dnn":  # what main.py builds for CatOneHot with args.backbone == 'DNNOneHot' / 'DNNOneHotEmbedding'
+        if args.backbone == "onehot":
+            model = gdmcf_amd.DNNOneHot([I, args.hidden], [args.hidden, I], 10, time_type="cat", norm=False).to(dev)
+        else:
+            model = gdmcf_amd.DNNOneHotEmbedding([I, args.hidden], [args.hidden, I], 10, time_type="cat", norm=False,
+                                                 item_num=I, user_num=U).to(dev)
         diffusion = gdmcf_amd.GaussianDiffusionDiscrete(gdmcf_amd.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01,
                                                         args.T, dev, CatOneHot=True)
+        diffusion.indexIn = args.backbone == "onehot-emb"  # main.py:241
     else:
         model = gdmcf_amd.DNN([I, args.hidden], [args.hidden, I], 10, time_type="cat", norm=False,
                               gemm_dtype="bf16" if args.bf16 else "f32").to(dev)

@@ -32,8 +32,9 @@ def train_one_epoch(diffusion, model, optimizer, train_csr, batch_size, device, 
                                generator=generator)
     step = step or DataParallelStep(diffusion, model, optimizer)
     total, count = None, 0
-    for batch, _index in loader:
-        loss = step(batch, reweight)
+    with_index = bool(getattr(diffusion, "indexIn", False))  # embedding backbones need the users' ids (main.py:346)
+    for batch, index in loader:
+        loss = step(batch, reweight, index=index) if with_index else step(batch, reweight)
         total = loss if total is None else total + loss
         count += 1
     return (float(total) if total is not None else 0.0), count
@@ -53,7 +54,8 @@ def evaluate(diffusion, model, data_csr, data_te, mask_his, topN, sampling_steps
     for lo in range(0, n, batch_size):
         rows = np.arange(lo, min(lo + batch_size, n))
         batch = dcsr.rows(torch.from_numpy(rows))
-        prediction = diffusion.p_sample(model, batch, sampling_steps, sampling_noise)
+        kw = dict(index=torch.from_numpy(rows)) if getattr(diffusion, "indexIn", False) else {}
+        prediction = diffusion.p_sample(model, batch, sampling_steps, sampling_noise, **kw)
         indptr, cols = evaluate_utils.csr_rows_to_device(mask_his, rows, device)
         predict_items.append(masked_topk(prediction, topN[-1], indptr, cols))
     # the ranked lists never leave the device; the metric terms per user are computed there too

@@ -282,3 +282,20 @@ def test_c_program_links_and_uses_the_abi(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, (r.stdout, r.stderr)
     assert "betas[1] = 2.2500225002275442e-05" in r.stdout and "rc -3" in r.stdout
+
+
+def test_onehot_embedding_backbone_surface_matches_reference_init_and_names():
+    """DNNOneHotEmbedding: the reference's state_dict names / shapes and initialisation draws (layers, then xavier-uniform
+    item and user tables), out_dims[0] grown like DNNOneHot's."""
+    fx = H.load("onehot_emb_ragged_eps_wd")
+    meta = H.onehot_emb_meta(fx)
+    torch.manual_seed(52)
+    I, dims = meta["I"], meta["dims"]
+    out_dims = dims[::-1] + [I]
+    m = gdmcf_amd.DNNOneHotEmbedding([I] + dims, out_dims, 10, item_num=I, user_num=meta["U"])
+    assert out_dims[0] == 2 * dims[-1]
+    sd, ref = m.state_dict(), H.state_dict_from(fx)
+    assert list(sd.keys()) == list(ref.keys())
+    for k in ref:
+        assert torch.equal(sd[k], ref[k]), k
+    assert m.embedding_item.weight.shape == (I, 3 * dims[-1]) and m.embedding_user.weight.shape == (meta["U"], dims[-1])
