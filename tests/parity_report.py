@@ -143,3 +143,35 @@ for case in H.ONEHOT_SAMPLE_CASES:
                        sampled0=cu(torch.from_numpy(fx["sampled_stepsT"])))
     print(f"{case:12s} p_sample rel err: steps=0 {H.relerr(p0.cpu().numpy(), fx['pred_steps0']):.2e}, "
           f"steps=T {H.relerr(pT.cpu().numpy(), fx['pred_stepsT']):.2e}")
+
+print("\n== indexIn backbone DNNOneHotEmbedding vs the reference (golden fixtures) ==")
+for case in H.ONEHOT_EMB_CASES:
+    fx = H.load("onehot_emb_" + case)
+    meta = H.onehot_emb_meta(fx)
+    I, dims = meta["I"], meta["dims"]
+    model = gdmcf_amd.DNNOneHotEmbedding([I] + dims, dims[::-1] + [I], 10, item_num=I, user_num=meta["U"])
+    model.load_state_dict(H.state_dict_from(fx))
+    model = model.to(DEV).train()
+    mt = {"x0": ModelMeanType.START_X, "eps": ModelMeanType.EPSILON}[meta["mean_type"]]
+    diff = gdmcf_amd.GaussianDiffusionDiscrete(mt, meta["schedule"], meta["scale"], meta["nmin"], meta["nmax"], meta["T"], DEV,
+                                               discrete=meta["discrete"], CatOneHot=True)
+    diff.indexIn = True
+    opt = gdmcf_amd.FusedAdamW(model.parameters(), lr=meta["lr"], weight_decay=meta["wd"])
+    e_loss = e_row = e_grad = e_closs = 0.0
+    for s in range(meta["n_steps"]):
+        inp = H.onehot_step_inputs(fx, s)
+        opt.zero_grad()
+        terms = diff.training_losses(model, cu(inp["x"]), True, index=torch.from_numpy(fx[f"s{s}.index"]), ts=cu(inp["ts"]),
+                                     pt=cu(inp["pt"]), noise=cu(inp["noise"]), drop_mask=cu(inp["drop_mask"]),
+                                     ts_U=cu(inp["ts_U"]), sampled=cu(inp["sampled"]), drop_mask_U=cu(inp["drop_mask_U"]))
+        loss = terms["loss"].mean()
+        loss.backward()
+        lv = terms["loss"].detach().cpu().numpy()
+        e_loss = max(e_loss, abs(float(loss.detach()) - float(fx[f"s{s}.loss"])) / abs(float(fx[f"s{s}.loss"])))
+        e_row = max(e_row, float(np.max(np.abs(lv - fx[f"s{s}.loss_vec"]) / np.abs(fx[f"s{s}.loss_vec"]))))
+        e_closs = max(e_closs, abs(float(model.engine.last_closs) - float(fx[f"s{s}.closs"])) / abs(float(fx[f"s{s}.closs"])))
+        if s == 0:
+            e_grad = max(H.relerr(v.grad.cpu().numpy(), fx["g0." + k]) for k, v in model.named_parameters() if v.grad is not None)
+        opt.step()
+    print(f"{case:16s} steps {meta['n_steps']}: loss {e_loss:.2e}, row loss {e_row:.2e}, NT-Xent term {e_closs:.2e}, "
+          f"gradients (step 0) {e_grad:.2e}")
