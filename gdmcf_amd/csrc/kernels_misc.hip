@@ -29,11 +29,12 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
 __device__ __forceinline__ void box_muller(uint32_t a, uint32_t b, float& z0, float& z1) {
     const float u1 = ((float)a + 1.0f) * 2.3283064365386963e-10f;  // (0,1]
     const float u2 = (float)b * 2.3283064365386963e-10f;
-    const float rad = sqrtf(-2.0f * logf(u1));
-    float s, c;
-    sincosf(6.283185307179586f * u2, &s, &c);
-    z0 = rad * c;
-    z1 = rad * s;
+    // hardware transcendentals (v_log_f32, v_sqrt_f32, v_sin_f32 / v_cos_f32 take the angle in revolutions): the libm
+    // forms cost ~10x the instructions and made the input builder ALU-bound; ~1e-6 absolute error is irrelevant for
+    // N(0,1) noise (tests/test_gpu_parity.py::test_philox_noise_and_dropout_statistics)
+    const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // sqrt(-2 ln u1)
+    z0 = rad * __builtin_amdgcn_cosf(u2);
+    z1 = rad * __builtin_amdgcn_sinf(u2);
 }
 
 // round-to-nearest-even float -> bfloat16 bits (v_cvt_pk_bf16_f32), for the bf16 shadow copies
@@ -249,7 +250,12 @@ __global__ __launch_bounds__(256) void onehot_noise_kernel(const float* __restri
             s = (sv >> (8 * j)) & 1;
         } else {
             // P(class 1) = a*[c0 == 1] + (1 - a)*(1 - e), each product and the sum rounded to f32 as torch does
-            const float p1 = __fadd_rn(c0 ? a : 0.f, __fmul_rn(__fsub_rn(1.f, a), p1_off));
+            float p1;
+            {
+#pragma clang fp contract(off)
+                const float q = (1.f - a) * p1_off;
+                p1 = (c0 ? a : 0.f) + q;
+            }
             s = ((float)(u[j] >> 8) * 5.9604644775390625e-8f) < p1;
         }
         so |= (uint32_t)s << (8 * j);
