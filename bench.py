@@ -196,13 +196,14 @@ def main():
 
     torch.manual_seed(0)
     if args.backbone in ("onehot", "onehot-emb"):
-        if args.gemm_dtype != "f32" or args.fuse_optimizer:
-            raise SystemExit("--backbone onehot / onehot-emb: fp32 with a separate AdamW pass only")
+        if args.fuse_optimizer:
+            raise SystemExit("--backbone onehot / onehot-emb: separate AdamW pass only")
         if args.backbone == "onehot":
-            model = gdmcf_amd.DNNOneHot([I, hid], [hid, I], 10, time_type="cat", norm=False).to(dev)
+            model = gdmcf_amd.DNNOneHot([I, hid], [hid, I], 10, time_type="cat", norm=False, gemm_dtype=args.gemm_dtype).to(dev)
         else:
             model = gdmcf_amd.DNNOneHotEmbedding([I, hid], [hid, I], 10, time_type="cat", norm=False, item_num=I,
-                                                 user_num=data.SHAPES[args.workload]["n_users"]).to(dev)
+                                                 user_num=data.SHAPES[args.workload]["n_users"],
+                                                 gemm_dtype=args.gemm_dtype).to(dev)
         diffusion = gdmcf_amd.GaussianDiffusionDiscrete(gdmcf_amd.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, T,
                                                         dev, CatOneHot=True)
         diffusion.indexIn = args.backbone == "onehot-emb"  # main.py:241

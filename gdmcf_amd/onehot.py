@@ -9,7 +9,7 @@ branch), the dense layers, the fused loss epilogue, the weight / input gradient 
 branch writes straight into its column range of one [B, h1 + h2] buffer, and the gradient of that buffer is read back
 by column range.
 
-fp32 only (no bf16 shadows).  Data parallel: the engine hands every gradient to `DataParallelStep`'s sink as soon as its
+`gemm_dtype="bf16"` rounds the GEMM operands to bf16 on chip (from the f32 tensors: no bf16 shadows here).  Data parallel: the engine hands every gradient to `DataParallelStep`'s sink as soon as its
 kernels are enqueued (overlapped all-reduce, or the sharded optimiser with its all-gathers waited for at the end of the
 step).  Constructor, parameter names and initialisation draw order are the reference's, so checkpoints interchange.
 """
@@ -65,6 +65,10 @@ class OneHotEngine:
     def manual_seed(self, seed):
         self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         self.offset = 0
+
+    def _precision(self):
+        """GDMCF_GEMM_F32 (0) or GDMCF_GEMM_BF16 (1: operands rounded to bf16 on their way to LDS -- no shadows here)."""
+        return 1 if getattr(self.model, "gemm_dtype", "f32") == "bf16" else 0
 
     # -- layers -------------------------------------------------------------------------------------------------------
     def _chains(self):
@@ -198,7 +202,7 @@ class OneHotEngine:
 
     # -- fused training forward / backward ----------------------------------------------------------------------------
     def train_forward(self, spec):
-        prev = self.lib.gdmcf_gemm_precision(0)
+        prev = self.lib.gdmcf_gemm_precision(self._precision())
         try:
             return self._train_forward(spec)
         finally:
@@ -261,7 +265,7 @@ class OneHotEngine:
         return loss
 
     def train_backward(self, gloss):
-        prev = self.lib.gdmcf_gemm_precision(0)
+        prev = self.lib.gdmcf_gemm_precision(self._precision())
         try:
             return self._train_backward(gloss)
         finally:
@@ -363,7 +367,7 @@ class OneHotEngine:
 
     # -- plain forward (evaluation / reverse loop) ----------------------------------------------------------------------
     def forward_plain(self, x, timesteps, x_U, training, drop_mask=None, drop_mask_U=None):
-        prev = self.lib.gdmcf_gemm_precision(0)
+        prev = self.lib.gdmcf_gemm_precision(self._precision())
         try:
             B, dev = x.shape[0], x.device
             br1, br2, out = self._chains()
@@ -397,8 +401,11 @@ class DNNOneHot(nn.Module):
     """Drop-in for the reference DNNOneHot (models/DNN.py:360-477).  As there, `out_dims[0]` of the CALLER's list grows
     by the width of the second branch (the reference aliases and mutates it, :384-385)."""
 
-    def __init__(self, in_dims, out_dims, emb_size, time_type="cat", norm=False, dropout=0.5):
+    def __init__(self, in_dims, out_dims, emb_size, time_type="cat", norm=False, dropout=0.5, gemm_dtype="f32"):
         super().__init__()
+        if gemm_dtype not in ("f32", "bf16"):
+            raise ValueError("Unimplemented GEMM input precision %s" % gemm_dtype)
+        self.gemm_dtype = gemm_dtype  # "bf16": dense products on the bf16 matrix pipe, f32 accumulate / state (§4.4)
         self.in_dims = in_dims
         self.in_dims2 = list(in_dims)
         self.in_dims2[0] *= 2

@@ -147,7 +147,7 @@ class OneHotEmbeddingEngine(OneHotEngine):
         return res + [dV, dWu]
 
     def forward_plain(self, x, timesteps, x_U, training, drop_mask=None, drop_mask_U=None, index=None):
-        prev = self.lib.gdmcf_gemm_precision(0)
+        prev = self.lib.gdmcf_gemm_precision(self._precision())
         try:
             B, dev = x.shape[0], x.device
             br1, br2, _ = self._chains()
@@ -181,9 +181,10 @@ class DNNOneHotEmbedding(DNNOneHot):
     """Drop-in for the reference DNNOneHotEmbedding (models/DNN.py:510-682); main.py:239-242 builds it with
     `item_num=n_item, user_num=n_user` and sets `diffusion.indexIn = True`."""
 
-    def __init__(self, in_dims, out_dims, emb_size, time_type="cat", norm=False, dropout=0.5, item_num=2810, user_num=5949):
+    def __init__(self, in_dims, out_dims, emb_size, time_type="cat", norm=False, dropout=0.5, item_num=2810, user_num=5949,
+                 gemm_dtype="f32"):
         self._defer_init = True
-        super().__init__(in_dims, out_dims, emb_size, time_type=time_type, norm=norm, dropout=dropout)
+        super().__init__(in_dims, out_dims, emb_size, time_type=time_type, norm=norm, dropout=dropout, gemm_dtype=gemm_dtype)
         eu = self.in_layers[-1].out_features
         self.embedding_item = nn.Embedding(item_num, eu + eu + self.in_layers2[-1].out_features)
         self.embedding_user = nn.Embedding(user_num, eu)

@@ -296,3 +296,35 @@ def test_onehot_embedding_full_width_step_matches_oracle():
             assert a.grad is None, k
         else:
             assert H.relerr(a.grad.cpu().numpy(), b.grad.numpy()) < 5e-4, k
+
+
+@pytest.mark.parametrize("backbone", ["onehot", "onehot-emb"])
+def test_onehot_backbones_with_bf16_gemm_inputs(backbone):
+    """gemm_dtype="bf16" on the one-hot backbones (operands rounded to bf16 on chip, f32 accumulate and state): one
+    training step within bf16 rounding of the f32 path -- loss 1e-3, gradients a few 1e-2 of their max-norm."""
+    torch.manual_seed(4)
+    I, hid, B, T, U = 1500, 96, 64, 5, 300
+    g = torch.Generator().manual_seed(8)
+    x = (torch.rand(B, I, generator=g) < 0.03).float().to(DEV)
+    rand = dict(ts=torch.randint(0, T, (B,), generator=g).to(DEV), pt=torch.ones(B, dtype=torch.float64, device=DEV),
+                noise=torch.randn(B, I, generator=g).to(DEV), drop_mask=(torch.rand(B, I, generator=g) < 0.5).to(torch.uint8).to(DEV),
+                sampled=(torch.rand(B, I, generator=g) < 0.02).to(torch.uint8).to(DEV),
+                drop_mask_U=(torch.rand(B, 2 * I, generator=g) < 0.5).to(torch.uint8).to(DEV))
+    if backbone == "onehot-emb":
+        rand["index"] = torch.randperm(U, generator=g)[:B]
+    res = {}
+    for dtype in ("f32", "bf16"):
+        torch.manual_seed(11)
+        if backbone == "onehot":
+            m = gdmcf_amd.DNNOneHot([I, hid], [hid, I], 10, gemm_dtype=dtype)
+        else:
+            m = gdmcf_amd.DNNOneHotEmbedding([I, hid], [hid, I], 10, item_num=I, user_num=U, gemm_dtype=dtype)
+        m = m.to(DEV).train()
+        d = gdmcf_amd.GaussianDiffusionDiscrete(ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, T, DEV, CatOneHot=True)
+        d.indexIn = backbone == "onehot-emb"
+        loss = d.training_losses(m, x, True, **rand)["loss"].mean()
+        loss.backward()
+        res[dtype] = (float(loss.detach()), [p.grad.clone() for p in m.parameters() if p.grad is not None])
+    assert abs(res["bf16"][0] - res["f32"][0]) <= 2e-3 * abs(res["f32"][0]) and res["bf16"][0] != res["f32"][0]
+    for a, b in zip(res["bf16"][1], res["f32"][1]):
+        assert H.relerr(a.cpu().numpy(), b.cpu().numpy()) < 5e-2
