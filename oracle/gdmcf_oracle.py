@@ -465,6 +465,106 @@ class DNNOneHotEmbedding(DNNOneHot):
         return (out, closs) if RCloss else out
 
 
+# ---- GCN backbone (reference models/DNN.py:1077-1103 LayerGCN, :1105-1327 DNNOneHotEmbeddingGCN) --------------------
+# PARITY UNPINNED for this class: `GCNConv` comes from torch_geometric==2.5.3 (requirements.txt:53), which is absent here
+# and not vendored by the reference, and the class constructs itself with `.cuda()` (:1155).  `gcn_conv` restates the
+# published algorithm of torch_geometric.nn.GCNConv (Kipf & Welling; PyG 2.5 `gcn_norm` + `propagate`, flow
+# source_to_target, add_self_loops=True, improved=False, normalize=True, bias=True):
+#     A^ = A + I (self loops of weight 1 added to every node),  deg_i = sum of the weights of edges INTO node i,
+#     out_i = sum over edges (j -> i) of  deg_j^-1/2 * deg_i^-1/2 * (Theta x_j)   + bias.
+def gcn_conv(x, edge_index, weight, bias):
+    n = x.size(0)
+    loops = torch.arange(n, device=x.device)
+    src = torch.cat([edge_index[0], loops])
+    dst = torch.cat([edge_index[1], loops])
+    w = torch.ones(src.numel(), dtype=x.dtype, device=x.device)
+    deg = torch.zeros(n, dtype=x.dtype, device=x.device).scatter_add_(0, dst, w)
+    dis = deg.pow(-0.5)
+    dis[dis == float("inf")] = 0
+    norm = dis[src] * w * dis[dst]
+    xw = x @ weight.t()
+    out = torch.zeros_like(xw).index_add_(0, dst, norm.unsqueeze(1) * xw[src])
+    return out + bias
+
+
+class _GCNConvParams(nn.Module):  # parameter names of PyG 2.5's GCNConv: `lin.weight` [out, in] (no bias) and `bias`
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.lin = nn.Linear(cin, cout, bias=False)
+        self.bias = nn.Parameter(torch.zeros(cout))
+        a = math.sqrt(6.0 / (cin + cout))  # PyG: glorot(weight), zeros(bias)
+        self.lin.weight.data.uniform_(-a, a)
+
+
+class _LayerGCNParams(nn.Module):  # reference :1077-1103
+    def __init__(self, cin, hidden, cout, layers):
+        super().__init__()
+        self.layers = layers
+        if layers == 1:
+            self.conv1 = _GCNConvParams(cin, cout)
+        else:
+            self.conv1 = _GCNConvParams(cin, hidden)
+            self.conv2 = _GCNConvParams(hidden, cout)
+
+    def forward(self, x, edge_index):
+        out = gcn_conv(x, edge_index, self.conv1.lin.weight, self.conv1.bias)
+        if self.layers == 2:
+            out = torch.nn.functional.leaky_relu(torch.relu(out), 0.1)  # :1097-1098 (leaky ReLU of a ReLU output: identity)
+            out = gcn_conv(out, edge_index, self.conv2.lin.weight, self.conv2.bias)
+        return out
+
+
+class DNNOneHotEmbeddingGCN(DNNOneHotEmbedding):
+    """The backbone the shipped YAML selects, args.noise_type == 0: DNNOneHotEmbedding whose user-side vector
+    hc = [h, h_U, embedding_user(index)] is blended with the output of a 1- or 2-layer GCN (3*hid -> 512 -> 3*hid) over the
+    nodes [hc rows; all item embeddings] and the batch-local edges user b -> item i (where `graph[b, i]` has its class-1
+    bit set), `hc * sumW + gcn(...)[:B] * (1 - sumW)` with a learnable scalar sumW (initially 1), before the cosine scores
+    against the RAW item embeddings (:1277-1289).  Only the first B rows of the GCN output are used, and user nodes are
+    never the TARGET of an edge, so under GCNConv's flow they aggregate their self loop only -- the scores do not depend
+    on `graph` (tests pin this property of the restatement)."""
+
+    def __init__(self, in_dims, out_dims, emb_size, time_type="cat", norm=False, dropout=0.5, item_num=2810, user_num=5949,
+                 gcn_layers=2, hidden_dim=512):
+        super().__init__(in_dims, out_dims, emb_size, time_type, norm, dropout, item_num, user_num)
+        d = self.embedding_item.weight.shape[1]
+        self.gcn_layers = gcn_layers
+        if gcn_layers > 0:
+            self.gcn_model = _LayerGCNParams(d, hidden_dim, d, gcn_layers)
+        self.sumW = nn.Parameter(torch.tensor(1.0))
+
+    def forward(self, x, timesteps, x_U, index=None, graph=None, RCloss=False, drop_mask=None, drop_mask_U=None):
+        ct = graph.argmax(dim=2)
+        edge_index = torch.nonzero(ct).t().contiguous()
+        edge_index[1, :] += ct.shape[0]
+        x_U = x_U.reshape(x_U.shape[0], -1)
+        emb = self.emb_layer(timestep_embedding(timesteps, self.time_emb_dim).to(x.device))
+        if self.norm:
+            x = torch.nn.functional.normalize(x)
+            x_U = torch.nn.functional.normalize(x_U)
+        if drop_mask is not None:
+            x = x * (drop_mask.to(x.dtype) / (1.0 - self.p))
+            x_U = x_U * (drop_mask_U.reshape(x_U.shape).to(x.dtype) / (1.0 - self.p))
+        else:
+            x = self.drop(x)
+            x_U = self.drop(x_U)
+        h = torch.cat([x, emb], dim=-1)
+        for layer in self.in_layers:
+            h = torch.tanh(layer(h))
+        h_U = torch.cat([x_U, emb], dim=-1)
+        for layer in self.in_layers2:
+            h_U = torch.tanh(layer(h_U))
+        closs = nt_xent_loss(h, h_U) if RCloss else None
+        items = self.embedding_item.weight
+        hc = torch.cat([h, h_U, self.embedding_user(index)], dim=1)
+        if self.gcn_layers > 0:
+            g = self.gcn_model(torch.cat([hc, items], dim=0), edge_index)[: hc.shape[0]]
+        else:
+            g = hc
+        u = hc * self.sumW + g * (1 - self.sumW)
+        out = torch.mm(u, items.t()) / (torch.norm(u, dim=1, keepdim=True) * torch.norm(items, dim=1).t())
+        return (out, closs) if RCloss else out
+
+
 class GaussianDiffusionDiscrete(GaussianDiffusion):
     """CatOneHot path of the reference's GaussianDiffusionDiscrete (gaussian_diffusion.py:552-1135), indexIn False:
     the rows are additionally handed to the model as one-hot pairs whose bits survive only where a draw from

@@ -253,3 +253,51 @@ def test_onehot_embedding_backbone_matches_reference(case):
         got = diff.p_sample(model, x, meta["T"], False, noise0=torch.from_numpy(fx["e.noise_stepsT"]),
                             sampled0=torch.from_numpy(fx["e.sampled_stepsT"].astype(np.int64)), index=idx)
         np.testing.assert_array_equal(got.numpy(), fx["e.pred_stepsT"])
+
+
+def test_gcn_backbone_restatement_ignores_the_graph_on_user_rows():
+    """DNNOneHotEmbeddingGCN (parity UNPINNED: torch_geometric is not vendored).  Property of the restated GCNConv that the
+    HIP path relies on: user nodes are never the target of an edge, so the rows of the GCN output that the backbone uses
+    equal a plain 2-layer perceptron of hc -- scores and gradients do not depend on `graph`; and gcn_conv itself equals
+    the dense D^-1/2 (A + I)^T-aggregation formula on a small random directed graph."""
+    torch.manual_seed(0)
+    n, cin, cout = 9, 5, 4
+    x, w, b = torch.randn(n, cin), torch.randn(cout, cin), torch.randn(cout)
+    ei = torch.tensor([[0, 0, 1, 2, 2, 7], [4, 5, 5, 6, 8, 3]])
+    A = torch.zeros(n, n)
+    A[ei[1], ei[0]] = 1.0  # A[i, j] = 1 for an edge j -> i
+    A = A + torch.eye(n)
+    dis = A.sum(1).pow(-0.5)
+    ref = (dis[:, None] * A * dis[None, :]) @ (x @ w.t()) + b
+    np.testing.assert_allclose(O.gcn_conv(x, ei, w, b).numpy(), ref.numpy(), rtol=1e-6, atol=1e-6)
+
+    I, hid, B, U, T = 40, 6, 7, 30, 5
+    m = O.DNNOneHotEmbeddingGCN([I, hid], [hid, I], 10, item_num=I, user_num=U, hidden_dim=8)
+    with torch.no_grad():
+        m.sumW.fill_(0.3)
+        m.gcn_model.conv1.bias.normal_()
+        m.gcn_model.conv2.bias.normal_()
+    m.eval()
+    xr = (torch.rand(B, I) < 0.2).float()
+    ts, idx = torch.randint(0, T, (B,)), torch.randperm(U)[:B]
+    xU = torch.nn.functional.one_hot(xr.long(), 2).float()
+    g1 = torch.nn.functional.one_hot(xr.long(), 2)
+    g2 = torch.nn.functional.one_hot((torch.rand(B, I) < 0.5).long(), 2)
+    g0 = torch.nn.functional.one_hot(torch.zeros(B, I, dtype=torch.long), 2)
+    outs = [m(xr, ts, xU, index=idx, graph=g) for g in (g1, g2, g0)]
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    # ... and they are the perceptron blend
+    with torch.no_grad():
+        ref_m = O.DNNOneHotEmbedding([I, hid], [hid, I], 10, item_num=I, user_num=U)
+        ref_m.load_state_dict({k: v for k, v in m.state_dict().items() if not k.startswith(("gcn_model", "sumW"))})
+        ref_m.eval()
+        emb = m.emb_layer(O.timestep_embedding(ts, 10))
+        h = torch.tanh(m.in_layers[0](torch.cat([xr, emb], 1)))
+        hU = torch.tanh(m.in_layers2[0](torch.cat([xU.reshape(B, -1), emb], 1)))
+        hc = torch.cat([h, hU, m.embedding_user(idx)], 1)
+        z = torch.relu(hc @ m.gcn_model.conv1.lin.weight.t() + m.gcn_model.conv1.bias)
+        z = z @ m.gcn_model.conv2.lin.weight.t() + m.gcn_model.conv2.bias
+        u = hc * 0.3 + z * 0.7
+        V = m.embedding_item.weight
+        want = (u @ V.t()) / (u.norm(dim=1, keepdim=True) * V.norm(dim=1))
+    np.testing.assert_allclose(outs[0].detach().numpy(), want.numpy(), rtol=1e-5, atol=1e-6)
