@@ -8,7 +8,8 @@ from .evaluate_utils import computeTopNAccuracy, computeTopNAccuracy_device, mas
 from .lightgcn import LightGCN  # noqa: F401
 from .onehot import DNNOneHot  # noqa: F401
 from .onehot_embedding import DNNOneHotEmbedding  # noqa: F401
+from .onehot_gcn import DNNOneHotEmbeddingGCN  # noqa: F401
 from . import checkpoint, data_utils, driver, parallel  # noqa: F401
 
 __all__ = ["DNN", "timestep_embedding", "GaussianDiffusion", "GaussianDiffusionDiscrete", "ModelMeanType", "FusedAdamW", "computeTopNAccuracy",
-           "computeTopNAccuracy_device", "masked_topk", "print_results", "LightGCN", "DNNOneHot", "DNNOneHotEmbedding"]
+           "computeTopNAccuracy_device", "masked_topk", "print_results", "LightGCN", "DNNOneHot", "DNNOneHotEmbedding", "DNNOneHotEmbeddingGCN"]

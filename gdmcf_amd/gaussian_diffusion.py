@@ -328,8 +328,8 @@ class GaussianDiffusionDiscrete(GaussianDiffusion):
         from .onehot_embedding import DNNOneHotEmbedding
         if self.indexIn:  # main.py:239-242 sets it together with the embedding backbones
             if not isinstance(model, DNNOneHotEmbedding):
-                raise NotImplementedError("indexIn is built for gdmcf_amd.DNNOneHotEmbedding only; the GCN backbones "
-                                          "(DNNOneHotEmbeddingGCN*) are not (SURVEY 8 f1: un-vendored torch_geometric)")
+                raise NotImplementedError("indexIn is built for gdmcf_amd.DNNOneHotEmbedding / DNNOneHotEmbeddingGCN only "
+                                          "(the *_conti / *_time variants are not, SURVEY 8 f1)")
         elif not isinstance(model, DNNOneHot) or isinstance(model, DNNOneHotEmbedding):
             raise TypeError("gdmcf_amd.GaussianDiffusionDiscrete(CatOneHot=True) needs a gdmcf_amd.DNNOneHot denoiser "
                             "(DNNOneHotEmbedding with indexIn = True)")

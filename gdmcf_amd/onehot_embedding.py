@@ -65,12 +65,21 @@ class OneHotEmbeddingEngine(OneHotEngine):
         ld = bufs.ucat.stride(0)
         _lib.check(lib.gdmcf_gather_rows_f32(Wu.data_ptr(), Wu.stride(0), index.data_ptr(), B, bufs.eu,
                                              bufs.ucat.data_ptr() + 4 * bufs.h12, ld, st))
-        _lib.check(lib.gdmcf_row_norms_f32(bufs.ucat.data_ptr(), ld, B, bufs.D, None, bufs.rn_u.data_ptr(), st))
+        u = self._user_vector(bufs, B)  # what is scored against the items: ucat itself, or a subclass's function of it
+        _lib.check(lib.gdmcf_row_norms_f32(u.data_ptr(), u.stride(0), B, bufs.D, None, bufs.rn_u.data_ptr(), st))
         _lib.check(lib.gdmcf_row_norms_f32(V.data_ptr(), V.stride(0), self.I, bufs.D, None, bufs.rn_v.data_ptr(), st))
-        _lib.check(lib.gdmcf_rowscale_f32(bufs.ucat.data_ptr(), ld, bufs.rn_u.data_ptr(), B, bufs.D, bufs.uhat.data_ptr(),
+        _lib.check(lib.gdmcf_rowscale_f32(u.data_ptr(), u.stride(0), bufs.rn_u.data_ptr(), B, bufs.D, bufs.uhat.data_ptr(),
                                           bufs.uhat.stride(0), st))
         _lib.check(lib.gdmcf_rowscale_f32(V.data_ptr(), V.stride(0), bufs.rn_v.data_ptr(), self.I, bufs.D,
                                           bufs.Vhat.data_ptr(), bufs.Vhat.stride(0), st))
+
+    def _user_vector(self, bufs, B):
+        return bufs.ucat
+
+    def _user_vector_backward(self, bufs, B):
+        """bufs.du holds the gradient w.r.t. the scored user vector; turn it into the gradient w.r.t. ucat (in place) and
+        return {parameter: gradient} of whatever lies between the two."""
+        return {}
 
     @staticmethod
     def _index_on(index, device, B):
@@ -128,6 +137,7 @@ class OneHotEmbeddingEngine(OneHotEngine):
         _lib.check(lib.gdmcf_normalize_rows_bwd_f32(bufs.du.data_ptr(), bufs.du.stride(0), bufs.uhat.data_ptr(),
                                                     bufs.uhat.stride(0), bufs.rn_u.data_ptr(), B, bufs.D, bufs.du.data_ptr(),
                                                     bufs.du.stride(0), st))
+        self._extra_grads = self._user_vector_backward(bufs, B)
         # user rows: scatter into the dense table gradient (torch.optim.AdamW on nn.Embedding sees a dense gradient too)
         dWu = torch.zeros_like(Wu)
         _lib.check(lib.gdmcf_scatter_add_rows_f32(bufs.du.data_ptr() + 4 * bufs.h12, bufs.du.stride(0), index.data_ptr(), B,

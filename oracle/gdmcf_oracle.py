@@ -662,9 +662,10 @@ class GaussianDiffusionDiscrete(GaussianDiffusion):
         zero = torch.nn.functional.one_hot(torch.zeros_like(x_start.long()), num_classes=2)
         for n, i in enumerate(indices):
             t = torch.tensor([i] * B)
-            if not injected:
-                # per-step degree-guided graph (:706-729): consumed only by the GCN backbones (`graph=`), but its two
-                # multinomial draws advance the generator, so they are replayed when the randomness is not injected
+            if not injected or self.indexIn:
+                # per-step degree-guided graph (:706-729): consumed only by the GCN backbones (`graph=`; whose scores do
+                # not depend on it, see DNNOneHotEmbeddingGCN), but its two multinomial draws advance the generator, so
+                # they are replayed when the randomness is not injected -- and always for the indexIn backbones
                 g_i, _ = self.apply_noise(t, zero.float())
                 deg = x_start.sum(dim=1)
                 deg = (deg / deg.max()).unsqueeze(1)

@@ -328,3 +328,59 @@ def test_onehot_backbones_with_bf16_gemm_inputs(backbone):
     assert abs(res["bf16"][0] - res["f32"][0]) <= 2e-3 * abs(res["f32"][0]) and res["bf16"][0] != res["f32"][0]
     for a, b in zip(res["bf16"][1], res["f32"][1]):
         assert H.relerr(a.cpu().numpy(), b.cpu().numpy()) < 5e-2
+
+
+@pytest.mark.parametrize("layers", [2, 1, 0])
+def test_gcn_backbone_matches_the_restated_oracle(layers):
+    """DNNOneHotEmbeddingGCN (PARITY UNPINNED: torch_geometric's GCNConv is restated in the oracle from its published
+    semantics): two training steps and p_sample against the oracle's FULL-GRAPH evaluation on the same injected randomness,
+    with sumW away from its initial 1 so that the GCN branch carries weight -- loss, every gradient incl. the GCNConv
+    parameters and sumW, weights after AdamW."""
+    torch.manual_seed(7)
+    I, hid, B, T, U = 210, 24, 20, 5, 70
+    om = O.DNNOneHotEmbeddingGCN([I, hid], [hid, I], 10, item_num=I, user_num=U, gcn_layers=layers)
+    with torch.no_grad():
+        om.sumW.fill_(0.4)
+        for k, p in om.named_parameters():
+            if k.startswith("gcn_model") and k.endswith("bias"):
+                p.normal_(0.0, 0.1)
+    gm = gdmcf_amd.DNNOneHotEmbeddingGCN([I, hid], [hid, I], 10, item_num=I, user_num=U, gcn_layers=layers)
+    gm.load_state_dict(om.state_dict())
+    gm = gm.to(DEV).train()
+    om.train()
+    od = O.GaussianDiffusionDiscrete(O.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, T, CatOneHot=True)
+    gd_ = gdmcf_amd.GaussianDiffusionDiscrete(ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, T, DEV, CatOneHot=True)
+    od.indexIn = gd_.indexIn = True
+    oo, go = O.make_optimizer(om, 1e-3, 0.01), gdmcf_amd.FusedAdamW(gm.parameters(), lr=1e-3, weight_decay=0.01)
+    g = torch.Generator().manual_seed(9)
+    for s in range(2):
+        x = (torch.rand(B, I, generator=g) < 0.06).float()
+        r = dict(ts=torch.randint(0, T, (B,), generator=g), pt=torch.ones(B, dtype=torch.float64),
+                 noise=torch.randn(B, I, generator=g), drop_mask=(torch.rand(B, I, generator=g) < 0.5).float(),
+                 ts_U=torch.randint(0, T, (B,), generator=g), sampled=(torch.rand(B, I, generator=g) < 0.05).long(),
+                 drop_mask_U=(torch.rand(B, 2 * I, generator=g) < 0.5).float(), index=torch.randperm(U, generator=g)[:B])
+        oo.zero_grad()
+        ol = od.training_losses(om, x, True, **r)["loss"]
+        ol.mean().backward()
+        go.zero_grad()
+        gl = gd_.training_losses(gm, cu(x), True, **{k: (v if k == "index" else cu(v)) for k, v in r.items()})["loss"]
+        gl.mean().backward()
+        np.testing.assert_allclose(gl.detach().cpu().numpy(), ol.detach().numpy(), rtol=1e-4, atol=0)
+        for (k, a), (_, b) in zip(gm.named_parameters(), om.named_parameters()):
+            if b.grad is None:
+                assert a.grad is None, k
+            else:
+                scale = max(float(b.grad.abs().max()), 1e-30)
+                assert float((a.grad.cpu() - b.grad).abs().max()) < 3e-4 * scale + 1e-9, (k, s)
+        oo.step()
+        go.step()
+    for (k, a), (_, b) in zip(gm.named_parameters(), om.named_parameters()):
+        assert float((a.detach().cpu() - b.detach()).abs().max()) < 0.02 * 1e-3 * 2, k
+    gm.eval()
+    om.eval()
+    x = (torch.rand(B, I, generator=g) < 0.06).float()
+    idx = torch.randperm(U, generator=g)[:B]
+    with torch.no_grad():
+        want = od.p_sample(om, x, 0, False, sampled0=torch.zeros(1), index=idx)
+    got = gd_.p_sample(gm, cu(x), 0, False, index=idx)
+    assert H.relerr(got.cpu().numpy(), want.numpy()) < 2e-4
