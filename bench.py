@@ -86,9 +86,10 @@ def parse():
                     help="single GPU: update the two large weights inside the weight-gradient GEMM epilogue "
                          "(FusedAdamW.fuse_into_backward); same update rule, gradient never materialised")
     ap.add_argument("--bpr", action="store_true", help="also time a LightGCN BPR training step (reported under 'bpr')")
-    ap.add_argument("--backbone", default="dnn", choices=["dnn", "onehot", "onehot-emb"],
+    ap.add_argument("--backbone", default="dnn", choices=["dnn", "onehot", "onehot-emb", "onehot-gcn"],
                     help="dnn: the plain denoiser (BASELINE configs); onehot: GaussianDiffusionDiscrete(CatOneHot=True) + "
-                         "DNNOneHot; onehot-emb: the indexIn backbone DNNOneHotEmbedding (SURVEY 8 f1; fp32)")
+                         "DNNOneHot; onehot-emb / onehot-gcn: the indexIn backbones DNNOneHotEmbedding / DNNOneHotEmbeddingGCN "
+                         "(SURVEY 8 f1)")
     ap.add_argument("--rehearse-dp", action="store_true",
                     help="N = 1 only: create a one-rank RCCL group and run every data-parallel collective through it "
                          "(rehearsal of the N > 1 code path on a single-GPU box)")
@@ -124,13 +125,15 @@ def cpu_baseline(args, I, x_batches, seconds):
     torch.manual_seed(0)
     from gdmcf_amd import data as _data
     n_users = _data.SHAPES[args.workload]["n_users"]
-    if args.backbone in ("onehot", "onehot-emb"):
+    if args.backbone != "dnn":
         if args.backbone == "onehot":
             om = O.DNNOneHot([I, args.hidden], [args.hidden, I], 10)
-        else:
+        elif args.backbone == "onehot-emb":
             om = O.DNNOneHotEmbedding([I, args.hidden], [args.hidden, I], 10, item_num=I, user_num=n_users)
+        else:
+            om = O.DNNOneHotEmbeddingGCN([I, args.hidden], [args.hidden, I], 10, item_num=I, user_num=n_users)
         od = O.GaussianDiffusionDiscrete(O.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, args.T, CatOneHot=True)
-        od.indexIn = args.backbone == "onehot-emb"
+        od.indexIn = args.backbone != "onehot"
     else:
         om = O.DNN([I, args.hidden], [args.hidden, I], 10)
         od = O.GaussianDiffusion(O.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, args.T)
@@ -138,7 +141,7 @@ def cpu_baseline(args, I, x_batches, seconds):
     om.train()
     xs = [torch.from_numpy(b) for b in x_batches[:2]]
     Bc = xs[0].shape[0]
-    extra = dict(index=torch.arange(Bc)) if args.backbone == "onehot-emb" else {}
+    extra = dict(index=torch.arange(Bc)) if args.backbone in ("onehot-emb", "onehot-gcn") else {}
     O.train_step(od, om, opt, xs[0], True, **extra)  # warm-up (allocations, thread pool)
     n, t0 = 0, time.perf_counter()
     while True:
@@ -195,18 +198,18 @@ def main():
     x_dev = torch.from_numpy(x_host[:1]).to(dev)
 
     torch.manual_seed(0)
-    if args.backbone in ("onehot", "onehot-emb"):
+    if args.backbone != "dnn":
         if args.fuse_optimizer:
-            raise SystemExit("--backbone onehot / onehot-emb: separate AdamW pass only")
+            raise SystemExit("--backbone onehot*: separate AdamW pass only")
         if args.backbone == "onehot":
             model = gdmcf_amd.DNNOneHot([I, hid], [hid, I], 10, time_type="cat", norm=False, gemm_dtype=args.gemm_dtype).to(dev)
         else:
-            model = gdmcf_amd.DNNOneHotEmbedding([I, hid], [hid, I], 10, time_type="cat", norm=False, item_num=I,
-                                                 user_num=data.SHAPES[args.workload]["n_users"],
-                                                 gemm_dtype=args.gemm_dtype).to(dev)
+            cls = gdmcf_amd.DNNOneHotEmbedding if args.backbone == "onehot-emb" else gdmcf_amd.DNNOneHotEmbeddingGCN
+            model = cls([I, hid], [hid, I], 10, time_type="cat", norm=False, item_num=I,
+                        user_num=data.SHAPES[args.workload]["n_users"], gemm_dtype=args.gemm_dtype).to(dev)
         diffusion = gdmcf_amd.GaussianDiffusionDiscrete(gdmcf_amd.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, T,
                                                         dev, CatOneHot=True)
-        diffusion.indexIn = args.backbone == "onehot-emb"  # main.py:241
+        diffusion.indexIn = args.backbone != "onehot"  # main.py:241, :245
     else:
         model = gdmcf_amd.DNN([I, hid], [hid, I], 10, time_type="cat", norm=False, gemm_dtype=args.gemm_dtype).to(dev)
         diffusion = gdmcf_amd.GaussianDiffusion(gdmcf_amd.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, T, dev)
@@ -222,7 +225,7 @@ def main():
     autotune = (world > 1 or args.autotune_dp) and not (args.shard_optimizer or args.allreduce_optimizer)
     step = DataParallelStep(diffusion, model, opt, shard_optimizer=sharded, force_exchange=args.rehearse_dp)
 
-    step_kw = [dict(index=r + lo) if args.backbone == "onehot-emb" else {} for r in row_ids]  # the rows' user ids
+    step_kw = [dict(index=r + lo) if args.backbone in ("onehot-emb", "onehot-gcn") else {} for r in row_ids]  # user ids
 
     def sync():
         torch.cuda.synchronize()
@@ -349,7 +352,9 @@ def main():
                                    + (", backbone DNNOneHot under GaussianDiffusionDiscrete(CatOneHot) (SURVEY 8 f1)"
                                       if args.backbone == "onehot" else
                                       ", backbone DNNOneHotEmbedding under GaussianDiffusionDiscrete(CatOneHot, indexIn) "
-                                      "(SURVEY 8 f1)" if args.backbone == "onehot-emb" else "")
+                                      "(SURVEY 8 f1)" if args.backbone == "onehot-emb" else
+                                      ", backbone DNNOneHotEmbeddingGCN (the shipped YAML's; parity unpinned, SURVEY 8 f1)"
+                                      if args.backbone == "onehot-gcn" else "")
                                    + (" (BASELINE configs[1])" if args.workload == "yelp" and T == 5 and hid == 1000
                                       and args.gemm_dtype == "f32" and args.backbone == "dnn" else "")
                                    + (" (BASELINE configs[2]: bf16 denoiser GEMM inputs, f32 accumulate/state)"

@@ -34,7 +34,7 @@ def main():
     ap.add_argument("--T", type=int, default=5)
     ap.add_argument("--lr", type=float, default=1e-4)
     ap.add_argument("--bf16", action="store_true")
-    ap.add_argument("--backbone", default="dnn", choices=["dnn", "onehot", "onehot-emb"],
+    ap.add_argument("--backbone", default="dnn", choices=["dnn", "onehot", "onehot-emb", "onehot-gcn"],
                     help="onehot: GaussianDiffusionDiscrete(CatOneHot=True) + DNNOneHot; onehot-emb: + user / item embedding "
                          "tables (DNNOneHotEmbedding, indexIn); both fp32")
     args = ap.parse_args()
@@ -62,11 +62,11 @@ def main():
         if args.backbone == "onehot":
             model = gdmcf_amd.DNNOneHot([I, args.hidden], [args.hidden, I], 10, time_type="cat", norm=False).to(dev)
         else:
-            model = gdmcf_amd.DNNOneHotEmbedding([I, args.hidden], [args.hidden, I], 10, time_type="cat", norm=False,
-                                                 item_num=I, user_num=U).to(dev)
+            cls = gdmcf_amd.DNNOneHotEmbedding if args.backbone == "onehot-emb" else gdmcf_amd.DNNOneHotEmbeddingGCN
+            model = cls([I, args.hidden], [args.hidden, I], 10, time_type="cat", norm=False, item_num=I, user_num=U).to(dev)
         diffusion = gdmcf_amd.GaussianDiffusionDiscrete(gdmcf_amd.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01,
                                                         args.T, dev, CatOneHot=True)
-        diffusion.indexIn = args.backbone == "onehot-emb"  # main.py:241
+        diffusion.indexIn = args.backbone != "onehot"  # main.py:241, :245
     else:
         model = gdmcf_amd.DNN([I, args.hidden], [args.hidden, I], 10, time_type="cat", norm=False,
                               gemm_dtype="bf16" if args.bf16 else "f32").to(dev)
