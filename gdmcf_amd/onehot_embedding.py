@@ -67,11 +67,16 @@ class OneHotEmbeddingEngine(OneHotEngine):
                                              bufs.ucat.data_ptr() + 4 * bufs.h12, ld, st))
         u = self._user_vector(bufs, B)  # what is scored against the items: ucat itself, or a subclass's function of it
         _lib.check(lib.gdmcf_row_norms_f32(u.data_ptr(), u.stride(0), B, bufs.D, None, bufs.rn_u.data_ptr(), st))
-        _lib.check(lib.gdmcf_row_norms_f32(V.data_ptr(), V.stride(0), self.I, bufs.D, None, bufs.rn_v.data_ptr(), st))
         _lib.check(lib.gdmcf_rowscale_f32(u.data_ptr(), u.stride(0), bufs.rn_u.data_ptr(), B, bufs.D, bufs.uhat.data_ptr(),
                                           bufs.uhat.stride(0), st))
-        _lib.check(lib.gdmcf_rowscale_f32(V.data_ptr(), V.stride(0), bufs.rn_v.data_ptr(), self.I, bufs.D,
-                                          bufs.Vhat.data_ptr(), bufs.Vhat.stride(0), st))
+        # V / |v| only changes with the item table (every optimiser step while training; never during evaluation, where
+        # the reverse loop calls the model T times per batch): rebuilt when the parameter's version counter moved
+        key = (V.data_ptr(), V._version)
+        if getattr(bufs, "vhat_key", None) != key:
+            _lib.check(lib.gdmcf_row_norms_f32(V.data_ptr(), V.stride(0), self.I, bufs.D, None, bufs.rn_v.data_ptr(), st))
+            _lib.check(lib.gdmcf_rowscale_f32(V.data_ptr(), V.stride(0), bufs.rn_v.data_ptr(), self.I, bufs.D,
+                                              bufs.Vhat.data_ptr(), bufs.Vhat.stride(0), st))
+            bufs.vhat_key = key
 
     def _user_vector(self, bufs, B):
         return bufs.ucat
