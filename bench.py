@@ -164,6 +164,9 @@ def main():
     if world > 1 or args.rehearse_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        # RCCL's kernels compete with MFMA-bound GEMMs for CUs while the exchange overlaps the backward: run them on a
+        # high-priority stream (read by ProcessGroupNCCL when the group is created; an explicit setting wins)
+        os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local)
