@@ -146,16 +146,30 @@ __global__ __launch_bounds__(256) void prep_rowss_kernel(const PrepArgs a, float
     if (threadIdx.x == 0) rownorm[b] = sqrtf(red[0] + red[1] + red[2] + red[3]);
 }
 
+// PREP_G column groups of 4 per thread (strided by the workgroup's 1024 columns): the per-row scalars (ts, coefficients)
+// are fetched once per thread and each workgroup moves 16 KB in and out instead of 4 KB.
+constexpr int PREP_G = 4;
+
 __global__ __launch_bounds__(256) void prep_input_kernel(const PrepArgs a) {
     const int b = blockIdx.y;
-    const int col = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (col >= a.ldxin) return;
     const int64_t t = a.ts ? a.ts[b] : 0;
     float ca = 1.f, cb = 0.f;
     if (a.ca) {
         ca = a.ca[t];
         cb = a.cb[t];
     }
+    // the workgroup that holds the embedding columns evaluates the E sinusoids ONCE, one per lane, instead of E times
+    // per embedding column in a serial chain of libm calls (that chain was a ~15 us tail of the whole launch)
+    __shared__ float s_temb[256];
+    const bool has_emb = a.E > 0 && a.E <= 256 && (int)((blockIdx.x + 1) * (256 * PREP_G * 4)) > a.I;
+    if (has_emb) {
+        if ((int)threadIdx.x < a.E) s_temb[threadIdx.x] = temb_value((float)t, threadIdx.x, a.E);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < PREP_G; ++u) {
+    const int col = (blockIdx.x * (256 * PREP_G) + u * 256 + threadIdx.x) * 4;
+    if (col >= a.ldxin) return;
     float v[4] = {0.f, 0.f, 0.f, 0.f};
     if (col < a.I) {
         xt4(a, b, col, ca, cb, v);
@@ -191,8 +205,13 @@ __global__ __launch_bounds__(256) void prep_input_kernel(const PrepArgs a) {
             if (i < a.I + a.E) {
                 const int eo = i - a.I;
                 e = a.emb_b[eo];
-                for (int f = 0; f < a.E; ++f) e += a.emb_w[eo * a.E + f] * temb_value((float)t, f, a.E);
-                if (a.temb_out) a.temb_out[(int64_t)b * a.E + eo] = temb_value((float)t, eo, a.E);
+                if (has_emb) {
+                    for (int f = 0; f < a.E; ++f) e += a.emb_w[eo * a.E + f] * s_temb[f];
+                    if (a.temb_out) a.temb_out[(int64_t)b * a.E + eo] = s_temb[eo];
+                } else {
+                    for (int f = 0; f < a.E; ++f) e += a.emb_w[eo * a.E + f] * temb_value((float)t, f, a.E);
+                    if (a.temb_out) a.temb_out[(int64_t)b * a.E + eo] = temb_value((float)t, eo, a.E);
+                }
             }
             v[j] = e;
         }
@@ -202,6 +221,7 @@ __global__ __launch_bounds__(256) void prep_input_kernel(const PrepArgs a) {
         const uint2 w = make_uint2(gd_bf16_bits(v[0]) | ((unsigned)gd_bf16_bits(v[1]) << 16),
                                    gd_bf16_bits(v[2]) | ((unsigned)gd_bf16_bits(v[3]) << 16));
         *reinterpret_cast<uint2*>(a.xin16 + (int64_t)b * a.ldxin16 + col) = w;
+    }
     }
 }
 
@@ -842,7 +862,7 @@ int gdmcf_dnn_prep_input_f32(const float* x, int64_t ldx, const int64_t* ts, con
         hipLaunchKernelGGL(prep_rowss_kernel, dim3(B), dim3(256), 0, s, a, rownorm_ws);
         a.rownorm = rownorm_ws;
     }
-    dim3 grid(gd_cdiv((int)(ldxin / 4), 256), B);
+    dim3 grid(gd_cdiv((int)(ldxin / 4), 256 * PREP_G), B);
     {
         // algorithmic bytes: read x (+ explicit noise / keep-mask), write xin
         const double bytes = (double)B * I * (4.0 + (a.noise_mode == 1 ? 4.0 : 0.0) + (drop_mode == 1 ? 1.0 : 0.0)) +
