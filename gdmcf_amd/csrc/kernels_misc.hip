@@ -421,30 +421,49 @@ __global__ void emb_cols_kernel(const int64_t* __restrict__ ts, const float* __r
 // split-K slab reducers (fixed slab order -> deterministic)
 // ---------------------------------------------------------------------------------------------
 // mode 0: out = act(sum + bias[n]);  mode 1: out = rowscale[m] * sum * (act ? 1 - aact^2 : 1)
+// Four consecutive columns per thread (one 16-byte load per slab; the slab rows are 16-byte aligned, see
+// gdmcf_linear_ws_bytes) -- the additions per element are in the same slab order as before.
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int64_t slab_stride,
                                                             int splits, int64_t ld_slab, int M, int N, int mode,
                                                             const float* __restrict__ bias,
                                                             const float* __restrict__ rowscale,
                                                             const float* __restrict__ aact, int64_t ldact, int act,
                                                             float* __restrict__ out, int64_t ldo,
-                                                            unsigned short* __restrict__ out16, int64_t ldo16) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= (int64_t)M * N) return;
-    const int m = (int)(e / N), n = (int)(e % N);
-    float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += slabs[(int64_t)k * slab_stride + (int64_t)m * ld_slab + n];
-    if (mode == 0) {
-        if (bias) s += bias[n];
-        if (act == 1) s = tanhf(s);
-    } else {
-        if (rowscale) s *= rowscale[m];
-        if (act == 1) {
-            const float h = aact[(int64_t)m * ldact + n];
-            s *= (1.f - h * h);
+                                                            unsigned short* __restrict__ out16, int64_t ldo16, int vec) {
+    const int m = blockIdx.y;
+    const int n0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (n0 >= N) return;
+    float sv[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* p = slabs + (int64_t)m * ld_slab + n0;
+    if (vec && n0 + 3 < N) {
+        for (int k = 0; k < splits; ++k) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(p + (int64_t)k * slab_stride);
+            sv[0] += t.x; sv[1] += t.y; sv[2] += t.z; sv[3] += t.w;
         }
+    } else {
+        for (int k = 0; k < splits; ++k)
+            for (int j = 0; j < 4; ++j)
+                if (n0 + j < N) sv[j] += p[(int64_t)k * slab_stride + j];
     }
-    out[(int64_t)m * ldo + n] = s;
-    if (out16) out16[(int64_t)m * ldo16 + n] = gd_bf16_bits(s);
+    const float rs = (mode != 0 && rowscale) ? rowscale[m] : 1.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + j;
+        if (n >= N) break;
+        float s = sv[j];
+        if (mode == 0) {
+            if (bias) s += bias[n];
+            if (act == 1) s = tanhf(s);
+        } else {
+            if (rowscale) s *= rs;
+            if (act == 1) {
+                const float h = aact[(int64_t)m * ldact + n];
+                s *= (1.f - h * h);
+            }
+        }
+        out[(int64_t)m * ldo + n] = s;
+        if (out16) out16[(int64_t)m * ldo16 + n] = gd_bf16_bits(s);
+    }
 }
 
 // out[m, k] = A[m, k] * rs[m]; four columns per thread (16-byte accesses; rows need only 4-byte alignment on gfx950)
@@ -1089,9 +1108,11 @@ int gd_splitk_reduce(const float* slabs, int64_t slab_stride, int splits, int64_
     const int64_t n = (int64_t)M * N;
     GdShadow sh;
     const bool has16 = gd_shadow_lookup(out, &sh) && sh.rows == M && sh.cols == N;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, slabs, slab_stride,
+    (void)n;
+    const int vec = (ld_slab % 4 == 0) && (slab_stride % 4 == 0) && gd_aligned16(slabs);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(gd_cdiv(N, 1024), M), dim3(256), 0, s, slabs, slab_stride,
                        splits, ld_slab, M, N, mode, bias, rowscale, aact, ldact, act, out, ldo,
-                       has16 ? (unsigned short*)sh.p16 : nullptr, has16 ? sh.ld16 : 0);
+                       has16 ? (unsigned short*)sh.p16 : nullptr, has16 ? sh.ld16 : 0, vec);
     return gd_launch_status("splitk_reduce");
 }
 
