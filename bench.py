@@ -226,7 +226,7 @@ def main():
     sharded = (args.shard_optimizer or world > 1) and not args.allreduce_optimizer
     # neither flag given at N > 1: both variants are timed during warm-up (untimed region) and the faster one runs
     autotune = (world > 1 or args.autotune_dp) and not (args.shard_optimizer or args.allreduce_optimizer)
-    step = DataParallelStep(diffusion, model, opt, shard_optimizer=sharded, force_exchange=args.rehearse_dp)
+    step = DataParallelStep(diffusion, model, opt, shard_optimizer=sharded and not autotune, force_exchange=args.rehearse_dp)
 
     step_kw = [dict(index=r + lo) if args.backbone in ("onehot-emb", "onehot-gcn") else {} for r in row_ids]  # user ids
 
@@ -243,24 +243,34 @@ def main():
     dp_autotune = None
     if autotune and step.exchange:
         # untimed: a few steps of each exchange variant on this node's links, max over ranks, keep the faster one
-        trial = {}
+        trial, failed = {}, None
         for name, flag in (("allreduce", False), ("sharded", True)):
-            step.set_shard_optimizer(flag)
-            for i in range(2):
-                step(dcsr.rows(row_ids[i % n_pool], out=x_buf), True, **step_kw[i % n_pool])
-            sync()
-            t1 = time.perf_counter()
-            for i in range(6):
-                step(dcsr.rows(row_ids[i % n_pool], out=x_buf), True, **step_kw[i % n_pool])
-            sync()
-            tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            trial[name] = float(tt) / 6 * 1e3
+            try:
+                step.set_shard_optimizer(flag)
+                for i in range(2):
+                    step(dcsr.rows(row_ids[i % n_pool], out=x_buf), True, **step_kw[i % n_pool])
+                sync()
+                t1 = time.perf_counter()
+                for i in range(6):
+                    step(dcsr.rows(row_ids[i % n_pool], out=x_buf), True, **step_kw[i % n_pool])
+                sync()
+                tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                trial[name] = float(tt) / 6 * 1e3
+            except Exception as exc:  # a variant this RCCL build refuses must not cost the whole run
+                if name == "allreduce":
+                    raise
+                failed = f"{type(exc).__name__}: {exc}"[:200]
+                print(f"[bench] sharded exchange failed on rank {rank}: {failed}", file=sys.stderr)
+                trial[name] = float("inf")
         sharded = trial["sharded"] <= trial["allreduce"]
         step.set_shard_optimizer(sharded)
         sync()
-        dp_autotune = dict(allreduce_ms_per_step=round(trial["allreduce"], 4), sharded_ms_per_step=round(trial["sharded"], 4),
+        dp_autotune = dict(allreduce_ms_per_step=round(trial["allreduce"], 4),
+                           sharded_ms_per_step=None if failed else round(trial["sharded"], 4),
                            chosen="sharded" if sharded else "allreduce")
+        if failed:
+            dp_autotune["sharded_error"] = failed
     prof = not args.no_prof
     every = max(1, args.prof_every)
     n_profiled = len(range(0, args.steps, every)) if prof else 0
