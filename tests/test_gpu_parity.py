@@ -1018,19 +1018,22 @@ def test_linear_entry_points_random_shapes(prec):
         lib.gdmcf_bf16_shadow_clear(None)
 
 
-def _linear_entry_points_random_shapes(lib, prec, shadows=False):
+def _linear_entry_points_random_shapes(lib, prec, shadows=False, shapes=None, seed=0):
     """shadows=True: every operand gets a registered bf16 shadow (the kernels then stream those, no edge predicates,
     zero padding) -- same reference, same tolerance."""
     from gdmcf_amd import _lib
     D = (lambda t: t.bfloat16().double()) if prec == "bf16" else (lambda t: t.double())
-    rng = np.random.default_rng(0)
+    rng = np.random.default_rng(seed)
     st = _lib.stream_ptr()
+    given = shapes
     # the first three need the element-wise kernel of gemm_small.hip in f32 (K < 4, or fewer than 4 rows of a
     # row-contiguous operand); the bf16 loaders take them as they are
     shapes = [(2, 3, 3), (4, 5, 2), (3, 2, 9), (1, 4, 4), (3, 5, 7), (16, 16, 16), (17, 33, 65), (80, 128, 32), (81, 129, 33),
               (100, 257, 36), (400, 130, 1000), (7, 1000, 515), (129, 70, 4099), (65, 64, 8195), (33, 300, 31), (5, 6, 20000)]
     if prec == "bf16":  # the last four take the 208x256 tile class (fused epilogues and weight gradients included)
         shapes += [(5, 2, 130), (200, 300, 515), (413, 1000, 700), (400, 28001, 70), (64, 1100, 28000)]
+    if given is not None:
+        shapes = given
     keep = []
     for (M, N, K) in shapes:
         for pad in (0, 3):
