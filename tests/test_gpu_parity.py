@@ -1067,7 +1067,9 @@ def _linear_entry_points_random_shapes(lib, prec, shadows=False, shapes=None, se
                                                      rowpart.data_ptr(), rowsum.data_ptr(), st))
             dref = alpha.double()[:, None] * ref - tgt.double()
             assert close(diff[:, :N].double(), dref) and close(out.double(), ref), ("loss", M, N, K, pad)
-            np.testing.assert_allclose(rowsum.cpu().numpy(), (dref ** 2).sum(1).cpu().numpy(), rtol=2e-5)
+            # (rows whose residual nearly cancels carry the f32 rounding of alpha*out - target relative to their tiny sum)
+            want_rs = (dref ** 2).sum(1).cpu().numpy()
+            np.testing.assert_allclose(rowsum.cpu().numpy(), want_rs, rtol=2e-5, atol=2e-6 * float(want_rs.max()))
             # backward wrt input: dA = rs * (dZ @ W) * (1 - act^2)
             dZ = torch.zeros(M, ldc, device=DEV); dZ[:, :N] = torch.from_numpy(rng.standard_normal((M, N)).astype(np.float32)).to(DEV)
             rs = torch.from_numpy(rng.uniform(0.5, 1.5, M).astype(np.float32)).to(DEV)
