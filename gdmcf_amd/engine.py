@@ -435,13 +435,23 @@ class DenoiserEngine:
         N, K = w.shape
         out = None
 
+        # per-step coefficient vectors [B] and timestep vectors: expanded ONCE per (schedule, batch size) into [T, B]
+        # tables whose rows are used as they stand (was 3-6 tiny launches per reverse step)
+        key = (id(tabs32), T, B)
+        if getattr(bufs, "step_tabs_key", None) != key:
+            bufs.step_tabs = {k: tabs32[k][:T, None].expand(T, B).contiguous() for k in ("c1", "c2", "r1", "r2", "sigma")
+                              if k in tabs32}
+            bufs.step_ts = torch.arange(T, dtype=torch.int64, device=dev)[:, None].expand(T, B).contiguous()
+            bufs.step_tabs_key = key
+        stabs, step_ts = bufs.step_tabs, bufs.step_ts
+
         def posterior(i, n, A, lda, xt, xn):
-            c1, c2 = tabs32["c1"][i].expand(B).contiguous(), tabs32["c2"][i].expand(B).contiguous()
+            c1, c2 = stabs["c1"][i], stabs["c2"][i]
             r1 = r2 = sg = z = None
             if eps_mode:
-                r1, r2 = tabs32["r1"][i].expand(B).contiguous(), tabs32["r2"][i].expand(B).contiguous()
+                r1, r2 = stabs["r1"][i], stabs["r2"][i]
             if sampling_noise and i != 0:
-                sg = tabs32["sigma"][i].expand(B).contiguous()
+                sg = stabs["sigma"][i]
                 z = step_noise[n] if step_noise is not None else torch.randn(B, I, dtype=torch.float32, device=dev)
                 z = z.contiguous()
             pred = torch.empty(B, I, dtype=torch.float32, device=dev) if capture is not None else None
@@ -462,7 +472,7 @@ class DenoiserEngine:
             cur, nxt = bufs.xin, bufs.xin2
             keep.append(self._prep(bufs, x_start, t_vec, ca, cb, noise0, None, False, xin=cur))  # x_T
             for n, i in enumerate(range(T - 1, -1, -1)):
-                ts = torch.full((B,), i, dtype=torch.int64, device=dev)
+                ts = step_ts[i]
                 _lib.check(lib.gdmcf_dnn_emb_cols_f32(ts.data_ptr(), m.emb_layer.weight.data_ptr(),
                                                       m.emb_layer.bias.data_ptr(), self.E, B, I, cur.data_ptr(),
                                                       cur.stride(0), bufs.temb.data_ptr(), st))
@@ -478,7 +488,7 @@ class DenoiserEngine:
             xt = bufs.xt
             keep.append(self._prep(bufs, x_start, t_vec, ca, cb, noise0, None, False, xt_out=xt, xin=bufs.xin2))
             for n, i in enumerate(range(T - 1, -1, -1)):
-                ts = torch.full((B,), i, dtype=torch.int64, device=dev)
+                ts = step_ts[i]
                 keep.append(self._prep(bufs, xt[:, :I], ts, None, None, None, None, False, xin=bufs.xin))
                 A, lda = self._hidden_forward(bufs, layers, B, xin=bufs.xin)
                 out = torch.empty(B, I, dtype=torch.float32, device=dev) if i == 0 else None
