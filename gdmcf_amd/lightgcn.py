@@ -1,9 +1,11 @@
 """LightGCN embedding propagation with the reference's interface (reference lightGCN.py:129-203).
 
 `get_A_tilda` builds the symmetric-normalised bipartite adjacency D^-1/2 A D^-1/2 once on the host
-(float32, as the reference), keeps it on the GPU as CSR and builds the execution plan that splits hub
-rows into virtual rows; `propagate_through_layers` runs the n_layers SpMMs in the HIP kernel
-gdmcf_spmm_csr_f32 with the layer mean fused into the last layer's epilogue.
+(float32, as the reference), keeps it on the GPU as CSR and builds the static schedule of the SpMM
+(spmm_bundle_plan: equal-cost runs of row bundles and hub-row pieces, one per resident wave; spmm_plan, the
+first-generation virtual-row plan, for widths the bundled kernel does not take); `propagate_through_layers`
+runs the n_layers SpMMs in the HIP kernel gdmcf_spmm_bundled_f32 (one launch per layer) with the layer mean
+fused into the last layer's epilogue.
 Only the forward propagation is on the hot path; BPR training is a
 "next" row (8f3), so E0 gradients are not produced here.
 """
@@ -74,6 +76,143 @@ def spmm_plan(indptr, chunk=SPMM_CHUNK, short=SPMM_SHORT, d=64):
                 lrow=lrow, lptr=lptr, n_slots=int(cut.sum()), n_short=int(len(srows)))
 
 
+SPMM_SMAX = int(os.environ.get("GDMCF_SPMM_SMAX", "64"))  # rows up to this many nonzeros are bundled G to a wave-step
+SPMM_PIECE = int(os.environ.get("GDMCF_SPMM_PIECE", "256"))  # longer rows are cut into pieces of at most this many
+SPMM_WAVES = int(os.environ.get("GDMCF_SPMM_WAVES", "4096"))  # 256 CUs x 16 resident waves, all started at once
+SPMM_COST_ROW = int(os.environ.get("GDMCF_SPMM_COST_ROW", "8"))  # fixed cost of a bundled row / of a piece, in nonzeros
+SPMM_COST_PIECE = int(os.environ.get("GDMCF_SPMM_COST_PIECE", "32"))
+SPMM_HOT_MB = float(os.environ.get("GDMCF_SPMM_HOT_MB", "2.0"))  # part of an XCD's L2 the bundled rows' hot columns can keep
+SPMM_NT = int(os.environ.get("GDMCF_SPMM_NT", "0"))  # streaming loads for bundles that gather mostly cold rows
+SPMM_MISS_W = float(os.environ.get("GDMCF_SPMM_MISS_W", "3.0"))  # cost of a gather served beyond L2, in L2-hit gathers
+
+
+def spmm_bundle_plan(indptr, indices, d=64, n_waves=None, s_max=None, piece=None, classes=8, n_cols=None):
+    """Static schedule for gdmcf_spmm_bundled_f32 (include/gdmcf_hip.h; kernel csrc/spmm_bundle.hip).
+
+    Work units: every row of at most s_max nonzeros ("short"), and the pieces (<= piece nonzeros, equal parts) of every
+    longer row.  Class c (of `classes` = 8) is served by the blocks b with b % 8 == c, i.e. by ONE XCD and its 4 MiB L2:
+    (1) the column space is cut into 8 ranges holding equal numbers of the long rows' nonzeros; a long row is cut where
+        it crosses a range boundary (CSR rows are sorted) and class = range: the pieces of a class gather 1/8 of the
+        table (2-3 MB at the Yelp shape: L2 resident), at the price of one 256-byte partial per piece;
+    (2) the short rows are sorted by length (longest first) and dealt to the classes bundle by bundle (G = 64/(d/4) rows
+        of the same length share a wave-step, so the lane groups of a wave finish together); every class gets the same
+        mix, so the gathers that miss L2 load the eight fabric links equally;
+    (3) the class's pieces + bundles are cut into n_waves/8 contiguous runs of equal cost, one per wave.
+    Cost = nonzeros (those to a column outside the `SPMM_HOT_MB` most gathered megabytes of the table count SPMM_MISS_W
+    times: they are served by the Infinity Cache at a third of the L2 rate) + a fixed overhead per row / piece.
+    Rows cut into several pieces get consecutive partial slots (crow / cptr), added up in slot order afterwards."""
+    s_max = SPMM_SMAX if s_max is None else s_max
+    piece = SPMM_PIECE if piece is None else piece
+    indptr = np.asarray(indptr, dtype=np.int64)
+    indices = np.asarray(indices)
+    deg = np.diff(indptr)
+    lpr = d // 4
+    if d % 4 != 0 or lpr not in (2, 4, 8, 16, 32, 64):
+        raise ValueError("spmm_bundle_plan: d must be one of 8, 16, 32, 64, 128, 256")
+    G = 64 // lpr
+    n_cols = int(indices.max()) + 1 if (n_cols is None and len(indices)) else int(n_cols or 1)
+    # ---- which gathers can hit: the most gathered rows of the table, as many as fit beside the pieces' slice ----
+    ccount = np.bincount(indices, minlength=n_cols)
+    n_hot = int(SPMM_HOT_MB * 1e6 // (d * 4))
+    if n_hot < n_cols:
+        thresh = np.partition(ccount, n_cols - n_hot)[n_cols - n_hot]
+        cold = (ccount < max(thresh, 1))[indices]
+    else:
+        cold = np.zeros(len(indices), bool)
+    csum = np.concatenate([[0], np.cumsum(cold, dtype=np.int64)])
+    ncold = csum[indptr[1:]] - csum[indptr[:-1]]  # per row
+    wdeg = deg + (SPMM_MISS_W - 1.0) * ncold  # weighted nonzeros
+    srows = np.nonzero(deg <= s_max)[0]
+    lrows = np.nonzero(deg > s_max)[0]
+    # ---- (1) pieces of the long rows: cut where the row crosses one of `classes` column ranges (each holding the same
+    # number of the long rows' nonzeros), then into equal parts of <= piece nonzeros; class = the range ----
+    lmask = np.zeros(len(deg), bool)
+    lmask[lrows] = True
+    row_of = np.repeat(np.arange(len(deg)), deg)
+    lidx = np.nonzero(lmask[row_of])[0]  # CSR positions of the long rows' nonzeros, in CSR order
+    if len(lidx):
+        lr, lc = row_of[lidx], indices[lidx]
+        bounds = np.quantile(lc, np.arange(1, classes) / classes, method="lower").astype(np.int64)
+        rng = np.searchsorted(bounds, lc, side="left")  # 0 .. classes-1, non-decreasing along a (sorted) row
+        start = np.concatenate([[True], (lr[1:] != lr[:-1]) | (rng[1:] != rng[:-1])])
+        rs = np.nonzero(start)[0]  # runs: (row, range)
+        rlen = np.diff(np.concatenate([rs, [len(lidx)]]))
+        rbeg, rrow, rrng = lidx[rs], lr[rs], rng[rs]
+        npc = -(-rlen // piece)  # parts per run
+        psz = -(-rlen // npc)
+        n_p = int(npc.sum())
+        first = np.cumsum(npc) - npc
+        k = np.arange(n_p, dtype=np.int64) - np.repeat(first, npc)
+        pbeg = np.repeat(rbeg, npc) + k * np.repeat(psz, npc)
+        plen = np.minimum(np.repeat(psz, npc), np.repeat(rbeg + rlen, npc) - pbeg).astype(np.int64)
+        prow = np.repeat(rrow, npc)
+        pcls = np.repeat(rrng, npc)
+        ppr = np.bincount(prow, minlength=len(deg))  # pieces per row
+        cut = ppr[prow] > 1
+        pslot = np.full(n_p, -1, dtype=np.int64)
+        pslot[cut] = np.arange(int(cut.sum()))  # CSR order: the slots of a row are consecutive
+        crow = np.nonzero(ppr > 1)[0].astype(np.int32)
+        cptr = np.concatenate([[0], np.cumsum(ppr[crow])]).astype(np.int32)
+    else:
+        n_p = 0
+        pbeg = plen = prow = pcls = pslot = np.zeros(0, np.int64)
+        cut = np.zeros(0, bool)
+        crow, cptr = np.zeros(0, np.int32), np.zeros(1, np.int32)
+    ptot = float((plen + float(SPMM_COST_PIECE)).sum())
+    pord = np.lexsort((pbeg, pcls))  # class-major, CSR order inside
+    P = dict(beg=pbeg[pord], len=plen[pord], row=prow[pord], slot=pslot[pord], cls=pcls[pord])
+    # (2) short rows: longest first, dealt to the classes bundle by bundle
+    sord = np.lexsort((srows, -deg[srows]))
+    s_sorted = srows[sord]
+    n_s = len(s_sorted)
+    scls_sorted = (np.arange(n_s) // G) % classes
+    sord2 = np.argsort(scls_sorted, kind="stable")  # class-major, still longest first inside a class
+    s_row, s_cls = s_sorted[sord2], scls_sorted[sord2]
+    ncls_rows = np.bincount(s_cls, minlength=classes)
+    nb_cls = -(-ncls_rows // G)  # bundles per class (last one padded)
+    n_b = int(nb_cls.sum())
+    b_first = np.cumsum(nb_cls) - nb_cls
+    r_first = np.cumsum(ncls_rows) - ncls_rows
+    pos = np.arange(n_s) - r_first[s_cls]  # position of the row inside its class
+    ent = b_first[s_cls] * G + pos  # entry index in the bundle arrays
+    sbeg = np.zeros(n_b * G, dtype=np.int64)
+    slen = np.zeros(n_b * G, dtype=np.int32)
+    srow = np.full(n_b * G, -1, dtype=np.int32)
+    swd = np.zeros(n_b * G, dtype=np.float64)
+    sbeg[ent], slen[ent], srow[ent], swd[ent] = indptr[s_row], deg[s_row], s_row, wdeg[s_row]
+    smax = slen.reshape(n_b, G).max(axis=1).astype(np.int32) if n_b else np.zeros(0, np.int32)
+    if n_b and SPMM_NT:  # bit 30: most of the bundle's gathers go to rarely gathered rows -> streaming (nt) loads
+        scold = np.zeros(n_b * G)
+        scold[ent] = ncold[s_row]
+        smax = smax | ((scold.reshape(n_b, G).sum(1) > 0.5 * slen.reshape(n_b, G).sum(1)).astype(np.int32) << 30)
+    bcost = (swd.reshape(n_b, G).max(axis=1) + float(SPMM_COST_ROW)) * G if n_b else np.zeros(0)
+    total = ptot + float(bcost.sum())
+    if n_waves is None:
+        n_waves = int(min(SPMM_WAVES, max(32, -(-int(total) // 4096) * 32)))  # >= ~128 cost units per wave
+    wpc = n_waves // classes
+    assert n_waves % (4 * classes) == 0
+    # (3) per class: equal-cost contiguous runs, one per wave
+    wdesc = np.zeros((n_waves, 4), dtype=np.int32)
+    np_cls = np.bincount(P["cls"], minlength=classes)
+    p_first = np.cumsum(np_cls) - np_cls
+    for c in range(classes):
+        pc = P["len"][p_first[c]:p_first[c] + np_cls[c]] + float(SPMM_COST_PIECE)
+        bc = bcost[b_first[c]:b_first[c] + nb_cls[c]]
+        cc = np.cumsum(np.concatenate([pc, bc]))
+        tot = cc[-1] if len(cc) else 0.0
+        bounds = np.searchsorted(cc, tot * np.arange(1, wpc) / wpc, side="left") if len(cc) else np.zeros(wpc - 1, np.int64)
+        edges = np.maximum.accumulate(np.concatenate([[0], bounds, [len(cc)]]).astype(np.int64))
+        a, b = edges[:-1], edges[1:]
+        nP = int(np_cls[c])
+        wdesc[c * wpc:(c + 1) * wpc, 0] = p_first[c] + np.minimum(a, nP)
+        wdesc[c * wpc:(c + 1) * wpc, 1] = p_first[c] + np.minimum(b, nP)
+        wdesc[c * wpc:(c + 1) * wpc, 2] = b_first[c] + np.maximum(a - nP, 0)
+        wdesc[c * wpc:(c + 1) * wpc, 3] = b_first[c] + np.maximum(b - nP, 0)
+    return dict(wdesc=wdesc.reshape(-1), n_waves=int(n_waves), lbeg=P["beg"].astype(np.int64), llen=P["len"].astype(np.int32),
+                lrow=P["row"].astype(np.int32), lslot=P["slot"].astype(np.int32), n_pieces=n_p, sbeg=sbeg, slen=slen, srow=srow,
+                smax=smax, n_bundles=n_b, crow=crow, cptr=cptr, n_slots=int(cut.sum()), G=G)
+
+
 class LightGCN(nn.Module):
     def __init__(self, data, n_users, n_items, n_layers, latent_dim, device="cuda", shard_rows=False, group=None):
         """data: DataFrame/dict with `user_id_idx` / `item_id_idx` columns (reference :147).
@@ -113,7 +252,10 @@ class LightGCN(nn.Module):
         if self._world > 1:
             lo, hi = int(indptr[r0]), int(indptr[r1])
             indptr, indices, vals = indptr[r0:r1 + 1] - indptr[r0], indices[lo:hi], vals[lo:hi]
-        plan = spmm_plan(indptr, d=self.latent_dim)
+        lpr = self.latent_dim // 4
+        self._bundled = (self.latent_dim % 4 == 0 and lpr in (2, 4, 8, 16, 32, 64) and
+                         indices.size > 0 and os.environ.get("GDMCF_SPMM_GEN", "1") != "1")
+        plan = spmm_bundle_plan(indptr, indices, d=self.latent_dim, n_cols=N) if self._bundled else spmm_plan(indptr, d=self.latent_dim)
         self._plan = {k: (torch.from_numpy(v).to(dev) if isinstance(v, np.ndarray) else v) for k, v in plan.items()}
         self._partial = torch.empty(max(plan["n_slots"], 1), self.latent_dim, dtype=torch.float32, device=dev)
         self.nnz = int(indices.size)
@@ -136,7 +278,7 @@ class LightGCN(nn.Module):
         st = _lib.stream_ptr()
         cur = X.contiguous()
         layers = [cur]
-        nv, nl = pl["vrow"].numel(), pl["lrow"].numel()
+        nv, nl = (0, 0) if self._bundled else (pl["vrow"].numel(), pl["lrow"].numel())
         r0, r1, rpr = self._rows
         sharded = self._world > 1
         for layer in range(self.n_layers):
@@ -145,7 +287,15 @@ class LightGCN(nn.Module):
             adds = layers if last else []
             # the fused layer mean reads this rank's rows of the earlier layers
             arr = (ctypes.c_void_p * max(len(adds), 1))(*[a.data_ptr() + r0 * a.stride(0) * 4 for a in adds])
-            if r1 > r0:
+            if r1 > r0 and self._bundled:
+                opt = lambda t: t.data_ptr() if t.numel() else None
+                _lib.check(lib.gdmcf_spmm_bundled_f32(
+                    pl["wdesc"].data_ptr(), pl["n_waves"], opt(pl["lbeg"]), opt(pl["llen"]), opt(pl["lrow"]), opt(pl["lslot"]),
+                    pl["n_pieces"], opt(pl["sbeg"]), opt(pl["slen"]), opt(pl["srow"]), opt(pl["smax"]), pl["n_bundles"],
+                    opt(pl["crow"]), pl["cptr"].data_ptr(), pl["crow"].numel(), indices.data_ptr(), vals.data_ptr(),
+                    indices.numel(), r1 - r0, N, cur.data_ptr(), cur.stride(0), d, out.data_ptr(), out.stride(0), self._partial.data_ptr(), arr,
+                    len(adds), cur.stride(0), 1.0 / (self.n_layers + 1) if last else 1.0, self.algorithmic_bytes(), st))
+            elif r1 > r0:
                 _lib.check(lib.gdmcf_spmm_csr_f32(
                     pl["vbeg"].data_ptr(), pl["vend"].data_ptr(), pl["vrow"].data_ptr(), pl["vslot"].data_ptr(), nv,
                     pl["n_short"], _lib.ptr(pl["lrow"]) if nl else None,

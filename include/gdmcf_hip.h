@@ -315,6 +315,24 @@ int gdmcf_spmm_csr_f32(const int64_t* vbeg, const int64_t* vend, const int32_t* 
                        const float* val, int n_rows, const float* X, int64_t ldx, int d, float* Y,
                        int64_t ldy, float* partial_ws, const float* const* addends_host, int n_add,
                        int64_t ld_add, float scale, double alg_bytes, void* stream);
+/* Second-generation schedule of the same product (one launch per layer; csrc/spmm_bundle.hip), for d in
+ * {8,16,32,64,128,256} with 16-byte aligned rows.  The host plan (gdmcf_amd/lightgcn.py:spmm_bundle_plan) sorts the rows
+ * of at most s_max nonzeros by length and bundles them G = 64/(d/4) to a wave-step, cuts longer rows into pieces, and
+ * gives every one of n_waves waves (a multiple of 32; block b = 4 waves serves class b % 8 = one XCD) a contiguous run
+ * of pieces and bundles of equal cost:
+ *   wdesc int32 [n_waves][4]   first / last+1 piece and first / last+1 bundle of the wave (class-major order)
+ *   lbeg int64, llen/lrow/lslot int32 [n_pieces]   first nonzero, length, row, partial slot (-1: the row is whole)
+ *   sbeg int64, slen/srow int32 [n_bundles*G], smax int32 [n_bundles]   per bundle entry: first nonzero, length, row
+ *                                                  (-1 = padding), and the longest length of the bundle
+ *   crow int32 [n_cut], cptr int32 [n_cut+1]       rows cut into several pieces and their slot ranges in partial_ws
+ * nnz = length of col / val (> 0), n_x_rows = rows of X (columns of the matrix).  Everything else as
+ * gdmcf_spmm_csr_f32.  Returns GDMCF_E_UNSUPPORTED for other widths / alignments.               */
+int gdmcf_spmm_bundled_f32(const int32_t* wdesc, int n_waves, const int64_t* lbeg, const int32_t* llen, const int32_t* lrow,
+                           const int32_t* lslot, int n_pieces, const int64_t* sbeg, const int32_t* slen, const int32_t* srow,
+                           const int32_t* smax, int n_bundles, const int32_t* crow, const int32_t* cptr, int n_cut,
+                           const int32_t* col, const float* val, int64_t nnz, int n_rows, int n_x_rows, const float* X,
+                           int64_t ldx, int d, float* Y, int64_t ldy, float* partial_ws, const float* const* addends_host, int n_add, int64_t ld_add,
+                           float scale, double alg_bytes, void* stream);
 /* out = acc * scale */
 int gdmcf_scale_f32(const float* acc, int64_t n, float scale, float* out, void* stream);
 

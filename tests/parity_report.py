@@ -101,7 +101,7 @@ for case in H.ONEHOT_TRAIN_CASES:
     fx = H.load("onehot_train_" + case)
     meta = H.onehot_train_meta(fx)
     I, dims = meta["I"], meta["dims"]
-    model = gdmcf_amd.DNNOneHot([I] + dims, dims[::-1] + [I], 10)
+    model = gdmcf_amd.DNNOneHot([I] + dims, dims[::-1] + [I], meta.get("emb", 10), norm=meta.get("norm", False))
     model.load_state_dict(H.state_dict_from(fx))
     model = model.to(DEV).train()
     mt = {"x0": ModelMeanType.START_X, "eps": ModelMeanType.EPSILON}[meta["mean_type"]]

@@ -52,6 +52,22 @@ def test_schedule_errors_follow_reference_conventions():
         gdmcf_amd.GaussianDiffusion(gdmcf_amd.ModelMeanType.START_X, "nope", 0.1, 0.001, 0.01, 5, "cpu")
 
 
+def test_product_normal_kl_matches_reference_vector():
+    """gdmcf_amd.gaussian_diffusion.normal_kl (reference gaussian_diffusion.py:1165-1192, a utility: dead code there,
+    SURVEY F10) against the KL vector the reference itself produced (schedules.npz `kl.*`), tensor and scalar forms."""
+    from gdmcf_amd.gaussian_diffusion import normal_kl
+    fx = H.load("schedules")
+    m1, lv1, m2, lv2 = [torch.from_numpy(fx[f"kl.{k}"]) for k in ("m1", "lv1", "m2", "lv2")]
+    np.testing.assert_array_equal(normal_kl(m1, lv1, m2, lv2).numpy(), fx["kl.out"])
+    # scalar log-variances are promoted to the tensor's dtype (reference :1181-1184)
+    a = normal_kl(m1, 0.25, m2, -0.5).numpy()
+    b = normal_kl(m1, torch.full_like(m1, 0.25), m2, torch.full_like(m1, -0.5)).numpy()
+    np.testing.assert_array_equal(a, b)
+    assert np.abs(normal_kl(m1, lv1, m1, lv1).numpy()).max() < 1e-6  # KL(p || p) = 0 up to f32 rounding
+    with pytest.raises(AssertionError):
+        normal_kl(0.0, 0.0, 1.0, 0.0)
+
+
 def test_diffusion_object_surface_and_weights():
     fx = H.load("schedules")
     d = gdmcf_amd.GaussianDiffusion(gdmcf_amd.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, 5, "cpu")
@@ -247,6 +263,87 @@ def test_spmm_plan_covers_every_nonzero_once(d):
         Y[r] = partial[pl["lptr"][i]:pl["lptr"][i + 1]].sum(0)
     np.testing.assert_allclose(Y, A @ X, rtol=1e-12, atol=1e-12)
     assert 8 in pl["lrow"] and 9 not in pl["lrow"] and len(pl["lptr"]) == len(pl["lrow"]) + 1  # only cut rows combine
+
+
+@pytest.mark.parametrize("d,n_waves", [(64, 32), (64, 64), (16, 32), (256, 32), (8, 32)])
+def test_spmm_bundle_plan_is_a_partition_of_the_work(d, n_waves):
+    """Static schedule of gdmcf_spmm_bundled_f32 (gdmcf_amd/lightgcn.py:spmm_bundle_plan), emulated in numpy wave by wave
+    exactly as csrc/spmm_bundle.hip walks it: every nonzero is gathered exactly once, every row is written exactly once
+    (whole rows by their wave, cut rows from their partial slots in slot order), bundles hold rows of the same class
+    sorted by length, the waves of a class own contiguous runs, empty rows still get written."""
+    import scipy.sparse as sp
+    from gdmcf_amd.lightgcn import spmm_bundle_plan
+    rng = np.random.default_rng(d + n_waves)
+    n, m = 257, 190
+    deg = np.minimum(rng.zipf(1.6, n), m)
+    deg[5], deg[6], deg[7] = 0, m, 150  # an empty row, a full row, a long one
+    rows = np.repeat(np.arange(n), deg)
+    cols = np.concatenate([np.sort(rng.choice(m, k, replace=False)) for k in deg])
+    A = sp.csr_matrix((rng.standard_normal(len(rows)), (rows, cols)), shape=(n, m))
+    A.sort_indices()
+    X = rng.standard_normal((m, d))
+    s_max, piece = 12, 40
+    pl = spmm_bundle_plan(A.indptr, A.indices, d=d, n_waves=n_waves, s_max=s_max, piece=piece)
+    G = pl["G"]
+    assert G == 64 // (d // 4) and pl["n_waves"] == n_waves
+    wd = pl["wdesc"].reshape(n_waves, 4)
+    wpc = n_waves // 8
+    cover = np.zeros(A.nnz, int)
+    written = np.zeros(n, int)
+    Y = np.full((n, d), np.nan)
+    partial = np.full((max(pl["n_slots"], 1), d), np.nan)
+    seen_p, seen_b = np.zeros(pl["n_pieces"], int), np.zeros(pl["n_bundles"], int)
+    for w in range(n_waves):
+        l0, l1, s0, s1 = wd[w]
+        assert l0 <= l1 and s0 <= s1
+        if w % wpc:  # contiguous runs inside a class
+            assert l0 == wd[w - 1][1] and s0 == wd[w - 1][3]
+        for p in range(l0, l1):
+            seen_p[p] += 1
+            b, ln, r = pl["lbeg"][p], pl["llen"][p], pl["lrow"][p]
+            assert 0 < ln <= piece and A.indptr[r] <= b and b + ln <= A.indptr[r + 1]
+            cover[b:b + ln] += 1
+            acc = (A.data[b:b + ln, None] * X[A.indices[b:b + ln]]).sum(0)
+            if pl["lslot"][p] >= 0:
+                partial[pl["lslot"][p]] = acc
+            else:
+                Y[r] = acc
+                written[r] += 1
+        for bd in range(s0, s1):
+            seen_b[bd] += 1
+            lens = pl["slen"][bd * G:(bd + 1) * G]
+            assert pl["smax"][bd] & 0x3FFFFFFF == lens.max()  # bit 30 = streaming-load hint
+            for e in range(bd * G, (bd + 1) * G):
+                r = pl["srow"][e]
+                if r < 0:
+                    assert pl["slen"][e] == 0
+                    continue
+                b, ln = pl["sbeg"][e], pl["slen"][e]
+                assert b == A.indptr[r] and ln == A.indptr[r + 1] - A.indptr[r] and ln <= s_max
+                cover[b:b + ln] += 1
+                Y[r] = (A.data[b:b + ln, None] * X[A.indices[b:b + ln]]).sum(0)
+                written[r] += 1
+    assert (seen_p == 1).all() and (seen_b == 1).all() and (cover == 1).all()
+    for i, r in enumerate(pl["crow"]):
+        sl = partial[pl["cptr"][i]:pl["cptr"][i + 1]]
+        assert len(sl) >= 2 and not np.isnan(sl).any()
+        Y[r] = sl.sum(0)
+        written[r] += 1
+    assert (written == 1).all()
+    np.testing.assert_allclose(Y, A @ X, rtol=1e-12, atol=1e-12)
+    assert 6 in pl["crow"] and 7 in pl["crow"] and 5 not in pl["crow"] and (Y[5] == 0).all()
+    # a piece never crosses a column-range boundary: the pieces of one class gather from one slice of the table
+    lo = np.array([A.indices[b] for b in pl["lbeg"]]); hi = np.array([A.indices[b + n - 1] for b, n in zip(pl["lbeg"], pl["llen"])])
+    pcls = np.searchsorted(wd[::wpc, 0], np.arange(pl["n_pieces"]), side="right") - 1  # class of a piece from the wave table
+    for c in range(7):
+        if (pcls == c).any() and (pcls > c).any():
+            assert hi[pcls == c].max() <= lo[pcls > c].min()
+    # classes hold equal shares of the cost (mean-column order), waves of a class equal shares of the class
+    lc = np.concatenate([[0], np.cumsum(pl["llen"] + 32)])
+    sc = np.concatenate([[0], np.cumsum(((pl["smax"] & 0x3FFFFFFF) + 8) * G)])
+    cost = (lc[wd[:, 1]] - lc[wd[:, 0]]) + (sc[wd[:, 3]] - sc[wd[:, 2]])
+    per_class = cost.reshape(8, wpc).sum(1)
+    assert per_class.max() <= 1.5 * per_class.mean() + (piece + 32)
 
 
 def test_header_is_plain_c(tmp_path):
