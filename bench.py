@@ -41,25 +41,26 @@ PEAK_HBM_GBPS = 8000.0
 TAGS = {1: "linear_fwd_gemm", 2: "loss_fwd_gemm", 3: "posterior_gemm", 4: "bwd_input_gemm", 5: "bwd_weight_gemm",
         6: "adamw", 7: "prep_input", 8: "spmm_csr", 9: "topk", 10: "onehot_noise"}
 GEMM_TAGS = (1, 2, 3, 4, 5)
-# rocprofv3 kernel names of the tagged launches at the Yelp-shape workload (for the PMC traffic lookup)
-TRAFFIC_KERNEL = {"bwd_weight_gemm": "gemm_f32_spec_kernel<1, 1, 128, 128, 16, 2, 2, 4, 2>",
-                  "loss_fwd_gemm": "gemm_f32_kernel<0, 0, 80, 128, 32, 1, 4, 2>",
-                  "bwd_input_gemm": "gemm_f32_kernel<0, 1, 80, 128, 32, 1, 4, 0>",
-                  "linear_fwd_gemm": "gemm_f32_kernel<0, 0, 80, 128, 32, 1, 4, 0>", "adamw": "adamw_kernel<true>",
-                  "prep_input": "prep_input_kernel"}
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_final_hbm_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
 
 
 def measured_traffic(kernel_tag, workload, gemm_dtype="f32"):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE and
-    WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950 note; profiles/summarize.py).  PMC counters
-    cannot be collected from inside the process, so this is a lookup; None when no profile matches."""
-    if workload != "yelp" or gemm_dtype != "f32" or kernel_tag not in TRAFFIC_KERNEL or not os.path.exists(TRAFFIC_FILE):
-        return None
-    for row in json.load(open(TRAFFIC_FILE)):
-        if row["kernel"] == TRAFFIC_KERNEL[kernel_tag]:
-            return int(row["hbm_total_MB"] * 1e6)
-    return None
+    """HBM bytes per launch of the kernel behind `kernel_tag`, from the committed rocprofv3 PMC passes of this same
+    command (FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950 note): profiles/summarize.py
+    writes one row per bench tag (kernel names are mapped to tags there, by layout / epilogue template arguments, not by
+    tile sizes).  PMC counters cannot be collected from inside the process, so this is a lookup -- and it says so loudly
+    when the profile has no row for the kernel instead of silently reporting null.  Returns (bytes or None, note)."""
+    if not os.path.exists(TRAFFIC_FILE):
+        return None, f"no {os.path.relpath(TRAFFIC_FILE, ROOT)}"
+    prof = json.load(open(TRAFFIC_FILE))
+    if prof.get("workload") != workload or prof.get("gemm_dtype") != gemm_dtype:
+        return None, f"profile is for {prof.get('workload')}/{prof.get('gemm_dtype')}, this run is {workload}/{gemm_dtype}"
+    row = prof.get("tags", {}).get(kernel_tag)
+    if row is None:
+        msg = f"{os.path.relpath(TRAFFIC_FILE, ROOT)} has no row for tag '{kernel_tag}' (re-run tools/profile_round.sh)"
+        print(f"[bench] WARNING: roofline.traffic unavailable: {msg}", file=sys.stderr)
+        return None, msg
+    return int(row["hbm_total_MB"] * 1e6), f"{row['kernel']} ({row['launches']} launches profiled)"
 
 
 def parse():
@@ -77,11 +78,21 @@ def parse():
                     help="input precision of the denoiser GEMMs (bf16 = BASELINE configs[2]; f32 is the parity path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu-1thread", action="store_true", help="skip the one-thread CPU step (tens of seconds)")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--prof-every", type=int, default=4,
                     help="bracket the tagged launches of every Nth timed step with HIP events (an event pair keeps the next "
                          "kernel from starting under the tail of the previous one: every step costs +3 %%, every 4th <1 %%)")
-    ap.add_argument("--spmm", action="store_true", help="also time the LightGCN SpMM (reported under 'spmm')")
+    ap.add_argument("--spmm", action="store_true", help="(default on) time the LightGCN SpMM, reported under 'spmm'")
+    ap.add_argument("--no-spmm", action="store_true", help="skip the LightGCN SpMM leg")
+    ap.add_argument("--spmm-sharded", action="store_true",
+                    help="N > 1: row-shard the adjacency over the ranks (local SpMM + all-gather per layer) instead of timing "
+                         "the replica on rank 0")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling as the main line: global batch 400 (BASELINE configs[3]) split over the ranks; without "
+                         "it the main line is weak scaling (400 rows per rank) and at N > 1 a short strong-scaling leg is "
+                         "reported under 'strong_scaling'")
+    ap.add_argument("--no-strong-leg", action="store_true", help="N > 1: skip the extra strong-scaling leg")
     ap.add_argument("--fuse-optimizer", action="store_true",
                     help="single GPU: update the two large weights inside the weight-gradient GEMM epilogue "
                          "(FusedAdamW.fuse_into_backward); same update rule, gradient never materialised")
@@ -101,8 +112,15 @@ def parse():
                          "happens by default when N > 1 and neither variant is requested)")
     ap.add_argument("--allreduce-optimizer", action="store_true",
                     help="N > 1: all-reduce of the gradients + full AdamW on every rank instead of the sharded optimiser")
-    ap.add_argument("--sampling", action="store_true", help="also time p_sample + masked top-k (reported under 'sampling')")
-    return ap.parse_args()
+    ap.add_argument("--sampling", action="store_true", help="(default on) time p_sample + masked top-k, reported under 'sampling'")
+    ap.add_argument("--no-sampling", action="store_true", help="skip the evaluation-path leg")
+    args = ap.parse_args()
+    if args.strong and not args.global_batch:
+        args.global_batch = 400
+    default_line = args.backbone == "dnn" and not args.rehearse_dp
+    args.spmm = (args.spmm or default_line) and not args.no_spmm
+    args.sampling = (args.sampling or default_line) and not args.no_sampling
+    return args
 
 
 def collect_prof(lib, cap=65536):
@@ -150,17 +168,89 @@ def cpu_baseline(args, I, x_batches, seconds):
         el = time.perf_counter() - t0
         if (el >= seconds and n >= 3) or n >= 50:
             break
-    return dict(value=round(Bc * n / el, 2), unit="users/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"{n} train steps of B={Bc}, I={I}, dims=[{args.hidden}], T={args.T} (oracle, PyTorch-CPU eager)",
-                ms_per_step=round(1e3 * el / n, 2))
+    threads = torch.get_num_threads()
+    out = dict(value=round(Bc * n / el, 2), unit="users/s", cores=threads, kind="port",
+               sample=f"{n} train steps of B={Bc}, I={I}, dims=[{args.hidden}], T={args.T} (oracle, PyTorch-CPU eager, "
+                      f"one process, {threads} intra-op threads)",
+               ms_per_step=round(1e3 * el / n, 2), physical_cores=physical_cores(), logical_cpus=os.cpu_count())
+    if not args.no_cpu_1thread:
+        # orientation figure: the same step on ONE thread, one step only (it takes tens of seconds)
+        torch.set_num_threads(1)
+        t1 = time.perf_counter()
+        O.train_step(od, om, opt, xs[0], True, **extra)
+        e1 = time.perf_counter() - t1
+        torch.set_num_threads(threads)
+        out["one_thread"] = dict(value=round(Bc / e1, 2), unit="users/s", ms_per_step=round(1e3 * e1, 1), sample="1 train step")
+    return out
+
+
+def physical_cores():
+    """distinct (physical id, core id) pairs of /proc/cpuinfo; None when the file does not say"""
+    try:
+        seen, phys = set(), None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("physical id"):
+                phys = ln.split(":")[1].strip()
+            elif ln.startswith("core id"):
+                seen.add((phys, ln.split(":")[1].strip()))
+        return len(seen) or None
+    except OSError:
+        return None
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: this parent -- which never touches the GPU -- starts N fresh child
+    processes (one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set), relays rank 0's JSON line and fails
+    loudly when a rank fails or fewer than N GPUs are visible."""
+    import socket
+    import subprocess
+    n = args.gpus
+    have = torch.cuda.device_count()  # counting devices does not initialise the GPU on this image
+    if have < n and not os.environ.get("GDMCF_BENCH_DRY_RUN"):
+        raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible; refusing to report an N-GPU line from fewer ranks")
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    codes = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    if any(codes):
+        raise SystemExit(f"bench.py --gpus {n}: rank exit codes {codes}")
+    lines = [ln for ln in out0.splitlines() if ln.startswith("{")]
+    if not lines or json.loads(lines[-1]).get("n_gpus") != n:
+        raise SystemExit(f"bench.py --gpus {n}: rank 0 did not report n_gpus == {n}")
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and not args.rehearse_dp:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python bench.py --gpus N starts them itself)")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
+    if os.environ.get("GDMCF_BENCH_DRY_RUN"):
+        # launcher rehearsal on a box without GPUs (tests/test_host_cpu.py): the ranks meet in a gloo group, nothing is timed
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        one = torch.ones(1)
+        dist.all_reduce(one)
+        if rank == 0:
+            print(json.dumps({"metric": "training users/sec", "value": None, "n_gpus": world, "dry_run": True,
+                              "ranks_in_group": int(one.item())}))
+        dist.destroy_process_group()
+        return
     if world > 1 or args.rehearse_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -301,6 +391,25 @@ def main():
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         in_sync = bool(torch.equal(lo, hi))
 
+    # ---- N > 1: strong-scaling leg (BASELINE configs[3] as stated: global batch 400 split over the ranks) ----
+    strong_leg = None
+    if world > 1 and not strong and not args.no_strong_leg and 400 % world == 0:
+        Bs = 400 // world
+        ids_s = [r[:Bs] for r in row_ids]
+        xs_buf = torch.empty(Bs, I, dtype=torch.float32, device=dev)
+        for i in range(max(3, args.warmup // 4)):
+            step(dcsr.rows(ids_s[i % n_pool], out=xs_buf), True, **{k: v[:Bs] for k, v in step_kw[i % n_pool].items()})
+        sync()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            step(dcsr.rows(ids_s[i % n_pool], out=xs_buf), True, **{k: v[:Bs] for k, v in step_kw[i % n_pool].items()})
+        sync()
+        ts_ = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
+        dist.all_reduce(ts_, op=dist.ReduceOp.MAX)
+        strong_leg = dict(global_batch=400, batch_per_gpu=Bs, steps=args.steps, ms_per_step=round(1e3 * float(ts_) / args.steps, 4),
+                          users_per_s=round(400 * args.steps / float(ts_), 1), scaling="strong")
+        step.flush()
+
     # ---- roofline of the dominant kernel (rank 0's events) ----
     roofline, klist = None, []
     for tag, d in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"]):
@@ -330,17 +439,18 @@ def main():
         klist.append(e)
     if klist:
         k0 = klist[0]
+        traffic, traffic_note = measured_traffic(k0["kernel"], args.workload, args.gemm_dtype)
         roofline = dict(bound=k0["bound"], achieved=k0["achieved"], peak=k0["peak"], unit=k0["unit"], frac=k0["frac"],
-                        traffic=measured_traffic(k0["kernel"], args.workload, args.gemm_dtype), kernel=k0["kernel"], avg_ms=k0["avg_ms"],
+                        traffic=traffic, traffic_source=traffic_note, kernel=k0["kernel"], avg_ms=k0["avg_ms"],
                         launches_per_step=k0["launches"] // max(n_profiled, 1), profiled_steps=n_profiled,
                         traffic_unit="HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE passes of this "
-                                     "command (profiles/r01_final_hbm_traffic.json)",
+                                     "command (profiles/r02_hbm_traffic.json)",
                         algorithmic_unit=("2*M*N*K FLOP per launch" if k0["bound"] == "mfma" else
                                           "compulsory bytes per launch (operands and results once; AdamW 28 B/param)"))
 
     spmm = None
-    if args.spmm and (rank == 0 or world > 1):
-        spmm = bench_spmm(gdmcf_amd, lib, args.workload, dev, world=world)  # world > 1: row-sharded, collective
+    if args.spmm and (rank == 0 or (world > 1 and args.spmm_sharded)):
+        spmm = bench_spmm(gdmcf_amd, lib, args.workload, dev, world=world if args.spmm_sharded else 1)
 
     bpr = None
     if args.bpr and rank == 0:
@@ -375,7 +485,8 @@ def main():
                        "n_items": I, "global_batch": world * B, "parallelism": f"dp{world}"},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": klist, "final_loss": final_loss,
             "host_enqueue_ms_per_step": round(1e3 * host_el / args.steps, 4),
-            "replicas_in_sync": in_sync, "dp_autotune": dp_autotune,
+            "replicas_in_sync": in_sync, "dp_autotune": dp_autotune, "strong_scaling": strong_leg,
+            "ranks_in_group": dist.get_world_size() if dist.is_initialized() else 1,
             "optimizer": "FusedAdamW" + (" fused into the dW GEMM epilogues" if (args.fuse_optimizer and world == 1) else
                                          " (row-sharded over the ranks: reduce-scatter, AdamW on 1/N rows, deferred all-gather)"
                                          if (sharded and step.exchange) else
@@ -454,8 +565,11 @@ def bench_spmm(gdmcf_amd, lib, workload, dev, layers=3, d=64, iters=20, world=1)
     ms = k["ms"] / k["n"]
     alg = m.algorithmic_bytes()
     gbps = alg / (ms * 1e-3) / 1e9
+    sched = "streamed (one launch + combine)" if getattr(m, "_streamed", False) else \
+        "bundled" if getattr(m, "_bundled", False) else "virtual rows (short / long / combine launches)"
     return dict(ms_per_layer=round(ms, 4), ms_per_propagation=round(wall_ms, 4), row_shards=world, nnz=nnz, nodes=N, d=d,
-                algorithmic_MB=round(alg / 1e6, 2),
+                schedule=sched, algorithmic_MB=round(alg / 1e6, 2), gathered_MB=round(nnz * d * 4 / 1e6, 1),
+                gathered_TBps=round(nnz * d * 4 / (ms * 1e-3) / 1e12, 2),
                 achieved=round(gbps, 1), peak=PEAK_HBM_GBPS, unit="GB/s", frac=round(gbps / PEAK_HBM_GBPS, 4), bound="hbm")
 
 

@@ -71,6 +71,8 @@ _SIGNATURES = {
                                    c_int64, c_float, c_double, P]),
     "gdmcf_spmm_bundled_f32": (c_int, [P, c_int, P, P, P, P, c_int, P, P, P, P, c_int, P, P, c_int, P, P, c_int64, c_int, c_int, P, c_int64, c_int, P,
                                        c_int64, P, P, c_int, c_int64, c_float, c_double, P]),
+    "gdmcf_spmm_stream_f32": (c_int, [P, c_int, P, c_int64, P, c_int, P, P, c_int, c_int, c_int, P, c_int64, c_int, P, c_int64, P, P,
+                                      c_int, c_int64, c_float, c_double, P]),
     "gdmcf_scale_f32": (c_int, [P, c_int64, c_float, P, P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -232,6 +232,119 @@ __global__ __launch_bounds__(256) void spmm_bundle_kernel(const SpmmBundlePlan p
 #undef GD_BATCH
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Third generation: the wave streams its nonzeros.  The schedule is the one above, but the host also re-orders the
+// (col, val) pairs into the order the waves gather them (gdmcf_amd/lightgcn.py:spmm_stream_pack): a wave reads ONE
+// contiguous run, 64 entries (= LPR steps of G gathers) per load, whatever rows they belong to, and a unit (a piece or a
+// bundle) is just "so many steps, then write these rows".  Why: vmcnt retires in order, so a load that goes to HBM (the
+// col/val of the next row, a descriptor) holds back every younger L2-hit gather behind it -- a wave that chases row
+// pointers pays an HBM latency per row (measured: 2.4 us per 40-nonzero piece).  Here the wave touches the lines of its
+// run and of its descriptors once when it starts (one HBM round trip for everything), after which every load it waits
+// for is an L2 hit.
+// ---------------------------------------------------------------------------------------------------------------------
+struct SpmmStreamPlan {
+    const int32_t* wdesc;  // [n_waves][4] = first batch of the wave's run, its batches, first / last+1 unit
+    int waves_per_class;
+    const int2* cw;        // (col, float bits of val), 64 entries per batch
+    const int32_t* ud;     // [n_units][DW]
+};
+
+template <int LPR, bool WIDE>
+__global__ __launch_bounds__(256) void spmm_stream_kernel(const SpmmStreamPlan pl, const float* __restrict__ X, int64_t ldx,
+                                                          float* __restrict__ Y, int64_t ldy, float* __restrict__ partial,
+                                                          int d, const SpmmAdd add, int dbg) {
+    constexpr int G = 64 / LPR;
+    constexpr int UN = LPR >= 4 ? 4 : LPR;
+    constexpr int DW = 1 + (G > 2 ? G : 2);
+    constexpr int GPB = LPR / UN;  // gather groups (UN steps each) per 64-entry batch
+    const int lane = threadIdx.x & 63;
+    const int g = lane / LPR, gl = lane % LPR;
+    const uint32_t ldxb = (uint32_t)ldx * 4u;
+    const int w = (blockIdx.x & 7) * pl.waves_per_class + (blockIdx.x >> 3) * 4 + (threadIdx.x >> 6);
+    const int sb = __builtin_amdgcn_readfirstlane(pl.wdesc[4 * w]);
+    const int nb = __builtin_amdgcn_readfirstlane(pl.wdesc[4 * w + 1]);
+    const int u0 = __builtin_amdgcn_readfirstlane(pl.wdesc[4 * w + 2]);
+    const int u1 = __builtin_amdgcn_readfirstlane(pl.wdesc[4 * w + 3]);
+    if (u0 >= u1) return;
+    const int2* __restrict__ run = pl.cw + (int64_t)sb * 64;
+    const int32_t* __restrict__ udw = pl.ud + (int64_t)u0 * DW;
+    // ---- warm-up: one dword of every 128-byte line (16 entries) of the first 32 batches and of the descriptors ----
+    // (independent registers, consumed only at the very end: three loads in flight together, one HBM round trip)
+    int t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    {
+        const int lines = min(nb * 4, 128);
+        const int* rl = reinterpret_cast<const int*>(run);
+        t0 = rl[min(lane, lines - 1) * 32];
+        t1 = rl[min(lane + 64, lines - 1) * 32];
+        const int dlast = (u1 - u0) * DW - 1;
+        t2 = udw[min(lane * 32, dlast)];
+    }
+    // the run and the results are streamed (non-temporal): an XCD's L2 is for the rows of X it gathers again and again
+    int2 cur = __builtin_nontemporal_load(run + lane);
+    int2 nxt = __builtin_nontemporal_load(run + min(1, nb - 1) * 64 + lane);
+    int b = 0, q = 0;
+    int hA = udw[0], aA = udw[1 + g], sA = udw[2];
+    for (int u = u0; u < u1; ++u) {
+        const int un = min(u + 1, u1 - 1) - u0;  // descriptor one unit ahead (L2 warm)
+        int hB = hA, aB = aA, sB = sA;
+        if (!(dbg & 4)) { hB = udw[un * DW]; aB = udw[un * DW + 1 + g]; sB = udw[un * DW + 2]; }
+        const int hdr = __builtin_amdgcn_readfirstlane(hA);
+        const int ngroups = hdr & 0x7FFFFFFF;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < ngroups; ++i) {
+            f32x4 x[UN];
+            float wt[UN];
+#pragma unroll
+            for (int j = 0; j < UN; ++j) {
+                const int src = (q * UN + j) * G + g;
+                const int c = __shfl(cur.x, src);
+                wt[j] = __int_as_float(__shfl(cur.y, src));
+                x[j] = gather_row<WIDE, false>(X, ldx, ldxb, c, gl);
+            }
+#pragma unroll
+            for (int j = 0; j < UN; ++j) acc += wt[j] * x[j];
+            if (++q == GPB) {  // batch used up: the next one is in registers, fetch the one after
+                q = 0;
+                ++b;
+                cur = nxt;
+                nxt = __builtin_nontemporal_load(run + (int64_t)min(b + 1, nb - 1) * 64 + lane);
+                if ((b & 15) == 0)  // every 16 batches: touch the lines of batches b+16 .. b+31 (never waited for here)
+                    t3 = reinterpret_cast<const int*>(run)[min((b + 16) * 4 + lane, nb * 4 - 1) * 32];
+            }
+        }
+        if (hdr < 0 && !(dbg & 2)) {  // piece: add the lane groups up; group 0 writes the row or its partial slot
+#pragma unroll
+            for (int o = LPR; o < 64; o <<= 1) {
+                acc.x += __shfl_xor(acc.x, o);
+                acc.y += __shfl_xor(acc.y, o);
+                acc.z += __shfl_xor(acc.z, o);
+                acc.w += __shfl_xor(acc.w, o);
+            }
+        }
+        const int a_st = aA, s_st = sA;
+        hA = hB; aA = aB; sA = sB;
+        asm volatile("" : "+v"(hA), "+v"(aA), "+v"(sA));  // keep the rotation above the stores
+        if (dbg & 1) {
+            if (acc.x == 1.2345f) Y[0] = acc.y;
+        } else if (hdr < 0) {
+            if (g == 0) {
+                if (s_st >= 0) {
+                    __builtin_nontemporal_store(acc, reinterpret_cast<f32x4*>(partial + (int64_t)s_st * d + gl * 4));
+                } else {
+                    for (int k = 0; k < add.n; ++k) acc += *reinterpret_cast<const f32x4*>(add.p[k] + (int64_t)a_st * add.ld + gl * 4);
+                    __builtin_nontemporal_store(acc * add.scale, reinterpret_cast<f32x4*>(Y + (int64_t)a_st * ldy + gl * 4));
+                }
+            }
+        } else if (a_st >= 0) {  // bundle: lane group g owns row a_st (bit 30: the row is empty, discard what was gathered)
+            const int r = a_st & 0x3FFFFFFF;
+            if (a_st & 0x40000000) acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < add.n; ++k) acc += *reinterpret_cast<const f32x4*>(add.p[k] + (int64_t)r * add.ld + gl * 4);
+            __builtin_nontemporal_store(acc * add.scale, reinterpret_cast<f32x4*>(Y + (int64_t)r * ldy + gl * 4));
+        }
+    }
+    asm volatile("" ::"v"(t0), "v"(t1), "v"(t2), "v"(t3));  // the touches are only waited for here
+}
+
 // rows cut into several pieces: Y[r] = (sum of the partial slots in slot order + addends) * scale; one wave per row,
 // LPR lanes per slot -> G slots per instruction, four instructions in flight; fixed order, no atomics
 template <int LPR>
@@ -332,4 +445,57 @@ extern "C" int gdmcf_spmm_bundled_f32(const int32_t* wdesc, int n_waves, const i
 #undef GD_GO
     }
     return gd_launch_status("spmm_bundled");
+}
+
+extern "C" int gdmcf_spmm_stream_f32(const int32_t* wdesc, int n_waves, const int32_t* cw, int64_t n_entries, const int32_t* ud,
+                                     int n_units, const int32_t* crow, const int32_t* cptr, int n_cut, int n_rows, int n_x_rows,
+                                     const float* X, int64_t ldx, int d, float* Y, int64_t ldy, float* partial_ws,
+                                     const float* const* addends_host, int n_add, int64_t ld_add, float scale, double alg_bytes,
+                                     void* stream) {
+    GD_CHECK_SHAPE(n_rows > 0 && n_x_rows > 0 && d > 0 && ldx >= d && ldy >= d, "spmm_stream: bad shape");
+    GD_CHECK_ARG(n_waves > 0 && n_waves % 32 == 0 && wdesc, "spmm_stream: n_waves must be a positive multiple of 32");
+    GD_CHECK_ARG(n_units >= 0 && n_entries >= 0 && n_entries % 64 == 0 && n_cut >= 0, "spmm_stream: bad counts");
+    GD_CHECK_ARG(n_units == 0 || (cw && ud), "spmm_stream: units without their arrays");
+    GD_CHECK_ARG(n_cut == 0 || (crow && cptr && partial_ws), "spmm_stream: cut rows need crow/cptr/partial_ws");
+    GD_CHECK_ARG(n_add >= 0 && n_add <= SPMM_MAX_ADD && (n_add == 0 || (addends_host && ld_add >= d)), "spmm_stream: bad addends");
+    const int lpr = d / 4;
+    bool ok = (d % 4 == 0) && (lpr == 2 || lpr == 4 || lpr == 8 || lpr == 16 || lpr == 32 || lpr == 64) && (ldx % 4 == 0) &&
+              (ldy % 4 == 0) && gd_aligned16(X) && gd_aligned16(Y) && (partial_ws == nullptr || gd_aligned16(partial_ws)) &&
+              ((reinterpret_cast<uintptr_t>(cw) & 7u) == 0);
+    SpmmAdd add = {};
+    add.n = n_add;
+    add.ld = ld_add;
+    add.scale = scale;
+    for (int k = 0; k < n_add; ++k) {
+        add.p[k] = addends_host[k];
+        ok = ok && gd_aligned16(add.p[k]) && (ld_add % 4 == 0);
+    }
+    if (!ok) {
+        gdmcf_set_error("spmm_stream: needs d in {8,16,32,64,128,256} and 16-byte aligned rows (use gdmcf_spmm_csr_f32 otherwise)");
+        return GDMCF_E_UNSUPPORTED;
+    }
+    SpmmStreamPlan pl = {wdesc, n_waves / 8, reinterpret_cast<const int2*>(cw), ud};
+    hipStream_t s = (hipStream_t)stream;
+    const int n_blocks = n_waves / 4;
+    const bool wide = (double)n_x_rows * (double)ldx * 4.0 >= 4294967296.0 || ldx * 4 >= (int64_t)1 << 31;
+    static const int dbg = getenv("GDMCF_SPMM_DBG") ? atoi(getenv("GDMCF_SPMM_DBG")) : 0;  // ablation switches (tools/spmm_probe2.py)
+    {
+        GdProfScope prof(8, alg_bytes, s);
+#define GD_GO(L)                                                                                                                        \
+    do {                                                                                                                                \
+        if (wide) hipLaunchKernelGGL((spmm_stream_kernel<L, true>), dim3(n_blocks), dim3(256), 0, s, pl, X, ldx, Y, ldy, partial_ws, d, add, dbg); \
+        else hipLaunchKernelGGL((spmm_stream_kernel<L, false>), dim3(n_blocks), dim3(256), 0, s, pl, X, ldx, Y, ldy, partial_ws, d, add, dbg);     \
+        if (n_cut > 0 && !(dbg & 8))                                                                                                                  \
+            hipLaunchKernelGGL(spmm_bundle_combine_kernel<L>, dim3(gd_cdiv(n_cut, 4)), dim3(256), 0, s, crow, cptr, n_cut, partial_ws,  \
+                               d, Y, ldy, add);                                                                                         \
+    } while (0)
+        if (lpr == 16) GD_GO(16);
+        else if (lpr == 8) GD_GO(8);
+        else if (lpr == 32) GD_GO(32);
+        else if (lpr == 64) GD_GO(64);
+        else if (lpr == 4) GD_GO(4);
+        else GD_GO(2);
+#undef GD_GO
+    }
+    return gd_launch_status("spmm_stream");
 }

@@ -82,6 +82,7 @@ SPMM_WAVES = int(os.environ.get("GDMCF_SPMM_WAVES", "4096"))  # 256 CUs x 16 res
 SPMM_COST_ROW = int(os.environ.get("GDMCF_SPMM_COST_ROW", "8"))  # fixed cost of a bundled row / of a piece, in nonzeros
 SPMM_COST_PIECE = int(os.environ.get("GDMCF_SPMM_COST_PIECE", "32"))
 SPMM_HOT_MB = float(os.environ.get("GDMCF_SPMM_HOT_MB", "2.0"))  # part of an XCD's L2 the bundled rows' hot columns can keep
+SPMM_SLICE_MB = float(os.environ.get("GDMCF_SPMM_SLICE_MB", "3.5"))  # largest per-XCD slice of the table worth cutting rows for
 SPMM_NT = int(os.environ.get("GDMCF_SPMM_NT", "0"))  # streaming loads for bundles that gather mostly cold rows
 SPMM_MISS_W = float(os.environ.get("GDMCF_SPMM_MISS_W", "3.0"))  # cost of a gather served beyond L2, in L2-hit gathers
 
@@ -96,8 +97,10 @@ def spmm_bundle_plan(indptr, indices, d=64, n_waves=None, s_max=None, piece=None
         table (2-3 MB at the Yelp shape: L2 resident), at the price of one 256-byte partial per piece;
     (2) the short rows are sorted by length (longest first) and dealt to the classes bundle by bundle (G = 64/(d/4) rows
         of the same length share a wave-step, so the lane groups of a wave finish together); every class gets the same
-        mix, so the gathers that miss L2 load the eight fabric links equally;
-    (3) the class's pieces + bundles are cut into n_waves/8 contiguous runs of equal cost, one per wave.
+        mix, so the gathers that miss L2 load the eight fabric links equally; rows whose columns are mostly among the
+        most gathered ones ("warm") and the others ("cold") are bundled apart;
+    (3) every wave of a class gets an equal-cost share of the class's pieces, of its warm and of its cold bundles, and
+        runs them in this order: the XCD's waves are in the same phase at the same time.
     Cost = nonzeros (those to a column outside the `SPMM_HOT_MB` most gathered megabytes of the table count SPMM_MISS_W
     times: they are served by the Infinity Cache at a third of the L2 rate) + a fixed overhead per row / piece.
     Rows cut into several pieces get consecutive partial slots (crow / cptr), added up in slot order afterwards."""
@@ -161,56 +164,168 @@ def spmm_bundle_plan(indptr, indices, d=64, n_waves=None, s_max=None, piece=None
     ptot = float((plen + float(SPMM_COST_PIECE)).sum())
     pord = np.lexsort((pbeg, pcls))  # class-major, CSR order inside
     P = dict(beg=pbeg[pord], len=plen[pord], row=prow[pord], slot=pslot[pord], cls=pcls[pord])
-    # (2) short rows: longest first, dealt to the classes bundle by bundle
-    sord = np.lexsort((srows, -deg[srows]))
-    s_sorted = srows[sord]
-    n_s = len(s_sorted)
-    scls_sorted = (np.arange(n_s) // G) % classes
-    sord2 = np.argsort(scls_sorted, kind="stable")  # class-major, still longest first inside a class
-    s_row, s_cls = s_sorted[sord2], scls_sorted[sord2]
-    ncls_rows = np.bincount(s_cls, minlength=classes)
-    nb_cls = -(-ncls_rows // G)  # bundles per class (last one padded)
-    n_b = int(nb_cls.sum())
-    b_first = np.cumsum(nb_cls) - nb_cls
-    r_first = np.cumsum(ncls_rows) - ncls_rows
-    pos = np.arange(n_s) - r_first[s_cls]  # position of the row inside its class
-    ent = b_first[s_cls] * G + pos  # entry index in the bundle arrays
-    sbeg = np.zeros(n_b * G, dtype=np.int64)
-    slen = np.zeros(n_b * G, dtype=np.int32)
-    srow = np.full(n_b * G, -1, dtype=np.int32)
-    swd = np.zeros(n_b * G, dtype=np.float64)
-    sbeg[ent], slen[ent], srow[ent], swd[ent] = indptr[s_row], deg[s_row], s_row, wdeg[s_row]
-    smax = slen.reshape(n_b, G).max(axis=1).astype(np.int32) if n_b else np.zeros(0, np.int32)
-    if n_b and SPMM_NT:  # bit 30: most of the bundle's gathers go to rarely gathered rows -> streaming (nt) loads
-        scold = np.zeros(n_b * G)
-        scold[ent] = ncold[s_row]
-        smax = smax | ((scold.reshape(n_b, G).sum(1) > 0.5 * slen.reshape(n_b, G).sum(1)).astype(np.int32) << 30)
-    bcost = (swd.reshape(n_b, G).max(axis=1) + float(SPMM_COST_ROW)) * G if n_b else np.zeros(0)
-    total = ptot + float(bcost.sum())
+    # (2) short rows: "warm" rows (most of their columns are among the most gathered ones) and "cold" rows apart, each
+    # set longest first and dealt to the classes G rows (= one bundle) at a time
+    cold_row = (ncold[srows] * 2 > deg[srows]).astype(np.int64)
+    sord = np.lexsort((srows, -deg[srows], cold_row))  # warm before cold, longest first
+    s_sorted, s_temp = srows[sord], cold_row[sord]
+    n_warm = int((s_temp == 0).sum())
+    pos_in_temp = np.arange(len(s_sorted)) - np.where(s_temp == 1, n_warm, 0)
+    s_cls = (pos_in_temp // G) % classes
+    grp = s_cls * 2 + s_temp  # (class, temperature) groups, bundles never mix them
+    gord = np.argsort(grp, kind="stable")
+    s_row, s_grp = s_sorted[gord], grp[gord]
+    n_grp_rows = np.bincount(s_grp, minlength=2 * classes)
+    nb_grp = -(-n_grp_rows // G)  # bundles per group (last one padded)
+    n_b = int(nb_grp.sum())
+    gb_first = np.cumsum(nb_grp) - nb_grp
+    gr_first = np.cumsum(n_grp_rows) - n_grp_rows
+    ent0 = gb_first[s_grp] * G + (np.arange(len(s_row)) - gr_first[s_grp])  # entry index, group-major bundle order
+    b_grp = np.repeat(np.arange(2 * classes), nb_grp)
+    slen0 = np.zeros(n_b * G, dtype=np.int64)
+    swd0 = np.zeros(n_b * G, dtype=np.float64)
+    slen0[ent0], swd0[ent0] = deg[s_row], wdeg[s_row]
+    bcost0 = (swd0.reshape(n_b, G).max(axis=1) + float(SPMM_COST_ROW)) * G if n_b else np.zeros(0)
+    total = ptot + float(bcost0.sum())
     if n_waves is None:
         n_waves = int(min(SPMM_WAVES, max(32, -(-int(total) // 4096) * 32)))  # >= ~128 cost units per wave
     wpc = n_waves // classes
     assert n_waves % (4 * classes) == 0
-    # (3) per class: equal-cost contiguous runs, one per wave
-    wdesc = np.zeros((n_waves, 4), dtype=np.int32)
-    np_cls = np.bincount(P["cls"], minlength=classes)
-    p_first = np.cumsum(np_cls) - np_cls
+
+    def equal_runs(cost, parts):
+        """run index (0 .. parts-1) of every element of a list cut into `parts` contiguous runs of equal cost"""
+        if len(cost) == 0:
+            return np.zeros(0, np.int64)
+        cum = np.cumsum(cost)
+        return np.minimum(((cum - 0.5 * cost) * parts / cum[-1]).astype(np.int64), parts - 1)
+
+    # (3) every wave of a class takes an equal share of EACH phase -- the class's pieces, its warm bundles, its cold
+    # bundles -- and runs them in that order, so that all waves of the XCD gather from the pieces' slice of the table
+    # first (L2 resident as long as nothing else streams through), then from the much-gathered rows, and last do the
+    # gathers that miss anyway.  (Pieces, warm and cold bundles run side by side evicted each other: 46 % L2 hits.)
+    pcost_sorted = P["len"] + float(SPMM_COST_PIECE)
+    p_wave = np.zeros(n_p, dtype=np.int64)
+    b_wave = np.zeros(n_b, dtype=np.int64)
     for c in range(classes):
-        pc = P["len"][p_first[c]:p_first[c] + np_cls[c]] + float(SPMM_COST_PIECE)
-        bc = bcost[b_first[c]:b_first[c] + nb_cls[c]]
-        cc = np.cumsum(np.concatenate([pc, bc]))
-        tot = cc[-1] if len(cc) else 0.0
-        bounds = np.searchsorted(cc, tot * np.arange(1, wpc) / wpc, side="left") if len(cc) else np.zeros(wpc - 1, np.int64)
-        edges = np.maximum.accumulate(np.concatenate([[0], bounds, [len(cc)]]).astype(np.int64))
-        a, b = edges[:-1], edges[1:]
-        nP = int(np_cls[c])
-        wdesc[c * wpc:(c + 1) * wpc, 0] = p_first[c] + np.minimum(a, nP)
-        wdesc[c * wpc:(c + 1) * wpc, 1] = p_first[c] + np.minimum(b, nP)
-        wdesc[c * wpc:(c + 1) * wpc, 2] = b_first[c] + np.maximum(a - nP, 0)
-        wdesc[c * wpc:(c + 1) * wpc, 3] = b_first[c] + np.maximum(b - nP, 0)
+        m = P["cls"] == c
+        p_wave[m] = c * wpc + equal_runs(pcost_sorted[m], wpc)
+        for t in (0, 1):
+            mb = b_grp == c * 2 + t
+            b_wave[mb] = c * wpc + equal_runs(bcost0[mb], wpc)
+    pw = np.argsort(p_wave, kind="stable")  # wave-major, CSR order inside
+    P = {k_: v_[pw] for k_, v_ in P.items()}
+    p_wave = p_wave[pw]
+    bw = np.lexsort((np.arange(n_b), b_grp & 1, b_wave))  # wave-major, warm before cold, longest first
+    new_of_old = np.empty(n_b, dtype=np.int64)
+    new_of_old[bw] = np.arange(n_b)
+    ent = new_of_old[ent0 // G] * G + ent0 % G
+    sbeg = np.zeros(n_b * G, dtype=np.int64)
+    slen = np.zeros(n_b * G, dtype=np.int32)
+    srow = np.full(n_b * G, -1, dtype=np.int32)
+    sbeg[ent], slen[ent], srow[ent] = indptr[s_row], deg[s_row], s_row
+    smax = slen.reshape(n_b, G).max(axis=1).astype(np.int32) if n_b else np.zeros(0, np.int32)
+    if n_b and SPMM_NT:  # bit 30: the bundle's rows gather mostly rarely gathered rows -> streaming (nt) loads
+        smax = smax | ((b_grp[bw] & 1).astype(np.int32) << 30)
+    wdesc = np.zeros((n_waves, 4), dtype=np.int32)
+    pcnt = np.bincount(p_wave, minlength=n_waves)
+    bcnt = np.bincount(b_wave, minlength=n_waves)
+    wdesc[:, 1] = np.cumsum(pcnt)
+    wdesc[:, 0] = wdesc[:, 1] - pcnt
+    wdesc[:, 3] = np.cumsum(bcnt)
+    wdesc[:, 2] = wdesc[:, 3] - bcnt
     return dict(wdesc=wdesc.reshape(-1), n_waves=int(n_waves), lbeg=P["beg"].astype(np.int64), llen=P["len"].astype(np.int32),
                 lrow=P["row"].astype(np.int32), lslot=P["slot"].astype(np.int32), n_pieces=n_p, sbeg=sbeg, slen=slen, srow=srow,
                 smax=smax, n_bundles=n_b, crow=crow, cptr=cptr, n_slots=int(cut.sum()), G=G)
+
+
+def spmm_stream_pack(plan, indptr, indices, vals, d=64):
+    """Packs the schedule of spmm_bundle_plan into what the kernel streams (csrc/spmm_bundle.hip, gdmcf_spmm_stream_f32):
+    the nonzeros themselves, re-ordered so that every wave reads ONE contiguous run of (col, val) pairs in exactly the order
+    it gathers them, and one small descriptor per unit.  A wave that has to chase row pointers (descriptor -> col/val of
+    that row -> gathers) pays an HBM latency per row; with a contiguous run it touches its lines once when it starts and
+    afterwards only ever waits for L2.
+
+    Layout: a unit (a piece, or a bundle of G rows) is a sequence of steps, a step = G entries, entry (k, g) = what lane
+    group g gathers in step k; pieces put nonzero j at (j // G, j % G), bundles put the k-th nonzero of row g at (k, g).
+    Units are padded to a multiple of UN = min(4, d/4) steps and a wave's run to a multiple of 64 entries with entries of
+    weight 0 that point at a column the row really has (empty rows: flagged in the descriptor, the sum is discarded).
+      cw    int32 [n_entries, 2]   (col, float bits of val)
+      ud    int32 [n_units, DW]    DW = 1 + max(G, 2): [steps/UN | kind << 31, piece: row, slot | bundle: row_g (-1 =
+                                   padding, bit 30 = empty row)]
+      wdesc int32 [n_waves, 4]     first batch (64 entries) of the wave's run, its batches, first / last+1 unit"""
+    indptr = np.asarray(indptr, dtype=np.int64)
+    indices = np.asarray(indices)
+    vals = np.asarray(vals, dtype=np.float32)
+    nnz = len(indices)
+    lpr = d // 4
+    G = 64 // lpr
+    UN = min(4, lpr)
+    DW = 1 + max(G, 2)
+    n_p, n_b, n_w = plan["n_pieces"], plan["n_bundles"], plan["n_waves"]
+    wd = plan["wdesc"].reshape(n_w, 4).astype(np.int64)
+    # units in wave order: the pieces of a wave, then its bundles
+    p_wave = np.repeat(np.arange(n_w), wd[:, 1] - wd[:, 0])
+    b_wave = np.repeat(np.arange(n_w), wd[:, 3] - wd[:, 2])
+    n_u = n_p + n_b
+    pu = np.arange(n_p) + wd[p_wave, 2]  # unit id of a piece: the bundles of the earlier waves come before it
+    bu = np.arange(n_b) + wd[b_wave, 1]  # unit id of a bundle: the pieces up to and including its own wave's
+    # ---- steps per unit ----
+    llen = plan["llen"].astype(np.int64)
+    smax = (plan["smax"] & 0x3FFFFFFF).astype(np.int64)
+    usteps = np.zeros(n_u, dtype=np.int64)
+    usteps[pu] = -(-(-(-llen // G)) // UN) * UN
+    usteps[bu] = -(-smax // UN) * UN
+    uent = usteps * G
+    # ---- waves: unit ranges, stream offsets (batch aligned) ----
+    u0 = wd[:, 0] + wd[:, 2]
+    u1 = wd[:, 1] + wd[:, 3]
+    ucum = np.concatenate([[0], np.cumsum(uent)])
+    wtot = ucum[u1] - ucum[u0]
+    wbat = -(-wtot // 64)
+    wbase = (np.cumsum(wbat) - wbat) * 64
+    n_ent = int(wbat.sum()) * 64
+    wave_of_unit = np.repeat(np.arange(n_w), u1 - u0)  # units are in wave order
+    upos = wbase[wave_of_unit] + (ucum[:-1] - ucum[u0][wave_of_unit])
+    wdesc = np.stack([wbase // 64, wbat, u0, u1], axis=1).astype(np.int32)
+    # ---- entries ----
+    c_out = np.zeros(max(n_ent, 1), dtype=np.int32)
+    w_out = np.zeros(max(n_ent, 1), dtype=np.float32)
+    if n_p:
+        ent = uent[pu]
+        first = np.cumsum(ent) - ent
+        j = np.arange(int(ent.sum()), dtype=np.int64) - np.repeat(first, ent)
+        ln = np.repeat(llen, ent)
+        src = np.repeat(plan["lbeg"].astype(np.int64), ent) + np.minimum(j, ln - 1)
+        pos = np.repeat(upos[pu], ent) + j
+        c_out[pos] = indices[src]
+        w_out[pos] = np.where(j < ln, vals[src], np.float32(0))
+    if n_b:
+        ent = uent[bu]
+        first = np.cumsum(ent) - ent
+        loc = np.arange(int(ent.sum()), dtype=np.int64) - np.repeat(first, ent)
+        bidx = np.repeat(np.arange(n_b), ent)
+        k, g = loc // G, loc % G
+        e = bidx * G + g
+        rl = plan["slen"].astype(np.int64)[e]
+        src = np.clip(plan["sbeg"].astype(np.int64)[e] + np.minimum(k, np.maximum(rl - 1, 0)), 0, max(nnz - 1, 0))
+        pos = np.repeat(upos[bu], ent) + loc
+        c_out[pos] = indices[src] if nnz else 0
+        w_out[pos] = np.where(k < rl, vals[src], np.float32(0)) if nnz else 0
+    # wave tails (padding up to a whole batch): any column of the matrix, weight 0 -- already 0 / 0.0 (column 0 exists)
+    cw = np.stack([c_out, w_out.view(np.int32)], axis=1)
+    # ---- unit descriptors ----
+    ud = np.full((max(n_u, 1), DW), -1, dtype=np.int32)
+    if n_p:
+        ud[pu, 0] = (usteps[pu] // UN).astype(np.int32) | np.int32(-2147483648)
+        ud[pu, 1] = plan["lrow"]
+        ud[pu, 2] = plan["lslot"]
+    if n_b:
+        ud[bu, 0] = (usteps[bu] // UN).astype(np.int32)
+        rows = plan["srow"].reshape(n_b, G).astype(np.int32)
+        empty = (plan["slen"].reshape(n_b, G) == 0) & (rows >= 0)
+        ud[bu, 1:1 + G] = np.where(empty, rows | np.int32(1 << 30), rows)
+    return dict(cw=cw.reshape(-1), ud=ud.reshape(-1), wdesc=wdesc.reshape(-1), n_waves=n_w, n_units=n_u, n_entries=n_ent,
+                crow=plan["crow"], cptr=plan["cptr"], n_slots=plan["n_slots"], G=G, UN=UN, DW=DW)
 
 
 class LightGCN(nn.Module):
@@ -253,9 +368,23 @@ class LightGCN(nn.Module):
             lo, hi = int(indptr[r0]), int(indptr[r1])
             indptr, indices, vals = indptr[r0:r1 + 1] - indptr[r0], indices[lo:hi], vals[lo:hi]
         lpr = self.latent_dim // 4
-        self._bundled = (self.latent_dim % 4 == 0 and lpr in (2, 4, 8, 16, 32, 64) and
-                         indices.size > 0 and os.environ.get("GDMCF_SPMM_GEN", "1") != "1")
-        plan = spmm_bundle_plan(indptr, indices, d=self.latent_dim, n_cols=N) if self._bundled else spmm_plan(indptr, d=self.latent_dim)
+        fits = self.latent_dim % 4 == 0 and lpr in (2, 4, 8, 16, 32, 64) and indices.size > 0
+        # Which kernel: the streamed schedule (third generation) pays when an eighth of the gathered table -- what one XCD
+        # gathers through its pieces -- fits that XCD's 4 MiB L2 beside the streams (Yelp shape: 2.85 MB; 56 us per layer
+        # against 61 us); on larger tables its length-sorted bundles scatter the 256-byte result rows over the whole
+        # output and the row-ordered first-generation kernels are faster (stress shape: 1.29 ms against 1.37 ms).
+        gen = os.environ.get("GDMCF_SPMM_GEN", "auto")
+        if gen == "auto":
+            gen = "3" if N * self.latent_dim * 4 / 8 <= SPMM_SLICE_MB * 1e6 else "1"
+        self._bundled = fits and gen == "2"
+        self._streamed = fits and gen == "3"
+        if self._streamed:
+            plan = spmm_stream_pack(spmm_bundle_plan(indptr, indices, d=self.latent_dim, n_cols=N), indptr, indices, vals,
+                                    d=self.latent_dim)
+        elif self._bundled:
+            plan = spmm_bundle_plan(indptr, indices, d=self.latent_dim, n_cols=N)
+        else:
+            plan = spmm_plan(indptr, d=self.latent_dim)
         self._plan = {k: (torch.from_numpy(v).to(dev) if isinstance(v, np.ndarray) else v) for k, v in plan.items()}
         self._partial = torch.empty(max(plan["n_slots"], 1), self.latent_dim, dtype=torch.float32, device=dev)
         self.nnz = int(indices.size)
@@ -278,7 +407,7 @@ class LightGCN(nn.Module):
         st = _lib.stream_ptr()
         cur = X.contiguous()
         layers = [cur]
-        nv, nl = (0, 0) if self._bundled else (pl["vrow"].numel(), pl["lrow"].numel())
+        nv, nl = (0, 0) if (self._bundled or self._streamed) else (pl["vrow"].numel(), pl["lrow"].numel())
         r0, r1, rpr = self._rows
         sharded = self._world > 1
         for layer in range(self.n_layers):
@@ -287,7 +416,14 @@ class LightGCN(nn.Module):
             adds = layers if last else []
             # the fused layer mean reads this rank's rows of the earlier layers
             arr = (ctypes.c_void_p * max(len(adds), 1))(*[a.data_ptr() + r0 * a.stride(0) * 4 for a in adds])
-            if r1 > r0 and self._bundled:
+            if r1 > r0 and self._streamed:
+                opt = lambda t: t.data_ptr() if t.numel() else None
+                _lib.check(lib.gdmcf_spmm_stream_f32(
+                    pl["wdesc"].data_ptr(), pl["n_waves"], pl["cw"].data_ptr(), pl["n_entries"], pl["ud"].data_ptr(),
+                    pl["n_units"], opt(pl["crow"]), pl["cptr"].data_ptr(), pl["crow"].numel(), r1 - r0, N, cur.data_ptr(),
+                    cur.stride(0), d, out.data_ptr(), out.stride(0), self._partial.data_ptr(), arr, len(adds), cur.stride(0),
+                    1.0 / (self.n_layers + 1) if last else 1.0, self.algorithmic_bytes(), st))
+            elif r1 > r0 and self._bundled:
                 opt = lambda t: t.data_ptr() if t.numel() else None
                 _lib.check(lib.gdmcf_spmm_bundled_f32(
                     pl["wdesc"].data_ptr(), pl["n_waves"], opt(pl["lbeg"]), opt(pl["llen"]), opt(pl["lrow"]), opt(pl["lslot"]),

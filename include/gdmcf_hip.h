@@ -333,6 +333,18 @@ int gdmcf_spmm_bundled_f32(const int32_t* wdesc, int n_waves, const int64_t* lbe
                            const int32_t* col, const float* val, int64_t nnz, int n_rows, int n_x_rows, const float* X,
                            int64_t ldx, int d, float* Y, int64_t ldy, float* partial_ws, const float* const* addends_host, int n_add, int64_t ld_add,
                            float scale, double alg_bytes, void* stream);
+/* Third generation: the schedule of gdmcf_spmm_bundled_f32 with the nonzeros re-ordered into the order the waves gather
+ * them (gdmcf_amd/lightgcn.py:spmm_stream_pack), so that a wave reads one contiguous run of (col, val) pairs instead of
+ * chasing row pointers:
+ *   wdesc int32 [n_waves][4]     first 64-entry batch of the wave's run, its batches, first / last+1 unit
+ *   cw    int32 [n_entries][2]   (column, float bits of the value); n_entries % 64 == 0; 8-byte aligned
+ *   ud    int32 [n_units][DW]    DW = 1 + max(G, 2), G = 64/(d/4):  [steps/UN | piece << 31,  piece: row, slot (-1 = whole
+ *                                row) | bundle: row of lane group g (-1 = padding, bit 30 = empty row)], UN = min(4, d/4)
+ *   crow / cptr / partial_ws / addends / scale / alg_bytes as above.                                                     */
+int gdmcf_spmm_stream_f32(const int32_t* wdesc, int n_waves, const int32_t* cw, int64_t n_entries, const int32_t* ud, int n_units,
+                          const int32_t* crow, const int32_t* cptr, int n_cut, int n_rows, int n_x_rows, const float* X,
+                          int64_t ldx, int d, float* Y, int64_t ldy, float* partial_ws, const float* const* addends_host,
+                          int n_add, int64_t ld_add, float scale, double alg_bytes, void* stream);
 /* out = acc * scale */
 int gdmcf_scale_f32(const float* acc, int64_t n, float scale, float* out, void* stream);
 

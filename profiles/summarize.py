@@ -68,8 +68,43 @@ def counters(path):
     return [dict(kernel=k, **v) for k, v in table.items()]
 
 
+# bench.py tag of a kernel, from its name and its layout / epilogue template arguments (never from tile sizes, which change
+# with tuning): gemm_f32_kernel<LAY_A, LAY_B, BM, BN, BK, ..., EPI>, gemm_f32_spec_kernel<LAY_A, LAY_B, ...>
+import re
+
+TAG_RULES = [
+    (r"^gemm_f32_spec_kernel<1, 1,", "bwd_weight_gemm"),
+    (r"^gemm_f32_kernel<0, 0, .*, 2>$", "loss_fwd_gemm"),
+    (r"^gemm_f32_kernel<0, 0, .*, 3>$", "posterior_gemm"),
+    (r"^gemm_f32_kernel<0, 1, .*, 0>$", "bwd_input_gemm"),
+    (r"^gemm_f32_kernel<0, 0, .*, 0>$", "linear_fwd_gemm"),
+    (r"^gemm_bf16", "bf16_gemm"),
+    (r"^adamw_kernel", "adamw"),
+    (r"^prep_input_kernel", "prep_input"),
+    (r"^spmm_stream_kernel|^spmm_short_kernel", "spmm_csr"),
+    (r"^spmm_vec_kernel", "spmm_csr_long_rows"),
+    (r"^topk_kernel", "topk"),
+    (r"^onehot_noise", "onehot_noise"),
+]
+
+
+def by_tag(rows, workload, gemm_dtype):
+    """rows of traffic() keyed by bench tag (the heaviest kernel wins when several map to one tag)"""
+    tags = {}
+    for r in rows:
+        for pat, tag in TAG_RULES:
+            if re.search(pat, r["kernel"]):
+                if tag not in tags or r["hbm_total_MB"] * r["launches"] > tags[tag]["hbm_total_MB"] * tags[tag]["launches"]:
+                    tags[tag] = r
+                break
+    return dict(workload=workload, gemm_dtype=gemm_dtype, note="HBM bytes per launch: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) and "
+                "WRITE_SIZE passes of `python bench.py` (tools/profile_round.sh)", tags=tags)
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "counters":
+    if sys.argv[1] == "traffic_by_tag":  # <fetch csv> <write csv> <workload> <gemm dtype>
+        print(json.dumps(by_tag(traffic(sys.argv[2], sys.argv[3]), sys.argv[4], sys.argv[5]), indent=1))
+    elif sys.argv[1] == "counters":
         print(json.dumps(counters(sys.argv[2]), indent=1))
     elif sys.argv[1] == "stats":
         print(json.dumps(stats(sys.argv[2]), indent=1))

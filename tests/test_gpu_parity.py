@@ -498,8 +498,10 @@ def test_topk_wide_rows_take_the_unstaged_path():
         np.testing.assert_array_equal(got.cpu().numpy(), ref.numpy(), err_msg=f"k={k}")
 
 
+@pytest.mark.parametrize("gen", ["1", "3"])
 @pytest.mark.parametrize("case", ["small", "mid"])
-def test_lightgcn_propagation_matches_reference(case):
+def test_lightgcn_propagation_matches_reference(case, gen, monkeypatch):
+    monkeypatch.setenv("GDMCF_SPMM_GEN", gen)
     fx = H.load("lightgcn_" + case)
     U, It, d, L = [int(v) for v in str(fx["meta"][0]).split("|")]
     data = {"user_id_idx": fx["users"], "item_id_idx": fx["items"]}
@@ -520,8 +522,11 @@ def test_lightgcn_propagation_matches_reference(case):
     np.testing.assert_allclose(fi2.cpu().numpy(), fx["final_item"], rtol=0, atol=3e-7)
 
 
-def test_spmm_hub_rows_are_split_and_exact():
-    """A hub item with thousands of neighbours goes through the virtual-row split + combine path."""
+@pytest.mark.parametrize("gen", ["1", "2", "3"])
+def test_spmm_hub_rows_are_split_and_exact(gen, monkeypatch):
+    """A hub item with thousands of neighbours goes through the split + combine path of every kernel generation
+    (1: virtual rows, 2: bundled schedule, 3: streamed schedule -- gdmcf_amd/lightgcn.py picks by table size)."""
+    monkeypatch.setenv("GDMCF_SPMM_GEN", gen)
     rng = np.random.default_rng(0)
     U, It, d = 3000, 50, 64
     users = np.concatenate([np.arange(U), rng.integers(0, U, 500)])
@@ -530,7 +535,8 @@ def test_spmm_hub_rows_are_split_and_exact():
     E0 = rng.standard_normal((U + It, d)).astype(np.float32)
     ref = O.lightgcn_propagate(A, E0, 3, U)
     m = gdmcf_amd.LightGCN({"user_id_idx": users, "item_id_idx": items}, U, It, 3, d, device=DEV)
-    assert m._plan["lrow"].numel() >= 1 and m._plan["n_slots"] >= 12
+    cut_rows = m._plan["crow"] if "crow" in m._plan else m._plan["lrow"]  # rows cut into several pieces
+    assert cut_rows.numel() >= 1 and m._plan["n_slots"] >= 12
     with torch.no_grad():
         m.E0.weight.copy_(torch.from_numpy(E0))
     m = m.to(DEV)
@@ -550,6 +556,48 @@ def test_spmm_hub_rows_are_split_and_exact():
     with torch.no_grad():
         fu2, fi2, _, _ = m.propagate_through_layers()
     assert torch.equal(fi, fi2) and torch.equal(fu, fu2)  # deterministic (no atomics)
+
+
+@pytest.mark.parametrize("gen", ["1", "2", "3"])
+def test_spmm_isolated_nodes_and_non_finite_strangers(gen, monkeypatch):
+    """Nodes without any edge keep mean_l(A~^l E0) = E0 / (L+1) (only the l = 0 term), and a non-finite embedding reaches
+    exactly the nodes the reference's sparse product lets it reach: its neighbourhood -- not rows that merely share a wave,
+    a bundle or a padded step with it (the schedules pad with weight-0 entries; 0 * inf must never be formed with a
+    stranger's row)."""
+    monkeypatch.setenv("GDMCF_SPMM_GEN", gen)
+    rng = np.random.default_rng(5)
+    U, It, d, L = 400, 300, 64, 2
+    users = rng.integers(0, U - 40, 5000)  # the last 40 users and ...
+    items = rng.integers(10, It, 5000)  # ... the first 10 items have no edge at all
+    A = O.lightgcn_norm_adj(users, items, U, It)
+    E0 = rng.standard_normal((U + It, d)).astype(np.float32)
+    E0[U + 3] = np.inf  # an isolated item (column 0..9 of the item block): nobody gathers it
+    E0[0, 5] = np.nan  # user 0: reaches its items after one layer, their users after two
+    m = gdmcf_amd.LightGCN({"user_id_idx": users, "item_id_idx": items}, U, It, L, d, device=DEV)
+    with torch.no_grad():
+        m.E0.weight.copy_(torch.from_numpy(E0))
+    m = m.to(DEV)
+    with torch.no_grad():
+        fu, fi, _, _ = m.propagate_through_layers()
+    got = np.concatenate([fu.cpu().numpy(), fi.cpu().numpy()])
+    with np.errstate(invalid="ignore"):
+        A64 = A.astype(np.float64)
+        cur, acc = E0.astype(np.float64), E0.astype(np.float64)
+        for _ in range(L):
+            nxt = np.zeros_like(cur)  # sparse product: only stored entries multiply (0-weight structural zeros do not exist)
+            for r in range(A64.shape[0]):
+                lo, hi = A64.indptr[r], A64.indptr[r + 1]
+                if hi > lo:
+                    nxt[r] = (A64.data[lo:hi, None] * cur[A64.indices[lo:hi]]).sum(0)
+            cur = nxt
+            acc = acc + cur
+        ref = acc / (L + 1)
+    bad_ref, bad_got = ~np.isfinite(ref), ~np.isfinite(got)
+    np.testing.assert_array_equal(bad_got, bad_ref)
+    np.testing.assert_allclose(got[~bad_ref], ref[~bad_ref], rtol=0, atol=2e-6)
+    iso = np.concatenate([np.arange(U - 40, U), U + np.arange(10)])
+    iso = iso[iso != U + 3]
+    np.testing.assert_array_equal(got[iso], (E0[iso] * np.float32(1.0 / (L + 1))))
 
 
 def test_lt_history_kernel_matches_serial_fifo():
@@ -603,8 +651,10 @@ def test_sample_timesteps_kernel():
     assert not torch.equal(t2, t3)
 
 
+@pytest.mark.parametrize("gen", ["1", "2", "3"])
 @pytest.mark.parametrize("d", [8, 16, 32, 64, 128, 256, 20, 7])
-def test_spmm_widths_against_oracle(d):
+def test_spmm_widths_against_oracle(d, gen, monkeypatch):
+    monkeypatch.setenv("GDMCF_SPMM_GEN", gen)
     rng = np.random.default_rng(d)
     U, It, nnz = 300, 200, 4000
     users, items = rng.integers(0, U, nnz), rng.integers(0, It, nnz)
@@ -1159,3 +1209,14 @@ def test_bench_emits_the_contract_line():
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     assert abs(d["value"] - 400 * 8 / (d["ms_per_step"] * 8e-3)) / d["value"] < 1e-3
+    assert cb["physical_cores"] is None or cb["physical_cores"] >= 1
+    assert cb["one_thread"]["value"] > 0  # the one-thread orientation figure of BASELINE.md section 3
+    # the SpMM and the evaluation path are part of the default line (north_star sets a target on the SpMM)
+    sp = d["spmm"]
+    assert sp["bound"] == "hbm" and sp["ms_per_layer"] > 0 and abs(sp["frac"] - sp["achieved"] / sp["peak"]) < 1e-3
+    assert d["sampling"]["users_per_s"] > 0 and d["ranks_in_group"] == 1
+    # asked for two GPUs on a one-GPU box: no line, non-zero exit
+    if __import__("torch").cuda.device_count() < 2:
+        r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                            capture_output=True, text=True, cwd=root, timeout=600)
+        assert r2.returncode != 0 and "{" not in r2.stdout

@@ -346,6 +346,112 @@ def test_spmm_bundle_plan_is_a_partition_of_the_work(d, n_waves):
     assert per_class.max() <= 1.5 * per_class.mean() + (piece + 32)
 
 
+@pytest.mark.parametrize("d,n_waves", [(64, 32), (64, 64), (16, 32), (256, 32), (8, 32)])
+def test_spmm_stream_pack_reproduces_the_product(d, n_waves):
+    """gdmcf_spmm_stream_f32's input (gdmcf_amd/lightgcn.py:spmm_stream_pack), walked in numpy exactly as the kernel does
+    (csrc/spmm_bundle.hip: spmm_stream_kernel): wave by wave, batch by batch, UN steps at a time, lane group g taking entry
+    step*G + g; pieces are summed over the lane groups and go to their slot or row, bundles write one row per lane group.
+    The result must be A @ X, every real nonzero must appear exactly once with its value, padding must have weight 0."""
+    import scipy.sparse as sp
+    from gdmcf_amd.lightgcn import spmm_bundle_plan, spmm_stream_pack
+    rng = np.random.default_rng(3 * d + n_waves)
+    n, m = 257, 190
+    deg = np.minimum(rng.zipf(1.6, n), m)
+    deg[5], deg[6], deg[7] = 0, m, 150
+    rows = np.repeat(np.arange(n), deg)
+    cols = np.concatenate([np.sort(rng.choice(m, k, replace=False)) for k in deg])
+    A = sp.csr_matrix((rng.standard_normal(len(rows)).astype(np.float32), (rows, cols)), shape=(n, m))
+    A.sort_indices()
+    X = rng.standard_normal((m, d))
+    plan = spmm_bundle_plan(A.indptr, A.indices, d=d, n_waves=n_waves, s_max=12, piece=40, n_cols=m)
+    sp_ = spmm_stream_pack(plan, A.indptr, A.indices, A.data, d=d)
+    G, UN, DW = sp_["G"], sp_["UN"], sp_["DW"]
+    LPR = 64 // G
+    assert UN == min(4, LPR) and DW == 1 + max(G, 2) and sp_["n_entries"] % 64 == 0
+    cw = sp_["cw"].reshape(-1, 2)
+    cc, ww = cw[:, 0], cw[:, 1].copy().view(np.float32)
+    ud = sp_["ud"].reshape(-1, DW)
+    wd = sp_["wdesc"].reshape(n_waves, 4)
+    Y = np.full((n, d), np.nan)
+    written = np.zeros(n, int)
+    partial = np.full((max(sp_["n_slots"], 1), d), np.nan)
+    units_seen = np.zeros(sp_["n_units"], int)
+    real = []  # (col, val) of every entry with a weight
+    for w in range(n_waves):
+        sb, nb, u0, u1 = wd[w]
+        pos = sb * 64  # entry index of the current step's group-0 lane
+        for u in range(u0, u1):
+            units_seen[u] += 1
+            hdr = int(ud[u, 0])
+            ngroups = hdr & 0x7FFFFFFF
+            acc = np.zeros((G, d))
+            for _ in range(ngroups * UN):
+                assert pos + G <= (sb + nb) * 64
+                for g in range(G):
+                    c, wt = cc[pos + g], ww[pos + g]
+                    assert 0 <= c < m
+                    acc[g] += float(wt) * X[c]
+                    if wt != 0:
+                        real.append((u, g, c, wt))
+                pos += G
+            if hdr < 0:
+                row, slot = ud[u, 1], ud[u, 2]
+                if slot >= 0:
+                    partial[slot] = acc.sum(0)
+                else:
+                    Y[row] = acc.sum(0)
+                    written[row] += 1
+            else:
+                for g in range(G):
+                    a = int(ud[u, 1 + g])
+                    if a < 0:
+                        assert not acc[g].any()
+                        continue
+                    r = a & 0x3FFFFFFF
+                    Y[r] = 0.0 if a & 0x40000000 else acc[g]
+                    assert (a & 0x40000000 != 0) == (deg[r] == 0)
+                    written[r] += 1
+        assert pos <= (sb + nb) * 64 and ((sb + nb) * 64 - pos < 64 or u0 == u1)  # the run is exactly the wave's units
+        kinds = [int(ud[u, 0]) < 0 for u in range(u0, u1)]
+        assert kinds == sorted(kinds, reverse=True)  # a wave runs its pieces first, then its bundles
+    assert (units_seen == 1).all()
+    for i, r in enumerate(sp_["crow"]):
+        sl = partial[sp_["cptr"][i]:sp_["cptr"][i + 1]]
+        assert len(sl) >= 2 and not np.isnan(sl).any()
+        Y[r] = sl.sum(0)
+        written[r] += 1
+    assert (written == 1).all()
+    np.testing.assert_allclose(Y, A @ X, rtol=1e-6, atol=1e-6)
+    assert len(real) == (A.data != 0).sum()
+
+
+def test_bench_gpus_n_starts_n_ranks_or_fails_loudly():
+    """`python bench.py --gpus N` (the shape of the command the driver runs) must produce an N-rank line or no line: the
+    parent starts N fresh rank processes itself (dry run here: the ranks meet in a gloo group on the CPU, nothing is timed),
+    and a rank count that does not match --gpus is an error, never a silent n_gpus = 1."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, GDMCF_BENCH_DRY_RUN="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["ranks_in_group"] == 2 and line["dry_run"] is True
+    # launched as ONE rank but asked for two GPUs: refuse (before anything touches a GPU)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="1", RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "--gpus 2 but WORLD_SIZE=1" in r.stderr and "{" not in r.stdout
+    # no dry run, no GPUs here: the parent refuses to start fewer ranks than asked for
+    if not torch.cuda.is_available():
+        env2 = {k: v for k, v in env.items() if k != "GDMCF_BENCH_DRY_RUN"}
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env2, capture_output=True,
+                           text=True, timeout=300)
+        assert r.returncode != 0 and "GPU(s) visible" in r.stderr and "{" not in r.stdout
+
+
 def test_header_is_plain_c(tmp_path):
     """include/gdmcf_hip.h is the C ABI: it must compile as C99 with nothing but the standard headers (no C++, no HIP,
     no torch types in any signature)."""

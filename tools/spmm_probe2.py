@@ -16,9 +16,10 @@ U = cfg["n_users"]
 users = np.repeat(np.arange(U), np.diff(indptr))
 t0 = time.time()
 m = gdmcf_amd.LightGCN({"user_id_idx": users, "item_id_idx": indices}, U, I, 1, 64, device=dev).to(dev)
-print(f"{shape}: graph + schedule built in {time.time() - t0:.2f} s; generation {'2 (bundled)' if m._bundled else '1'}; "
-      f"waves {m._plan.get('n_waves')}, pieces {m._plan.get('n_pieces')}, bundles {m._plan.get('n_bundles')}, cut rows "
-      f"{m._plan['crow'].numel() if m._bundled else m._plan['lrow'].numel()}")
+print(f"{shape}: graph + schedule built in {time.time() - t0:.2f} s; generation {'3 (streamed)' if m._streamed else '2 (bundled)' if m._bundled else '1'}; "
+      f"waves {m._plan.get('n_waves')}, pieces {m._plan.get('n_pieces')}, bundles {m._plan.get('n_bundles')}, units "
+      f"{m._plan.get('n_units')}, entries {m._plan.get('n_entries')}, cut rows "
+      f"{m._plan['crow'].numel() if (m._bundled or m._streamed) else m._plan['lrow'].numel()}")
 nnz, alg = m.nnz, m.algorithmic_bytes()
 X = torch.randn(U + I, 64, device=dev)
 
@@ -45,7 +46,10 @@ def timeit(n=50):
 
 t, wall = timeit()
 print(f"real columns            {t:8.1f} us/layer (wall {wall:.1f})  algorithmic {alg / t / 1e6:.2f} TB/s = {alg / t / 8e6:.3f} of 8 TB/s; gathered {nnz * 256 / t / 1e6:.2f} TB/s")
-col = m.norm_adj_csr[1]
+if m._streamed:
+    col = m._plan["cw"].view(-1, 2)[:, 0]
+else:
+    col = m.norm_adj_csr[1]
 keep = col.clone()
 for span in (2048, 8192):
     col.copy_(keep % span)

@@ -1,6 +1,2 @@
-echo "== default (nt off)"; GDMCF_SPMM_NT=0 python tools/spmm_probe2.py yelp 2>&1 | grep -E "yelp:|real|only|mod  2048"
-echo "== nt on"; GDMCF_SPMM_NT=1 python tools/spmm_probe2.py yelp 2>&1 | grep -E "real"
-echo "== smax 128"; GDMCF_SPMM_NT=0 GDMCF_SPMM_SMAX=128 python tools/spmm_probe2.py yelp 2>&1 | grep -E "yelp:|real|only"
-echo "== smax 32"; GDMCF_SPMM_NT=0 GDMCF_SPMM_SMAX=32 python tools/spmm_probe2.py yelp 2>&1 | grep -E "yelp:|real|only"
-echo "== waves 8192"; GDMCF_SPMM_NT=0 GDMCF_SPMM_WAVES=8192 python tools/spmm_probe2.py yelp 2>&1 | grep -E "yelp:|real|only"
-echo "== stress"; GDMCF_SPMM_NT=0 python tools/spmm_probe2.py stress 2>&1 | grep -E "stress:|real|only"
+for D in 0 8 1 9 11 15; do echo "== gen3 dbg $D (1 no stores, 2 no piece reduction, 4 no descriptor loads, 8 no combine kernel)"; GDMCF_SPMM_DBG=$D GDMCF_SPMM_GEN=3 python tools/spmm_probe2.py yelp 2>&1 | grep -E "real|mod  2048"; done
+for D in 0 9 15; do echo "== gen3 stress dbg $D"; GDMCF_SPMM_DBG=$D GDMCF_SPMM_GEN=3 python tools/spmm_probe2.py stress 2>&1 | grep -E "real|mod  2048"; done
