@@ -300,6 +300,62 @@ __global__ __launch_bounds__(256) void onehot_noise_kernel(const float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------
+// degree-guided graph of the reverse loop (reference gaussian_diffusion.py:706-729): per reverse step the reference
+// draws a class for every (user, item) from row c of Q_bar(t / batch) where c is the edge's state so far
+// (apply_noise on the accumulated one-hot graph), draws ONE bit per user from [1 - deg/maxdeg, deg/maxdeg]
+// (multinomial(1)), ANDs the two when args.user_guided and ORs the result into the graph.  As bits:
+//   graph[b,i] |= s[b,i] & (user_guided ? pick[b] : 1),   s ~ (u < a*[c == 1] + (1 - a)*(1 - e)),  a = (float)ts[b]/B.
+// One byte per edge state, four items per thread; Philox4x32-10 streams 5 (classes) and 6 (user bits).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void graph_step_kernel(uint8_t* __restrict__ graph, int64_t ldg, const int64_t* __restrict__ ts,
+                                                        int B, int I, float p1_off, const uint8_t* __restrict__ sampled,
+                                                        int64_t lds, const uint8_t* __restrict__ pick_in,
+                                                        const float* __restrict__ degp, int user_guided, uint64_t seed,
+                                                        uint64_t offset, uint8_t* __restrict__ sampled_out, int64_t ldso,
+                                                        uint8_t* __restrict__ pick_out) {
+    const int b = blockIdx.y;
+    const int i0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const uint2 key = make_uint2((uint32_t)seed, (uint32_t)(seed >> 32));
+    int pick = 1;
+    if (pick_in) {
+        pick = pick_in[b] != 0;
+    } else if (degp) {  // one draw per user, the same in every thread of the row
+        const uint4 r = philox4x32_10(make_uint4(0xFFFFFFFFu, (uint32_t)b, 6u, (uint32_t)offset), key);
+        pick = ((float)(r.x >> 8) * 5.9604644775390625e-8f) < degp[b];
+    }
+    if (pick_out && blockIdx.x == 0 && threadIdx.x == 0) pick_out[b] = (uint8_t)pick;
+    if (i0 >= I) return;
+    uint32_t u[4] = {0u, 0u, 0u, 0u};
+    float a = 1.f;
+    if (!sampled) {
+        const uint4 r = philox4x32_10(make_uint4((uint32_t)(i0 >> 2), (uint32_t)b, 5u, (uint32_t)offset), key);
+        u[0] = r.x; u[1] = r.y; u[2] = r.z; u[3] = r.w;
+        a = __fdiv_rn((float)ts[b], (float)B);
+    }
+    const int gate = user_guided ? pick : 1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (i0 + j >= I) break;
+        uint8_t* gp = graph + (int64_t)b * ldg + i0 + j;
+        const int c = *gp != 0;
+        int s;
+        if (sampled) {
+            s = sampled[(int64_t)b * lds + i0 + j] != 0;
+        } else {
+            float p1;
+            {
+#pragma clang fp contract(off)
+                const float q = (1.f - a) * p1_off;
+                p1 = (c ? a : 0.f) + q;
+            }
+            s = ((float)(u[j] >> 8) * 5.9604644775390625e-8f) < p1;
+        }
+        if (sampled_out) sampled_out[(int64_t)b * ldso + i0 + j] = (uint8_t)s;
+        *gp = (uint8_t)(c | (s & gate));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // pieces of the indexIn backbone (reference models/DNN.py:510-682): embedding-row gather / scatter, row norms and
 // the backward of x / |x| for the cosine scores, tanh' on a gradient with an extra addend.  All HBM-bound, one
 // workgroup per row (16-byte accesses along the row), reductions in a fixed order (deterministic).
@@ -925,6 +981,20 @@ int gdmcf_onehot_noise_f32(const float* x0, int64_t ldx, const int64_t* ts, int 
                            I, p1_off, sampled, lds, seed, offset, xU, ldu, sampled_out, ldso);
     }
     return gd_launch_status("onehot_noise");
+}
+
+int gdmcf_graph_guided_step_u8(uint8_t* graph, int64_t ldg, const int64_t* ts, int B, int I, float discrete,
+                               const uint8_t* sampled_in, int64_t lds, const uint8_t* pick_in, const float* degree_prob,
+                               int user_guided, uint64_t seed, uint64_t offset, uint8_t* sampled_out, int64_t ldso,
+                               uint8_t* pick_out, void* stream) {
+    GD_CHECK_SHAPE(B > 0 && I > 0 && ldg >= I, "graph_guided_step: bad shape");
+    GD_CHECK_ARG(graph && (sampled_in ? lds >= I : ts != nullptr) && (!sampled_out || ldso >= I),
+                 "graph_guided_step: null pointer / bad leading dimension");
+    GD_CHECK_ARG(!user_guided || pick_in || degree_prob, "graph_guided_step: user_guided needs pick_in or degree_prob");
+    const float p1_off = (float)(1.0 - (double)discrete);
+    hipLaunchKernelGGL(graph_step_kernel, dim3(gd_cdiv(I, 1024), B), dim3(256), 0, (hipStream_t)stream, graph, ldg, ts, B, I,
+                       p1_off, sampled_in, lds, pick_in, degree_prob, user_guided, seed, offset, sampled_out, ldso, pick_out);
+    return gd_launch_status("graph_guided_step");
 }
 
 int gdmcf_row_norms_f32(const float* X, int64_t ld, int rows, int cols, float* norm, float* inv_norm, void* stream) {

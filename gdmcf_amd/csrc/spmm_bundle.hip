@@ -242,10 +242,12 @@ __global__ __launch_bounds__(256) void spmm_bundle_kernel(const SpmmBundlePlan p
 // run and of its descriptors once when it starts (one HBM round trip for everything), after which every load it waits
 // for is an L2 hit.
 // ---------------------------------------------------------------------------------------------------------------------
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+
 struct SpmmStreamPlan {
     const int32_t* wdesc;  // [n_waves][4] = first batch of the wave's run, its batches, first / last+1 unit
     int waves_per_class;
-    const int2* cw;        // (col, float bits of val), 64 entries per batch
+    const i32x2* cw;       // (col, float bits of val), 64 entries per batch
     const int32_t* ud;     // [n_units][DW]
 };
 
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(256) void spmm_stream_kernel(const SpmmStreamPlan p
     const int u0 = __builtin_amdgcn_readfirstlane(pl.wdesc[4 * w + 2]);
     const int u1 = __builtin_amdgcn_readfirstlane(pl.wdesc[4 * w + 3]);
     if (u0 >= u1) return;
-    const int2* __restrict__ run = pl.cw + (int64_t)sb * 64;
+    const i32x2* __restrict__ run = pl.cw + (int64_t)sb * 64;
     const int32_t* __restrict__ udw = pl.ud + (int64_t)u0 * DW;
     // ---- warm-up: one dword of every 128-byte line (16 entries) of the first 32 batches and of the descriptors ----
     // (independent registers, consumed only at the very end: three loads in flight together, one HBM round trip)
@@ -280,8 +282,8 @@ __global__ __launch_bounds__(256) void spmm_stream_kernel(const SpmmStreamPlan p
         t2 = udw[min(lane * 32, dlast)];
     }
     // the run and the results are streamed (non-temporal): an XCD's L2 is for the rows of X it gathers again and again
-    int2 cur = __builtin_nontemporal_load(run + lane);
-    int2 nxt = __builtin_nontemporal_load(run + min(1, nb - 1) * 64 + lane);
+    i32x2 cur = __builtin_nontemporal_load(run + lane);
+    i32x2 nxt = __builtin_nontemporal_load(run + min(1, nb - 1) * 64 + lane);
     int b = 0, q = 0;
     int hA = udw[0], aA = udw[1 + g], sA = udw[2];
     for (int u = u0; u < u1; ++u) {
@@ -474,7 +476,7 @@ extern "C" int gdmcf_spmm_stream_f32(const int32_t* wdesc, int n_waves, const in
         gdmcf_set_error("spmm_stream: needs d in {8,16,32,64,128,256} and 16-byte aligned rows (use gdmcf_spmm_csr_f32 otherwise)");
         return GDMCF_E_UNSUPPORTED;
     }
-    SpmmStreamPlan pl = {wdesc, n_waves / 8, reinterpret_cast<const int2*>(cw), ud};
+    SpmmStreamPlan pl = {wdesc, n_waves / 8, reinterpret_cast<const i32x2*>(cw), ud};
     hipStream_t s = (hipStream_t)stream;
     const int n_blocks = n_waves / 4;
     const bool wide = (double)n_x_rows * (double)ldx * 4.0 >= 4294967296.0 || ldx * 4 >= (int64_t)1 << 31;

@@ -297,6 +297,8 @@ class GaussianDiffusionDiscrete(GaussianDiffusion):
         self.args = args
         self.discrete_noise = True
         self.indexIn = False
+        self.user_guided = bool(getattr(args, "user_guided", False))  # the only field of `args` the reference reads (:720)
+        self.last_graph = None
 
     # -- the reference's public pieces of the discrete noise, for callers that use them directly -------------------
     def get_Qt_bar(self, alpha_bar_t):
@@ -379,7 +381,13 @@ class GaussianDiffusionDiscrete(GaussianDiffusion):
         return {"loss": loss}
 
     def p_sample(self, model, x_start, steps, sampling_noise=False, index=None, *, noise0=None, step_noise=None,
-                 capture=None, sampled0=None):
+                 capture=None, sampled0=None, graph_sampled=None, graph_pick=None):
+        """Reverse loop of the one-hot variant (reference :668-768).  With `indexIn` (the embedding backbones) every reverse
+        step also advances the degree-guided graph of :706-729 on the device (gdmcf_graph_guided_step_u8: classes drawn
+        from the accumulated graph's transition rows, one bit per user drawn from its relative degree, AND-ed when
+        args.user_guided, OR-ed into the graph) and hands it to the model as `graph=` -- a uint8 [B, I] tensor of edge
+        states (the reference passes its one-hot [B, I, 2] image).  `graph_sampled` [T, B, I] / `graph_pick` [T, B] (uint8)
+        inject the draws (parity runs); `self.last_graph` keeps the final graph, `capture["graph"]` every step's."""
         if not self.CatOneHot:
             return super().p_sample(model, x_start, steps, sampling_noise, index, noise0=noise0, step_noise=step_noise,
                                     capture=capture)
@@ -397,12 +405,23 @@ class GaussianDiffusionDiscrete(GaussianDiffusion):
                 t = torch.full((B,), steps - 1, dtype=torch.int64, device=dev)
                 x_tU, keep = model.engine.onehot_rows(x0, t, sampled0, self.discrete)
                 x_t = self.q_sample(x0, t, noise0) if self.noise_scale != 0.0 else x0
+            graph = degp = None
+            if self.indexIn and self.noise_scale != 0.0:
+                graph = torch.zeros(B, x0.shape[1], dtype=torch.uint8, device=dev)
+                deg = x0.sum(dim=1)
+                degp = (deg / deg.max()).float().contiguous()  # :710-711 (a batch without any interaction gives nan, as there)
             for n, i in enumerate(list(range(self.steps))[::-1]):
                 t = torch.full((B,), i, dtype=torch.int64, device=dev)
                 kw = dict(index=index) if self.indexIn else {}
                 if self.noise_scale == 0.0:
                     x_t = model(x_t, t, x_tU, **kw)
                     continue
+                if graph is not None:
+                    self._graph_step(graph, t, degp, None if graph_sampled is None else graph_sampled[n],
+                                     None if graph_pick is None else graph_pick[n])
+                    kw["graph"] = graph
+                    if capture is not None:
+                        capture.setdefault("graph", []).append(graph.clone())
                 out = model(x_t, t, x_tU, **kw)
                 pred = out if self.mean_type == ModelMeanType.START_X else self._predict_xstart_from_eps(x_t, t, eps=out)
                 mean, _, logvar = self.q_posterior_mean_variance(x_start=pred, x_t=x_t, t=t)
@@ -416,7 +435,21 @@ class GaussianDiffusionDiscrete(GaussianDiffusion):
                 else:
                     x_t = mean
             del keep
+            self.last_graph = graph
             return x_t
+
+    def _graph_step(self, graph, t, degp, sampled=None, pick=None, sampled_out=None, pick_out=None):
+        """graph |= s & (user_guided ? pick : 1) for one reverse step (reference :709-727), in place, on the device."""
+        B, I = graph.shape
+        self._noise_calls = getattr(self, "_noise_calls", 0) + 1
+        u8 = lambda v: None if v is None else v.to(device=graph.device, dtype=torch.uint8).contiguous()
+        sampled, pick = u8(sampled), u8(pick)
+        _lib.check(_lib.load().gdmcf_graph_guided_step_u8(
+            graph.data_ptr(), graph.stride(0), t.data_ptr(), B, I, float(self.discrete), _lib.ptr(sampled),
+            sampled.stride(0) if sampled is not None else 0, _lib.ptr(pick), _lib.ptr(degp), int(self.user_guided),
+            int(torch.initial_seed()) & (2 ** 63 - 1), (1 << 42) + self._noise_calls, _lib.ptr(sampled_out),
+            sampled_out.stride(0) if sampled_out is not None else 0, _lib.ptr(pick_out), _lib.stream_ptr()))
+        return graph
 
 
 # ---- module-level helpers of the reference file (kept for API parity) -------------------------------

@@ -222,6 +222,33 @@ class DNNOneHotEmbedding(DNNOneHot):
             self._engine = OneHotEmbeddingEngine(self)
         return self._engine
 
+    @torch.no_grad()
+    def load_lightgcn_embeddings(self, lightgcn, users=True, items=True):
+        """Hand-off of the LightGCN propagation into the denoiser (the reference's script only saves
+        final_user_Embed / final_item_Embed, lightGCN.py:305-323, and nothing reads them).  The propagated tables
+        mean_l(A~^l E0) (HIP SpMM, gdmcf_amd.LightGCN.propagate_through_layers) initialise the tables this backbone
+        conditions on (reference models/DNN.py:1148-1149, read at :1263-1265 / :1274):
+          embedding_user.weight          <- final_user                       (the user row appended to [h, h_U], :1274)
+          embedding_item.weight[:, -w:]  <- final_item, w = user width       (the columns that meet the user row in the
+                                                                              cosine score, :1288-1289)
+        so that score(u, i) contains <e_u, e_i> of the graph model from the first step on.  Needs latent_dim == the user
+        embedding width (in_dims[-1] by construction, :1144).  Returns (final_user, final_item)."""
+        fu, fi, _, _ = lightgcn.propagate_through_layers()
+        wu = self.embedding_user.weight
+        if users:
+            if fu.shape != wu.shape:
+                raise ValueError(f"LightGCN user table {tuple(fu.shape)} does not fit embedding_user {tuple(wu.shape)}")
+            wu.copy_(fu)
+        if items:
+            wi = self.embedding_item.weight
+            if fi.shape != (wi.shape[0], wu.shape[1]):
+                raise ValueError(f"LightGCN item table {tuple(fi.shape)} does not fit the last {wu.shape[1]} columns of "
+                                 f"embedding_item {tuple(wi.shape)}")
+            wi[:, wi.shape[1] - wu.shape[1]:].copy_(fi)
+        for p_ in (self.embedding_user.weight, self.embedding_item.weight):
+            torch.autograd.graph.increment_version(p_)  # cached V/|v| and shadows are keyed on the version counter
+        return fu, fi
+
     def forward(self, x, timesteps, x_U, index=None, graph=None, RCloss=False, drop_mask=None, drop_mask_U=None):
         """model(x_t, t, x_tU, index=..., graph=...) of the reference's evaluation path (`graph` is accepted and, as in the
         reference, unused).  Training goes through GaussianDiffusionDiscrete.training_losses."""

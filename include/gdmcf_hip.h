@@ -111,6 +111,20 @@ int gdmcf_onehot_noise_f32(const float* x0, int64_t ldx, const int64_t* ts, int 
                            const uint8_t* sampled, int64_t lds, uint64_t seed, uint64_t offset,
                            float* xU, int64_t ldu, uint8_t* sampled_out, int64_t ldso, void* stream);
 
+/* ---- degree-guided graph of the reverse loop (gaussian_diffusion.py:706-729, inside GaussianDiffusionDiscrete.p_sample) ----
+ * One reverse step's update of the accumulated user-item graph, one byte per edge state:
+ *   s[b,i] ~ row c of Q = a*I + (1-a)*[[e,1-e],[e,1-e]], c = graph[b,i], a = (float)ts[b]/B, e = discrete   (apply_noise on
+ *            the accumulated one-hot graph, :709);
+ *   pick[b] ~ Bernoulli(degree_prob[b]), degree_prob = row sum / largest row sum of x_start   (multinomial(1), :710-716);
+ *   graph[b,i] |= s[b,i] & (user_guided ? pick[b] : 1)                                          (:719-727).
+ * sampled_in / pick_in (optional, uint8): the draws are given (parity runs); otherwise Philox4x32-10, key seed, counters
+ * (i>>2, b, 5, offset) for the classes and (0xFFFFFFFF, b, 6, offset) for the user bit.  sampled_out / pick_out
+ * (optional) receive the draws.  The graph is what the reference hands to the denoiser as `graph=` (:744).              */
+int gdmcf_graph_guided_step_u8(uint8_t* graph, int64_t ldg, const int64_t* ts, int B, int I, float discrete,
+                               const uint8_t* sampled_in, int64_t lds, const uint8_t* pick_in, const float* degree_prob,
+                               int user_guided, uint64_t seed, uint64_t offset, uint8_t* sampled_out, int64_t ldso,
+                               uint8_t* pick_out, void* stream);
+
 /* Rewrites only the embedding + padding columns [I, ldxin) of xin for new timesteps (reverse
  * loop: x_t already sits in xin[:, 0:I], written by gdmcf_linear_posterior_fwd_f32).          */
 int gdmcf_dnn_emb_cols_f32(const int64_t* ts, const float* emb_w, const float* emb_b, int E, int B,

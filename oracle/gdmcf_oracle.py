@@ -673,6 +673,9 @@ class GaussianDiffusionDiscrete(GaussianDiffusion):
                 if self.user_guided:
                     g_i = g_i & torch.nn.functional.one_hot(pick, num_classes=2)
                 zero = graph = torch.nn.functional.one_hot(g_i.argmax(dim=2) | zero.argmax(dim=2), num_classes=2)
+                if capture is not None:
+                    capture.setdefault("graph", []).append(graph.argmax(dim=2).clone())
+                    capture.setdefault("pick", []).append(pick[:, 0].clone())
             out = self._p_mean_variance_onehot(model, x_t, t, x_tU, index, graph)
             if capture is not None:
                 capture.setdefault("pred_xstart", []).append(out["pred_xstart"])
@@ -793,6 +796,15 @@ def lightgcn_propagate(A_csr, E0, n_layers, n_users):
     return mean[:n_users], mean[n_users:], E0[:n_users], E0[n_users:], layers
 
 
+def bpr_loss(users, users_emb, pos_emb, neg_emb, userEmb0, posEmb0, negEmb0):
+    """(mf_loss, reg_loss) -- reference lightGCN.py:207-219; pinned by tests/golden/bpr_loss.npz (outputs of the reference's
+    own function, oracle/gen_golden.py:gen_bpr)."""
+    reg_loss = (1 / 2) * (userEmb0.norm().pow(2) + posEmb0.norm().pow(2) + negEmb0.norm().pow(2)) / float(len(users))
+    pos_scores = torch.sum(torch.mul(users_emb, pos_emb), dim=1)
+    neg_scores = torch.sum(torch.mul(users_emb, neg_emb), dim=1)
+    return torch.mean(torch.nn.functional.softplus(neg_scores - pos_scores)), reg_loss
+
+
 def lightgcn_bpr_step(A_csr, E0, n_layers, n_users, users, pos, neg, decay):
     """One BPR objective evaluation with autograd (reference lightGCN.py:196-219, :291-298): returns
     (mf_loss, reg_loss, dE0) using torch.sparse.mm on the same normalised adjacency."""
@@ -808,7 +820,6 @@ def lightgcn_bpr_step(A_csr, E0, n_layers, n_users, users, pos, neg, decay):
     iu, ii = E[:n_users], E[n_users:]
     users, pos, neg = (torch.as_tensor(v, dtype=torch.int64) for v in (users, pos, neg))
     ue, pe, ne, u0, p0, n0 = fu[users], fi[pos], fi[neg], iu[users], ii[pos], ii[neg]
-    reg = 0.5 * (u0.norm().pow(2) + p0.norm().pow(2) + n0.norm().pow(2)) / float(len(users))
-    mf = torch.mean(torch.nn.functional.softplus((ue * ne).sum(1) - (ue * pe).sum(1)))
+    mf, reg = bpr_loss(users, ue, pe, ne, u0, p0, n0)
     (mf + decay * reg).backward()
     return float(mf), float(reg), E.grad.numpy()

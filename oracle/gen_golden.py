@@ -591,10 +591,96 @@ def gen_onehot():
     gen_sample_onehot("ragged_eps", 10, 131, [24], 5, "eps", seed=42, scale=50.0)
 
 
+def gen_bpr(seed=7):
+    """`bpr_loss` of the reference's LightGCN script (lightGCN.py:207-219, AST-extracted: the module itself trains at
+    import): losses and the gradients w.r.t. every input on random embeddings, two batch sizes."""
+    (ref_bpr,) = _extract(f"{REF}/lightGCN.py", ["bpr_loss"], dict(torch=torch))
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for tag, (B, d) in (("a", (64, 16)), ("b", (257, 64))):
+        ins = [torch.randn(B, d, generator=g, requires_grad=True) for _ in range(6)]
+        users = torch.arange(B)
+        mf, reg = ref_bpr(users, *ins)
+        (mf + 1e-4 * reg).backward()
+        out[f"{tag}.mf"], out[f"{tag}.reg"] = npy(mf), npy(reg)
+        for k, t in zip(("users_emb", "pos_emb", "neg_emb", "userEmb0", "posEmb0", "negEmb0"), ins):
+            out[f"{tag}.{k}"] = npy(t)
+            out[f"{tag}.g_{k}"] = npy(t.grad)
+    np.savez_compressed(os.path.join(OUT, "bpr_loss.npz"), **out)
+    print("bpr_loss:", float(out["a.mf"]), float(out["b.reg"]))
+
+
+class _ArgsGuided:
+    user_guided = True
+
+
+def gen_graph_guided(name, B, I, T, user_guided, seed, density=0.1, scale=0.01):
+    """Degree-guided graph of GaussianDiffusionDiscrete.p_sample (:706-744): the real reverse loop on the CPU with
+    indexIn = True (so that `graph=` reaches the model, :1073) around a stand-in denoiser that records it.  Captured per
+    reverse step: the classes drawn by apply_noise on the accumulated graph, the one bit per user drawn from its degree,
+    the transition probabilities, and the graph handed to the model."""
+    import contextlib
+    import io
+    torch.manual_seed(seed)
+    g = torch.Generator().manual_seed(seed + 100)
+    with contextlib.redirect_stdout(io.StringIO()):
+        diff = gd.GaussianDiffusionDiscrete(gd.ModelMeanType.START_X, "linear-var", scale, 0.001, 0.01, T, "cpu", discrete=0.99,
+                                            CatOneHot=True, args=_ArgsGuided() if user_guided else _Args())
+    diff.indexIn = True
+    x = make_rows(B, I, density, g)
+    x[0] = 0.0  # a user without interactions (degree probability 0) ...
+    x[1, : I // 2] = 1.0  # ... and the one with the largest degree (probability 1)
+    cap = dict(sampled=[], probX=[], pick=[], graph=[])
+    orig_sd = diff.sample_discrete_features
+
+    def sd(probX):
+        r = orig_sd(probX)
+        cap["sampled"].append(r.clone())
+        cap["probX"].append(probX[..., 1].clone())
+        return r
+
+    diff.sample_discrete_features = sd
+    orig_mn = torch.Tensor.multinomial
+
+    def mn(self, *a, **k):
+        r = orig_mn(self, *a, **k)
+        if self.dim() == 2 and self.shape == (B, 2):
+            cap["pick"].append(r.clone())
+        return r
+
+    def model(x_t, t, x_tU, index=None, graph=None):
+        cap["graph"].append(graph.argmax(dim=2).clone())
+        return x_t * 0.5
+
+    torch.Tensor.multinomial = mn
+    try:
+        pred = diff.p_sample(model, x, 0, False, index=_Index())
+    finally:
+        torch.Tensor.multinomial = orig_mn
+    assert len(cap["graph"]) == T and len(cap["pick"]) == T and len(cap["sampled"]) == T
+    out = dict(meta=np.array([f"{B}|{I}|{T}|{int(user_guided)}|{scale}|0.99|{seed}"]), x_start=npy(x).astype(np.uint8),
+               sampled=np.stack([npy(t) for t in cap["sampled"]]).astype(np.uint8),
+               pick=np.stack([npy(t)[:, 0] for t in cap["pick"]]).astype(np.uint8),
+               prob1=np.stack([npy(t) for t in cap["probX"]]).astype(np.float32),
+               graph=np.stack([npy(t) for t in cap["graph"]]).astype(np.uint8), pred=npy(pred))
+    np.savez_compressed(os.path.join(OUT, f"graph_guided_{name}.npz"), **out)
+    print(f"graph_guided_{name}: edges per step {out['graph'].reshape(T, -1).sum(1).tolist()}, picks {out['pick'].sum(1).tolist()}")
+
+
+def gen_round2():
+    gen_bpr()
+    gen_graph_guided("plain", 12, 97, 5, False, seed=61)
+    gen_graph_guided("guided", 12, 97, 5, True, seed=62)
+    gen_graph_guided("guided_T9", 20, 64, 9, True, seed=63, density=0.2)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if sys.argv[1:] == ["onehot"]:  # only the fixtures of the one-hot variant
         gen_onehot()
+        sys.exit(0)
+    if sys.argv[1:] == ["round2"]:  # bpr_loss + the degree-guided graph of the reverse loop
+        gen_round2()
         sys.exit(0)
     gen_data_load()
     gen_schedules()
@@ -617,3 +703,4 @@ if __name__ == "__main__":
     gen_lightgcn("small", 50, 40, 8, 3, 300, seed=0)
     gen_lightgcn("mid", 600, 400, 64, 3, 6000, seed=1)
     gen_onehot()
+    gen_round2()

@@ -384,3 +384,103 @@ def test_gcn_backbone_matches_the_restated_oracle(layers):
         want = od.p_sample(om, x, 0, False, sampled0=torch.zeros(1), index=idx)
     got = gd_.p_sample(gm, cu(x), 0, False, index=idx)
     assert H.relerr(got.cpu().numpy(), want.numpy()) < 2e-4
+
+
+@pytest.mark.parametrize("case", ["plain", "guided", "guided_T9"])
+def test_degree_guided_graph_of_the_reverse_loop_matches_reference(case):
+    """GaussianDiffusionDiscrete.p_sample with indexIn: the per-step degree-guided graph (reference :706-744) built on the
+    device by gdmcf_graph_guided_step_u8.  With the reference's draws injected (classes per item, one bit per user) the graph
+    handed to the model at every reverse step equals the one the reference handed to its model, bit for bit."""
+    fx = H.load("graph_guided_" + case)
+    B, I, T, guided, scale, disc, _ = str(fx["meta"][0]).split("|")
+    B, I, T, guided = int(B), int(I), int(T), bool(int(guided))
+
+    class A:
+        user_guided = guided
+
+    d = gdmcf_amd.GaussianDiffusionDiscrete(gdmcf_amd.ModelMeanType.START_X, "linear-var", float(scale), 0.001, 0.01, T, DEV,
+                                            discrete=float(disc), CatOneHot=True, args=A())
+    d.indexIn = True
+    torch.manual_seed(0)
+    model = gdmcf_amd.DNNOneHotEmbedding([I, 16], [16, I], 10, item_num=I, user_num=B).to(DEV).eval()
+    seen = []
+    inner = model.forward
+
+    def spy(x, t, x_U, index=None, graph=None, **kw):
+        seen.append(graph.clone())
+        return inner(x, t, x_U, index=index, graph=graph, **kw)
+
+    model.forward = spy
+    x = torch.from_numpy(fx["x_start"].astype(np.float32)).to(DEV)
+    cap = {}
+    d.p_sample(model, x, 0, False, index=torch.arange(B), capture=cap, graph_sampled=torch.from_numpy(fx["sampled"]).to(DEV),
+               graph_pick=torch.from_numpy(fx["pick"]).to(DEV))
+    assert len(seen) == T and seen[0].dtype == torch.uint8
+    np.testing.assert_array_equal(torch.stack(seen).cpu().numpy(), fx["graph"])
+    np.testing.assert_array_equal(d.last_graph.cpu().numpy(), fx["graph"][-1])
+    np.testing.assert_array_equal(torch.stack(cap["graph"]).cpu().numpy(), fx["graph"])
+
+
+def test_degree_guided_graph_draws_follow_the_transition_rows():
+    """Un-injected: the in-kernel Philox draws of gdmcf_graph_guided_step_u8 follow the reference's probabilities --
+    P(edge appears) = (1-a)(1-e), P(edge stays) = a + (1-a)(1-e), a = t/B (:775), user bit ~ deg/maxdeg (:710-716) -- and an
+    edge that is in the graph stays in it."""
+    from gdmcf_amd import _lib
+    B, I, e = 64, 20000, 0.9
+    d = gdmcf_amd.GaussianDiffusionDiscrete(gdmcf_amd.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, 40, DEV,
+                                            discrete=e, CatOneHot=True)
+    g = torch.zeros(B, I, dtype=torch.uint8, device=DEV)
+    g[:, ::2] = 1
+    before = g.clone()
+    t = torch.full((B,), 16, dtype=torch.int64, device=DEV)  # a = 16/64 = 0.25
+    degp = torch.linspace(0, 1, B, device=DEV)
+    sampled = torch.empty_like(g)
+    pick = torch.empty(B, dtype=torch.uint8, device=DEV)
+    d.user_guided = False
+    d._graph_step(g, t, degp, sampled_out=sampled, pick_out=pick)
+    s = sampled.float().cpu().numpy()
+    a = 0.25
+    assert abs(s[:, 1::2].mean() - (1 - a) * (1 - e)) < 0.002  # state 0 -> 1
+    assert abs(s[:, ::2].mean() - (a + (1 - a) * (1 - e))) < 0.004  # state 1 -> 1
+    np.testing.assert_array_equal(g.cpu().numpy(), (before | sampled).cpu().numpy())  # not user guided: every draw counts
+    assert (g[:, ::2] == 1).all()
+    # user bits: frequency follows the relative degree; guided: rows whose bit is 0 do not change
+    d.user_guided = True
+    picks = []
+    for _ in range(200):
+        g2 = before.clone()
+        d._graph_step(g2, t, degp, sampled_out=sampled, pick_out=pick)
+        picks.append(pick.float().cpu().numpy())
+        unchanged = (g2 == before).all(dim=1).cpu().numpy()
+        assert unchanged[pick.cpu().numpy() == 0].all()
+    freq = np.mean(picks, axis=0)
+    assert np.abs(freq - degp.cpu().numpy()).max() < 0.15 and freq[0] == 0.0 and freq[-1] == 1.0
+
+
+def test_lightgcn_tables_are_handed_to_the_embedding_backbone():
+    """the propagated LightGCN tables (HIP SpMM) initialise embedding_user / the user-facing columns of
+    embedding_item of DNNOneHotEmbedding (reference models/DNN.py:1148-1149, :1263-1274); the score of (u, i) then carries
+    <e_u, e_i> of the graph model, and the diffusion step trains on from there."""
+    rng = np.random.default_rng(3)
+    U, I, h = 96, 70, 16
+    users, items = rng.integers(0, U, 900), rng.integers(0, I, 900)
+    lg = gdmcf_amd.LightGCN({"user_id_idx": users, "item_id_idx": items}, U, I, 2, h, device=DEV).to(DEV)
+    torch.manual_seed(0)
+    model = gdmcf_amd.DNNOneHotEmbedding([I, h], [h, I], 10, item_num=I, user_num=U).to(DEV)
+    before_items = model.embedding_item.weight.detach().clone()
+    fu, fi = model.load_lightgcn_embeddings(lg)
+    A = O.lightgcn_norm_adj(users, items, U, I)
+    ref_u, ref_i = O.lightgcn_propagate(A, lg.E0.weight.detach().cpu().numpy(), 2, U)[:2]
+    np.testing.assert_allclose(fu.cpu().numpy(), ref_u, atol=2e-6)
+    assert torch.equal(model.embedding_user.weight, fu) and torch.equal(model.embedding_item.weight[:, -h:], fi)
+    assert torch.equal(model.embedding_item.weight[:, :-h], before_items[:, :-h])  # the [h, h_U] columns keep their init
+    with pytest.raises(ValueError):
+        model.load_lightgcn_embeddings(gdmcf_amd.LightGCN({"user_id_idx": users, "item_id_idx": items}, U, I, 1, 8, device=DEV).to(DEV))
+    # one diffusion step on top of the handed-over tables: loss finite, both tables receive gradients
+    d = gdmcf_amd.GaussianDiffusionDiscrete(gdmcf_amd.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, 5, DEV, CatOneHot=True)
+    d.indexIn = True
+    x = torch.from_numpy((rng.random((32, I)) < 0.1).astype(np.float32)).to(DEV)
+    model.train()
+    loss = d.training_losses(model, x, True, index=torch.arange(32))["loss"].mean()
+    loss.backward()
+    assert torch.isfinite(loss) and model.embedding_user.weight.grad.abs().sum() > 0 and model.embedding_item.weight.grad.abs().sum() > 0
