@@ -96,6 +96,7 @@ def parse():
     ap.add_argument("--fuse-optimizer", action="store_true",
                     help="single GPU: update the two large weights inside the weight-gradient GEMM epilogue "
                          "(FusedAdamW.fuse_into_backward); same update rule, gradient never materialised")
+    ap.add_argument("--no-fused-leg", action="store_true", help="N = 1: skip the extra leg with AdamW fused into the dW epilogues")
     ap.add_argument("--bpr", action="store_true", help="also time a LightGCN BPR training step (reported under 'bpr')")
     ap.add_argument("--backbone", default="dnn", choices=["dnn", "onehot", "onehot-emb", "onehot-gcn"],
                     help="dnn: the plain denoiser (BASELINE configs); onehot: GaussianDiffusionDiscrete(CatOneHot=True) + "
@@ -410,6 +411,25 @@ def main():
                           users_per_s=round(400 * args.steps / float(ts_), 1), scaling="strong")
         step.flush()
 
+    # ---- N = 1: the same step with AdamW inside the weight-gradient GEMM epilogues (FusedAdamW.fuse_into_backward:
+    # same update rule, bit-identical weights by test; opt-in because `.grad` of the two big weights is then never
+    # materialised).  Reported beside the main line, which keeps backward(); optimizer.step() as the reference's loop. ----
+    fused_leg = None
+    if world == 1 and args.backbone == "dnn" and not args.fuse_optimizer and not args.rehearse_dp and not args.no_fused_leg:
+        opt.fuse_into_backward(model)
+        for i in range(max(3, args.warmup // 4)):
+            step(dcsr.rows(row_ids[i % n_pool], out=x_buf), True)
+        sync()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            loss_f = step(dcsr.rows(row_ids[i % n_pool], out=x_buf), True)
+        sync()
+        ef = time.perf_counter() - t1
+        fused_leg = dict(ms_per_step=round(1e3 * ef / args.steps, 4), users_per_s=round(B * args.steps / ef, 1), steps=args.steps,
+                         final_loss=float(loss_f), what="AdamW of the two large weights fused into their weight-gradient GEMM "
+                         "epilogues (bench.py --fuse-optimizer makes it the main line)")
+        opt.fuse_into_backward(model, min_numel=1 << 62)  # off again
+
     # ---- roofline of the dominant kernel (rank 0's events) ----
     roofline, klist = None, []
     for tag, d in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"]):
@@ -485,7 +505,7 @@ def main():
                        "n_items": I, "global_batch": world * B, "parallelism": f"dp{world}"},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": klist, "final_loss": final_loss,
             "host_enqueue_ms_per_step": round(1e3 * host_el / args.steps, 4),
-            "replicas_in_sync": in_sync, "dp_autotune": dp_autotune, "strong_scaling": strong_leg,
+            "replicas_in_sync": in_sync, "dp_autotune": dp_autotune, "strong_scaling": strong_leg, "fused_optimizer_leg": fused_leg,
             "ranks_in_group": dist.get_world_size() if dist.is_initialized() else 1,
             "optimizer": "FusedAdamW" + (" fused into the dW GEMM epilogues" if (args.fuse_optimizer and world == 1) else
                                          " (row-sharded over the ranks: reduce-scatter, AdamW on 1/N rows, deferred all-gather)"
