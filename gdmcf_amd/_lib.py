@@ -75,6 +75,7 @@ _SIGNATURES = {
                                       c_int, c_int64, c_float, c_double, P]),
     "gdmcf_graph_guided_step_u8": (c_int, [P, c_int64, P, c_int, c_int, c_float, P, c_int64, P, P, c_int, c_uint64, c_uint64, P,
                                            c_int64, P, P]),
+    "gdmcf_debug_spmm_stamps": (c_int, [c_int, P]),
     "gdmcf_scale_f32": (c_int, [P, c_int64, c_float, P, P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -254,10 +254,11 @@ struct SpmmStreamPlan {
 template <int LPR, bool WIDE>
 __global__ __launch_bounds__(256) void spmm_stream_kernel(const SpmmStreamPlan pl, const float* __restrict__ X, int64_t ldx,
                                                           float* __restrict__ Y, int64_t ldy, float* __restrict__ partial,
-                                                          int d, const SpmmAdd add, int dbg) {
+                                                          int d, const SpmmAdd add, int dbg, long long* __restrict__ stamps) {
     constexpr int G = 64 / LPR;
     constexpr int UN = LPR >= 4 ? 4 : LPR;
     constexpr int DW = 1 + (G > 2 ? G : 2);
+    const long long t_start = stamps ? wall_clock64() : 0;
     constexpr int GPB = LPR / UN;  // gather groups (UN steps each) per 64-entry batch
     const int lane = threadIdx.x & 63;
     const int g = lane / LPR, gl = lane % LPR;
@@ -286,6 +287,7 @@ __global__ __launch_bounds__(256) void spmm_stream_kernel(const SpmmStreamPlan p
     i32x2 nxt = __builtin_nontemporal_load(run + min(1, nb - 1) * 64 + lane);
     int b = 0, q = 0;
     int hA = udw[0], aA = udw[1 + g], sA = udw[2];
+    long long t_first = 0, t_pieces = 0;
     for (int u = u0; u < u1; ++u) {
         const int un = min(u + 1, u1 - 1) - u0;  // descriptor one unit ahead (L2 warm)
         int hB = hA, aB = aA, sB = sA;
@@ -293,6 +295,10 @@ __global__ __launch_bounds__(256) void spmm_stream_kernel(const SpmmStreamPlan p
         const int hdr = __builtin_amdgcn_readfirstlane(hA);
         const int ngroups = hdr & 0x7FFFFFFF;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (stamps) {
+            if (u == u0) t_first = wall_clock64();  // descriptors and the first batch have arrived
+            if (hdr >= 0 && t_pieces == 0) t_pieces = wall_clock64();
+        }
         for (int i = 0; i < ngroups; ++i) {
             f32x4 x[UN];
             float wt[UN];
@@ -345,6 +351,13 @@ __global__ __launch_bounds__(256) void spmm_stream_kernel(const SpmmStreamPlan p
         }
     }
     asm volatile("" ::"v"(t0), "v"(t1), "v"(t2), "v"(t3));  // the touches are only waited for here
+    if (stamps && lane == 0) {
+        long long* o = stamps + (long long)w * 8;
+        int xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        o[0] = t_start; o[1] = t_first; o[2] = t_pieces ? t_pieces : wall_clock64(); o[3] = wall_clock64();
+        o[4] = u1 - u0; o[5] = nb; o[6] = xcc & 0xf; o[7] = blockIdx.x;
+    }
 }
 
 // rows cut into several pieces: Y[r] = (sum of the partial slots in slot order + addends) * scale; one wave per row,
@@ -449,6 +462,27 @@ extern "C" int gdmcf_spmm_bundled_f32(const int32_t* wdesc, int n_waves, const i
     return gd_launch_status("spmm_bundled");
 }
 
+static long long* g_spmm_stamps = nullptr;  // development aid: per-wave timestamps of the next launches (tools/spmm_waves.py)
+static int g_spmm_stamp_waves = 0;
+
+extern "C" int gdmcf_debug_spmm_stamps(int n_waves, long long* host_out) {
+    // n_waves > 0, host_out == NULL: start recording (8 int64 per wave);  host_out != NULL: copy out and stop
+    if (host_out) {
+        if (!g_spmm_stamps) return GDMCF_E_ARG;
+        hipError_t e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = hipMemcpy(host_out, g_spmm_stamps, (size_t)g_spmm_stamp_waves * 64, hipMemcpyDeviceToHost);
+        (void)hipFree(g_spmm_stamps);
+        g_spmm_stamps = nullptr;
+        return e == hipSuccess ? GDMCF_OK : GDMCF_E_HIP;
+    }
+    if (g_spmm_stamps) (void)hipFree(g_spmm_stamps);
+    g_spmm_stamps = nullptr;
+    if (hipMalloc(&g_spmm_stamps, (size_t)n_waves * 64) != hipSuccess) return GDMCF_E_HIP;
+    if (hipMemset(g_spmm_stamps, 0, (size_t)n_waves * 64) != hipSuccess) return GDMCF_E_HIP;
+    g_spmm_stamp_waves = n_waves;
+    return GDMCF_OK;
+}
+
 extern "C" int gdmcf_spmm_stream_f32(const int32_t* wdesc, int n_waves, const int32_t* cw, int64_t n_entries, const int32_t* ud,
                                      int n_units, const int32_t* crow, const int32_t* cptr, int n_cut, int n_rows, int n_x_rows,
                                      const float* X, int64_t ldx, int d, float* Y, int64_t ldy, float* partial_ws,
@@ -485,8 +519,8 @@ extern "C" int gdmcf_spmm_stream_f32(const int32_t* wdesc, int n_waves, const in
         GdProfScope prof(8, alg_bytes, s);
 #define GD_GO(L)                                                                                                                        \
     do {                                                                                                                                \
-        if (wide) hipLaunchKernelGGL((spmm_stream_kernel<L, true>), dim3(n_blocks), dim3(256), 0, s, pl, X, ldx, Y, ldy, partial_ws, d, add, dbg); \
-        else hipLaunchKernelGGL((spmm_stream_kernel<L, false>), dim3(n_blocks), dim3(256), 0, s, pl, X, ldx, Y, ldy, partial_ws, d, add, dbg);     \
+        if (wide) hipLaunchKernelGGL((spmm_stream_kernel<L, true>), dim3(n_blocks), dim3(256), 0, s, pl, X, ldx, Y, ldy, partial_ws, d, add, dbg, g_spmm_stamps); \
+        else hipLaunchKernelGGL((spmm_stream_kernel<L, false>), dim3(n_blocks), dim3(256), 0, s, pl, X, ldx, Y, ldy, partial_ws, d, add, dbg, g_spmm_stamps);     \
         if (n_cut > 0 && !(dbg & 8))                                                                                                                  \
             hipLaunchKernelGGL(spmm_bundle_combine_kernel<L>, dim3(gd_cdiv(n_cut, 4)), dim3(256), 0, s, crow, cptr, n_cut, partial_ws,  \
                                d, Y, ldy, add);                                                                                         \

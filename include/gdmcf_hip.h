@@ -359,6 +359,10 @@ int gdmcf_spmm_stream_f32(const int32_t* wdesc, int n_waves, const int32_t* cw, 
                           const int32_t* crow, const int32_t* cptr, int n_cut, int n_rows, int n_x_rows, const float* X,
                           int64_t ldx, int d, float* Y, int64_t ldy, float* partial_ws, const float* const* addends_host,
                           int n_add, int64_t ld_add, float scale, double alg_bytes, void* stream);
+/* development aid (tools/spmm_waves.py): per-wave timestamps of gdmcf_spmm_stream_f32's main kernel.  (n_waves, NULL) starts
+ * recording 8 int64 per wave -- start, first gather, end of pieces, end (100 MHz ticks), units, batches, XCC id, block --,
+ * (n_waves, host buffer) copies them out and stops.                                                                     */
+int gdmcf_debug_spmm_stamps(int n_waves, long long* host_out);
 /* out = acc * scale */
 int gdmcf_scale_f32(const float* acc, int64_t n, float scale, float* out, void* stream);
 

@@ -1,2 +1,4 @@
-for D in 0 8 1 9 11 15; do echo "== gen3 dbg $D (1 no stores, 2 no piece reduction, 4 no descriptor loads, 8 no combine kernel)"; GDMCF_SPMM_DBG=$D GDMCF_SPMM_GEN=3 python tools/spmm_probe2.py yelp 2>&1 | grep -E "real|mod  2048"; done
-for D in 0 9 15; do echo "== gen3 stress dbg $D"; GDMCF_SPMM_DBG=$D GDMCF_SPMM_GEN=3 python tools/spmm_probe2.py stress 2>&1 | grep -E "real|mod  2048"; done
+echo "== gen3 pipelined"; GDMCF_SPMM_GEN=3 python tools/spmm_probe2.py yelp 2>&1 | grep -E "real|mod  2048"
+echo "== gen3 unpipelined"; GDMCF_SPMM_PIPE=0 GDMCF_SPMM_GEN=3 python tools/spmm_probe2.py yelp 2>&1 | grep -E "real|mod  2048"
+echo "== gen3 pipelined 8192 waves"; GDMCF_SPMM_WAVES=8192 GDMCF_SPMM_GEN=3 python tools/spmm_probe2.py yelp 2>&1 | grep -E "real|mod  2048"
+echo "== gen3 pipelined stress"; GDMCF_SPMM_GEN=3 python tools/spmm_probe2.py stress 2>&1 | grep -E "real|mod  2048"
