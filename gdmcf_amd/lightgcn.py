@@ -77,14 +77,17 @@ def spmm_plan(indptr, chunk=SPMM_CHUNK, short=SPMM_SHORT, d=64):
 
 
 SPMM_SMAX = int(os.environ.get("GDMCF_SPMM_SMAX", "64"))  # rows up to this many nonzeros are bundled G to a wave-step
-SPMM_PIECE = int(os.environ.get("GDMCF_SPMM_PIECE", "256"))  # longer rows are cut into pieces of at most this many
+SPMM_PIECE = int(os.environ.get("GDMCF_SPMM_PIECE", "128"))  # longer rows are cut into pieces of at most this many
 SPMM_WAVES = int(os.environ.get("GDMCF_SPMM_WAVES", "4096"))  # 256 CUs x 16 resident waves, all started at once
-SPMM_COST_ROW = int(os.environ.get("GDMCF_SPMM_COST_ROW", "8"))  # fixed cost of a bundled row / of a piece, in nonzeros
-SPMM_COST_PIECE = int(os.environ.get("GDMCF_SPMM_COST_PIECE", "32"))
+# fixed cost of a bundled row / of a piece, in nonzeros.  Calibrated on the per-wave timeline of the Yelp-shape graph
+# (tools/spmm_waves.py: least squares over 4096 waves): 0.56 us per piece group of 16 nonzeros, 0.67 / 0.76 us per warm /
+# cold bundle group, 0.42 us per piece, 1.0-1.1 us per bundle of four rows
+SPMM_COST_ROW = int(os.environ.get("GDMCF_SPMM_COST_ROW", "8"))
+SPMM_COST_PIECE = int(os.environ.get("GDMCF_SPMM_COST_PIECE", "12"))
 SPMM_HOT_MB = float(os.environ.get("GDMCF_SPMM_HOT_MB", "2.0"))  # part of an XCD's L2 the bundled rows' hot columns can keep
 SPMM_SLICE_MB = float(os.environ.get("GDMCF_SPMM_SLICE_MB", "3.5"))  # largest per-XCD slice of the table worth cutting rows for
 SPMM_NT = int(os.environ.get("GDMCF_SPMM_NT", "0"))  # streaming loads for bundles that gather mostly cold rows
-SPMM_MISS_W = float(os.environ.get("GDMCF_SPMM_MISS_W", "3.0"))  # cost of a gather served beyond L2, in L2-hit gathers
+SPMM_MISS_W = float(os.environ.get("GDMCF_SPMM_MISS_W", "1.15"))  # cost of a gather of a rarely gathered row, in warm ones
 
 
 def spmm_bundle_plan(indptr, indices, d=64, n_waves=None, s_max=None, piece=None, classes=8, n_cols=None):
@@ -171,7 +174,27 @@ def spmm_bundle_plan(indptr, indices, d=64, n_waves=None, s_max=None, piece=None
     s_sorted, s_temp = srows[sord], cold_row[sord]
     n_warm = int((s_temp == 0).sum())
     pos_in_temp = np.arange(len(s_sorted)) - np.where(s_temp == 1, n_warm, 0)
-    s_cls = (pos_in_temp // G) % classes
+    # Dealing: class c takes the share of the bundles that fills it up to the same total cost as the others (the pieces
+    # of a class that straddles two kinds of rows are shorter and more numerous, so that class gets fewer bundles) --
+    # stride scheduling: class c picks at times (j + 1/2) / share_c, bundle k goes to whoever picks k-th.
+    pcost_cls = np.bincount(P["cls"], weights=P["len"] + float(SPMM_COST_PIECE), minlength=classes) if n_p else np.zeros(classes)
+    rough_total = pcost_cls.sum() + float((wdeg[srows] + SPMM_COST_ROW).sum())
+    room = np.maximum(rough_total / classes - pcost_cls, 0.02 * rough_total / classes)
+    share = room / room.sum()
+
+    def deal(n_bundles):
+        if n_bundles == 0:
+            return np.zeros(0, np.int64)
+        quota = np.maximum(np.floor(share * n_bundles).astype(np.int64), 0)
+        quota[np.argsort(-(share * n_bundles - quota))[: n_bundles - quota.sum()]] += 1
+        times = np.concatenate([(np.arange(q_) + 0.5) / max(q_, 1) for q_ in quota])
+        who = np.repeat(np.arange(classes), quota)
+        return who[np.argsort(times, kind="stable")]
+
+    n_cold = len(s_sorted) - n_warm
+    cls_of_bundle = [deal(-(-n_warm // G)), deal(-(-n_cold // G))]
+    s_cls = np.where(s_temp == 0, cls_of_bundle[0][np.minimum(pos_in_temp // G, max(len(cls_of_bundle[0]) - 1, 0))] if n_warm else 0,
+                     cls_of_bundle[1][np.minimum(pos_in_temp // G, max(len(cls_of_bundle[1]) - 1, 0))] if n_cold else 0)
     grp = s_cls * 2 + s_temp  # (class, temperature) groups, bundles never mix them
     gord = np.argsort(grp, kind="stable")
     s_row, s_grp = s_sorted[gord], grp[gord]
@@ -192,26 +215,37 @@ def spmm_bundle_plan(indptr, indices, d=64, n_waves=None, s_max=None, piece=None
     wpc = n_waves // classes
     assert n_waves % (4 * classes) == 0
 
-    def equal_runs(cost, parts):
-        """run index (0 .. parts-1) of every element of a list cut into `parts` contiguous runs of equal cost"""
-        if len(cost) == 0:
-            return np.zeros(0, np.int64)
-        cum = np.cumsum(cost)
-        return np.minimum(((cum - 0.5 * cost) * parts / cum[-1]).astype(np.int64), parts - 1)
-
-    # (3) every wave of a class takes an equal share of EACH phase -- the class's pieces, its warm bundles, its cold
-    # bundles -- and runs them in that order, so that all waves of the XCD gather from the pieces' slice of the table
-    # first (L2 resident as long as nothing else streams through), then from the much-gathered rows, and last do the
-    # gathers that miss anyway.  (Pieces, warm and cold bundles run side by side evicted each other: 46 % L2 hits.)
+    # (3) every wave of a class takes a share of EACH phase -- the class's pieces, its warm bundles, its cold bundles --
+    # and runs them in that order, so that all waves of the XCD gather from the pieces' slice of the table first (L2
+    # resident as long as nothing else streams through), then from the much-gathered rows, and last do the gathers that
+    # miss anyway.  (Pieces, warm and cold bundles run side by side evicted each other: 46 % L2 hits.)  Units are
+    # indivisible and a wave's share of one phase is only a dozen gather groups (one bundle of 64-nonzero rows is 16),
+    # so the shares are dealt greedily on the RUNNING total: phase by phase, largest unit first, to the wave that holds
+    # the least so far (longest-processing-time rule) -- the waves' totals stay within one small unit of each other
+    # after every phase, which also keeps the phases aligned in time.
+    import heapq
     pcost_sorted = P["len"] + float(SPMM_COST_PIECE)
     p_wave = np.zeros(n_p, dtype=np.int64)
     b_wave = np.zeros(n_b, dtype=np.int64)
     for c in range(classes):
-        m = P["cls"] == c
-        p_wave[m] = c * wpc + equal_runs(pcost_sorted[m], wpc)
-        for t in (0, 1):
-            mb = b_grp == c * 2 + t
-            b_wave[mb] = c * wpc + equal_runs(bcost0[mb], wpc)
+        heap = [(0.0, j) for j in range(wpc)]
+        for phase in range(3):
+            if phase == 0:
+                idx = np.nonzero(P["cls"] == c)[0]
+                cost = pcost_sorted[idx]
+            else:
+                idx = np.nonzero(b_grp == c * 2 + (phase - 1))[0]
+                cost = bcost0[idx]
+            order_ = np.argsort(-cost, kind="stable")
+            dest = np.empty(len(idx), dtype=np.int64)
+            for k_, cst in zip(order_.tolist(), cost[order_].tolist()):
+                tot_, j = heapq.heappop(heap)
+                dest[k_] = j
+                heapq.heappush(heap, (tot_ + cst, j))
+            if phase == 0:
+                p_wave[idx] = c * wpc + dest
+            else:
+                b_wave[idx] = c * wpc + dest
     pw = np.argsort(p_wave, kind="stable")  # wave-major, CSR order inside
     P = {k_: v_[pw] for k_, v_ in P.items()}
     p_wave = p_wave[pw]

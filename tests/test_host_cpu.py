@@ -339,8 +339,9 @@ def test_spmm_bundle_plan_is_a_partition_of_the_work(d, n_waves):
         if (pcls == c).any() and (pcls > c).any():
             assert hi[pcls == c].max() <= lo[pcls > c].min()
     # classes hold equal shares of the cost (mean-column order), waves of a class equal shares of the class
-    lc = np.concatenate([[0], np.cumsum(pl["llen"] + 32)])
-    sc = np.concatenate([[0], np.cumsum(((pl["smax"] & 0x3FFFFFFF) + 8) * G)])
+    from gdmcf_amd.lightgcn import SPMM_COST_PIECE, SPMM_COST_ROW
+    lc = np.concatenate([[0], np.cumsum(pl["llen"] + SPMM_COST_PIECE)])
+    sc = np.concatenate([[0], np.cumsum(((pl["smax"] & 0x3FFFFFFF) + SPMM_COST_ROW) * G)])
     cost = (lc[wd[:, 1]] - lc[wd[:, 0]]) + (sc[wd[:, 3]] - sc[wd[:, 2]])
     per_class = cost.reshape(8, wpc).sum(1)
     assert per_class.max() <= 1.5 * per_class.mean() + (piece + 32)
