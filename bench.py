@@ -76,6 +76,9 @@ def parse():
     ap.add_argument("--hidden", type=int, default=1000)
     ap.add_argument("--gemm-dtype", default="f32", choices=["f32", "bf16"],
                     help="input precision of the denoiser GEMMs (bf16 = BASELINE configs[2]; f32 is the parity path)")
+    ap.add_argument("--dense-rows", action="store_true",
+                    help="densify the batch on the device (gdmcf_densify_rows_f32) and hand the dense rows to training_losses as "
+                         "the reference's loop does, instead of leaving them sparse (CsrBatch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-1thread", action="store_true", help="skip the one-thread CPU step (tens of seconds)")
@@ -290,6 +293,13 @@ def main():
     row_ids = [torch.arange(i * B, (i + 1) * B, device=dev) for i in range(n_pool)]
     x_buf = torch.empty(B, I, dtype=torch.float32, device=dev)
     x_dev = torch.from_numpy(x_host[:1]).to(dev)
+    # what the step is handed: the rows left sparse (default for the plain denoiser: the CSR-fed input builder and the bitmap
+    # loss target, gdmcf_amd.data_utils.CsrBatch -- bit-identical to the dense path), or densified on the device first
+    # (--dense-rows; always for the one-hot backbones, which read the dense row)
+    sparse_rows = args.backbone == "dnn" and not args.dense_rows
+
+    def rows_of(k):
+        return dcsr.batch(row_ids[k]) if sparse_rows else dcsr.rows(row_ids[k], out=x_buf)
 
     torch.manual_seed(0)
     if args.backbone != "dnn":
@@ -329,7 +339,7 @@ def main():
 
     loss = None
     for i in range(args.warmup):
-        loss = step(dcsr.rows(row_ids[i % n_pool], out=x_buf), True, **step_kw[i % n_pool])
+        loss = step(rows_of(i % n_pool), True, **step_kw[i % n_pool])
     sync()
     dp_autotune = None
     if autotune and step.exchange:
@@ -339,11 +349,11 @@ def main():
             try:
                 step.set_shard_optimizer(flag)
                 for i in range(2):
-                    step(dcsr.rows(row_ids[i % n_pool], out=x_buf), True, **step_kw[i % n_pool])
+                    step(rows_of(i % n_pool), True, **step_kw[i % n_pool])
                 sync()
                 t1 = time.perf_counter()
                 for i in range(6):
-                    step(dcsr.rows(row_ids[i % n_pool], out=x_buf), True, **step_kw[i % n_pool])
+                    step(rows_of(i % n_pool), True, **step_kw[i % n_pool])
                 sync()
                 tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -369,7 +379,7 @@ def main():
     for i in range(args.steps):
         if prof:
             lib.gdmcf_prof_enable(1 if i % every == 0 else 2)  # 2 = pause, records kept
-        loss = step(dcsr.rows(row_ids[i % n_pool], out=x_buf), True, **step_kw[i % n_pool])
+        loss = step(rows_of(i % n_pool), True, **step_kw[i % n_pool])
     host_el = time.perf_counter() - t0  # enqueue time only: well below `el` when the host runs ahead of the GPU
     sync()
     el = time.perf_counter() - t0
@@ -398,12 +408,15 @@ def main():
         Bs = 400 // world
         ids_s = [r[:Bs] for r in row_ids]
         xs_buf = torch.empty(Bs, I, dtype=torch.float32, device=dev)
+
+        def rows_of_s(k):
+            return dcsr.batch(ids_s[k]) if sparse_rows else dcsr.rows(ids_s[k], out=xs_buf)
         for i in range(max(3, args.warmup // 4)):
-            step(dcsr.rows(ids_s[i % n_pool], out=xs_buf), True, **{k: v[:Bs] for k, v in step_kw[i % n_pool].items()})
+            step(rows_of_s(i % n_pool), True, **{k: v[:Bs] for k, v in step_kw[i % n_pool].items()})
         sync()
         t1 = time.perf_counter()
         for i in range(args.steps):
-            step(dcsr.rows(ids_s[i % n_pool], out=xs_buf), True, **{k: v[:Bs] for k, v in step_kw[i % n_pool].items()})
+            step(rows_of_s(i % n_pool), True, **{k: v[:Bs] for k, v in step_kw[i % n_pool].items()})
         sync()
         ts_ = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
         dist.all_reduce(ts_, op=dist.ReduceOp.MAX)
@@ -418,11 +431,11 @@ def main():
     if world == 1 and args.backbone == "dnn" and not args.fuse_optimizer and not args.rehearse_dp and not args.no_fused_leg:
         opt.fuse_into_backward(model)
         for i in range(max(3, args.warmup // 4)):
-            step(dcsr.rows(row_ids[i % n_pool], out=x_buf), True)
+            step(rows_of(i % n_pool), True)
         sync()
         t1 = time.perf_counter()
         for i in range(args.steps):
-            loss_f = step(dcsr.rows(row_ids[i % n_pool], out=x_buf), True)
+            loss_f = step(rows_of(i % n_pool), True)
         sync()
         ef = time.perf_counter() - t1
         fused_leg = dict(ms_per_step=round(1e3 * ef / args.steps, 4), users_per_s=round(B * args.steps / ef, 1), steps=args.steps,
@@ -502,7 +515,8 @@ def main():
                                       and args.gemm_dtype == "f32" and args.backbone == "dnn" else "")
                                    + (" (BASELINE configs[2]: bf16 denoiser GEMM inputs, f32 accumulate/state)"
                                       if args.workload == "amazon-book" and args.gemm_dtype == "bf16" else ""),
-                       "n_items": I, "global_batch": world * B, "parallelism": f"dp{world}"},
+                       "n_items": I, "global_batch": world * B, "parallelism": f"dp{world}",
+                       "batch_rows": "device CSR rows (CsrBatch)" if sparse_rows else "dense rows densified from the device CSR"},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": klist, "final_loss": final_loss,
             "host_enqueue_ms_per_step": round(1e3 * host_el / args.steps, 4),
             "replicas_in_sync": in_sync, "dp_autotune": dp_autotune, "strong_scaling": strong_leg, "fused_optimizer_leg": fused_leg,

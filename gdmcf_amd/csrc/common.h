@@ -106,6 +106,8 @@ struct GdGemm {
     int act;
     const float* aux;  // target (LOSS) / x_t (POST)
     int64_t ldaux;
+    const uint32_t* aux_bits;  // LOSS: the target as a bitmap of {0,1} rows instead of aux (word n>>5 of row m, bit n&31)
+    int64_t ldbits;
     const float* aux2;  // z noise (POST)
     int64_t ldaux2;
     const float* r0;  // LOSS: alpha[m];  POST: c1[m]

@@ -212,7 +212,10 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GdGemm
                 }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    av[e][j] = g.aux[(int64_t)mc * g.ldaux + ncl[j]];
+                    if (EPI == GD_EPI_LOSS && g.aux_bits)  // {0,1} target rows kept as bitmaps (CSR input path)
+                        av[e][j] = ((g.aux_bits[(int64_t)mc * g.ldbits + (ncl[j] >> 5)] >> (ncl[j] & 31)) & 1u) ? 1.f : 0.f;
+                    else
+                        av[e][j] = g.aux[(int64_t)mc * g.ldaux + ncl[j]];
                     zv[e][j] = has_z ? g.aux2[(int64_t)mc * g.ldaux2 + ncl[j]] : 0.f;
                 }
             }

@@ -28,7 +28,9 @@ __global__ __launch_bounds__(256) void gemm_f32_small_kernel(const GdGemm g, int
             g.C[o] = v;
         } else if (EPI == GD_EPI_LOSS) {
             const float v = acc + (g.bias ? g.bias[n] : 0.f);
-            const float d = (g.r0 ? g.r0[m] : 1.f) * v - g.aux[(int64_t)m * g.ldaux + n];
+            const float tgt = g.aux_bits ? (((g.aux_bits[(int64_t)m * g.ldbits + (n >> 5)] >> (n & 31)) & 1u) ? 1.f : 0.f)
+                                         : g.aux[(int64_t)m * g.ldaux + n];
+            const float d = (g.r0 ? g.r0[m] : 1.f) * v - tgt;
             if (g.out2) g.out2[(int64_t)m * g.ldout2 + n] = v;
             g.C[o] = d;
             rowacc += d * d;

@@ -69,6 +69,13 @@ struct PrepArgs {
     float* temb_out;
     unsigned short* xin16;  // bf16 shadow of xin (or NULL), row stride ldxin16 (a multiple of 64 >= I+E)
     int64_t ldxin16;
+    // CSR source (gdmcf_dnn_prep_input_csr_f32): row b of the batch is row csr_rows[b] of a {0,1} matrix held as CSR;
+    // x is NULL then.  bits_out receives the rows as bitmaps (word w of row b = columns 32w .. 32w+31), the loss target.
+    const int64_t* csr_indptr;
+    const int32_t* csr_indices;
+    const int64_t* csr_rows;
+    uint32_t* bits_out;
+    int64_t ldbits;
 };
 
 __device__ __forceinline__ float temb_value(float t, int f, int E) {
@@ -82,9 +89,14 @@ __device__ __forceinline__ float temb_value(float t, int f, int E) {
 }
 
 // x_t for 4 consecutive columns of one row (shared by the row-norm pass and the main pass)
-__device__ __forceinline__ void xt4(const PrepArgs& a, int b, int col, float ca, float cb, float (&v)[4]) {
+__device__ __forceinline__ void xt4(const PrepArgs& a, int b, int col, float ca, float cb, float (&v)[4],
+                                    const uint32_t* bm = nullptr, int bm_col0 = 0) {
     const float* xr = a.x + (int64_t)b * a.ldx;
-    if (col + 3 < a.I) {
+    if (bm) {  // CSR source: the workgroup's span as a bitmap in LDS (col is a multiple of 4: one word holds all four)
+        const uint32_t w = bm[(col - bm_col0) >> 5] >> ((col - bm_col0) & 31);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (col + j < a.I && ((w >> j) & 1u)) ? 1.f : 0.f;
+    } else if (col + 3 < a.I) {
         // one 16-byte load (rows of the dense batch are only 4-byte aligned when I is odd: gfx950 takes that)
         typedef f32x4 f32x4_u4 __attribute__((aligned(4)));
         const f32x4 t4 = *reinterpret_cast<const f32x4_u4*>(xr + col);
@@ -161,6 +173,24 @@ __global__ __launch_bounds__(256) void prep_input_kernel(const PrepArgs a) {
     // the workgroup that holds the embedding columns evaluates the E sinusoids ONCE, one per lane, instead of E times
     // per embedding column in a serial chain of libm calls (that chain was a ~15 us tail of the whole launch)
     __shared__ float s_temb[256];
+    __shared__ uint32_t s_bm[256 * PREP_G * 4 / 32];  // CSR source: this workgroup's 4096 columns of row b as bits
+    const int bm_col0 = blockIdx.x * (256 * PREP_G * 4);
+    if (a.csr_indptr) {
+        if (threadIdx.x < 256 * PREP_G * 4 / 32) s_bm[threadIdx.x] = 0u;
+        __syncthreads();
+        const int64_t r = a.csr_rows[b];
+        const int64_t beg = a.csr_indptr[r], end = a.csr_indptr[r + 1];
+        for (int64_t k = beg + threadIdx.x; k < end; k += 256) {
+            const int c = a.csr_indices[k] - bm_col0;
+            if (c >= 0 && c < 256 * PREP_G * 4) atomicOr(&s_bm[c >> 5], 1u << (c & 31));
+        }
+        __syncthreads();
+        if (a.bits_out && threadIdx.x < 256 * PREP_G * 4 / 32) {
+            const int64_t w = (int64_t)(bm_col0 >> 5) + threadIdx.x;
+            if (w < a.ldbits) a.bits_out[(int64_t)b * a.ldbits + w] = s_bm[threadIdx.x];
+        }
+    }
+    const uint32_t* bm = a.csr_indptr ? s_bm : nullptr;
     const bool has_emb = a.E > 0 && a.E <= 256 && (int)((blockIdx.x + 1) * (256 * PREP_G * 4)) > a.I;
     if (has_emb) {
         if ((int)threadIdx.x < a.E) s_temb[threadIdx.x] = temb_value((float)t, threadIdx.x, a.E);
@@ -172,7 +202,7 @@ __global__ __launch_bounds__(256) void prep_input_kernel(const PrepArgs a) {
     if (col >= a.ldxin) return;
     float v[4] = {0.f, 0.f, 0.f, 0.f};
     if (col < a.I) {
-        xt4(a, b, col, ca, cb, v);
+        xt4(a, b, col, ca, cb, v, bm, bm_col0);
         if (a.xt_out) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -933,6 +963,7 @@ int gdmcf_dnn_prep_input_f32(const float* x, int64_t ldx, const int64_t* ts, con
     a.seed = seed; a.offset = offset; a.rownorm = nullptr; a.emb_w = emb_w; a.emb_b = emb_b; a.E = E; a.B = B;
     a.I = I; a.xin = xin; a.ldxin = ldxin; a.xt_out = xt_out; a.ldxt = ldxt; a.temb_out = temb_out;
     a.xin16 = nullptr; a.ldxin16 = 0;
+    a.csr_indptr = nullptr; a.csr_indices = nullptr; a.csr_rows = nullptr; a.bits_out = nullptr; a.ldbits = 0;
     GdShadow sh;
     if (gd_shadow_lookup(xin, &sh) && sh.rows == B && sh.cols == I + E) {  // keep the bf16 shadow of xin in sync
         a.xin16 = (unsigned short*)sh.p16;
@@ -954,6 +985,48 @@ int gdmcf_dnn_prep_input_f32(const float* x, int64_t ldx, const int64_t* ts, con
         hipLaunchKernelGGL(prep_input_kernel, grid, dim3(256), 0, s, a);
     }
     return gd_launch_status("prep_input");
+}
+
+int gdmcf_dnn_prep_input_csr_f32(const int64_t* indptr, const int32_t* indices, const int64_t* rows, const int64_t* ts,
+                                 const float* ca, const float* cb, int noise_mode, const float* noise, int64_t ldn,
+                                 int drop_mode, const uint8_t* keep, int64_t ldkeep, float drop_p, uint64_t seed,
+                                 uint64_t offset, const float* emb_w, const float* emb_b, int E, int B, int I, float* xin,
+                                 int64_t ldxin, float* temb_out, uint32_t* bits_out, int64_t ldbits, void* stream) {
+    GD_CHECK_SHAPE(B > 0 && I > 0 && E >= 0, "prep_input_csr: empty batch");
+    GD_CHECK_SHAPE(ldxin >= I + E && (ldxin % 4) == 0 && gd_aligned16(xin), "prep_input_csr: xin must be 16B aligned, ld%4==0");
+    GD_CHECK_ARG(indptr && indices && rows, "prep_input_csr: CSR arrays / row ids missing");
+    GD_CHECK_ARG(!bits_out || ldbits >= (I + 31) / 32, "prep_input_csr: ldbits < ceil(I/32)");
+    GD_CHECK_ARG((ca == nullptr) == (cb == nullptr), "prep_input_csr: ca/cb must both be set or both NULL");
+    GD_CHECK_ARG(noise_mode >= 0 && noise_mode <= 2 && drop_mode >= 0 && drop_mode <= 2, "prep_input_csr: bad mode");
+    GD_CHECK_ARG(noise_mode != 1 || (noise && ldn >= I), "prep_input_csr: explicit noise missing");
+    GD_CHECK_ARG(drop_mode != 1 || (keep && ldkeep >= I), "prep_input_csr: explicit keep-mask missing");
+    GD_CHECK_ARG(drop_p >= 0.f && drop_p < 1.f, "prep_input_csr: dropout p out of range");
+    GD_CHECK_ARG(E == 0 || (emb_w && emb_b && ts), "prep_input_csr: embedding weights / ts missing");
+    GD_CHECK_ARG(!ca || ts, "prep_input_csr: ts missing");
+    PrepArgs a;
+    a.x = nullptr; a.ldx = 0; a.ts = ts; a.ca = ca; a.cb = cb; a.noise_mode = ca ? noise_mode : 0; a.noise = noise;
+    a.ldn = ldn; a.drop_mode = drop_mode; a.keep = keep; a.ldkeep = ldkeep; a.drop_scale = 1.0f / (1.0f - drop_p);
+    const double th = (1.0 - (double)drop_p) * 4294967296.0;
+    a.keep_thresh = th >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)th;
+    a.seed = seed; a.offset = offset; a.rownorm = nullptr; a.emb_w = emb_w; a.emb_b = emb_b; a.E = E; a.B = B;
+    a.I = I; a.xin = xin; a.ldxin = ldxin; a.xt_out = nullptr; a.ldxt = 0; a.temb_out = temb_out;
+    a.xin16 = nullptr; a.ldxin16 = 0;
+    a.csr_indptr = indptr; a.csr_indices = indices; a.csr_rows = rows; a.bits_out = bits_out; a.ldbits = ldbits;
+    GdShadow sh;
+    if (gd_shadow_lookup(xin, &sh) && sh.rows == B && sh.cols == I + E) {
+        a.xin16 = (unsigned short*)sh.p16;
+        a.ldxin16 = sh.ld16;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(gd_cdiv((int)(ldxin / 4), 256 * PREP_G), B);
+    {
+        // algorithmic bytes: write xin (+ explicit noise / keep-mask); the rows themselves are a few hundred bytes of CSR
+        const double bytes = (double)B * I * ((a.noise_mode == 1 ? 4.0 : 0.0) + (drop_mode == 1 ? 1.0 : 0.0)) +
+                             (double)B * ldxin * 4.0;
+        GdProfScope prof(7, bytes, s);
+        hipLaunchKernelGGL(prep_input_kernel, grid, dim3(256), 0, s, a);
+    }
+    return gd_launch_status("prep_input_csr");
 }
 
 int gdmcf_dnn_emb_cols_f32(const int64_t* ts, const float* emb_w, const float* emb_b, int E, int B, int I, float* xin,

@@ -162,6 +162,29 @@ int gdmcf_linear_loss_fwd_f32(const float* A, int64_t lda, const float* W, int64
     return gd_rowpart_reduce(rowpart, g.ld_rowpart, M, g.tiles_n, rowsum, s);
 }
 
+int gdmcf_linear_loss_fwd_bits_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
+                                   const uint32_t* target_bits, int64_t ldbits, const float* alpha, int M, int N, int K,
+                                   float* out, int64_t ldo, float* diff, int64_t ldd, float* rowpart, float* rowsum,
+                                   void* stream) {
+    GD_CHECK_SHAPE(M > 0 && N > 0 && K > 0 && lda >= K && ldw >= K && ldd >= N, "linear_loss_fwd_bits: bad shape");
+    GD_CHECK_SHAPE(out == nullptr || ldo >= N, "linear_loss_fwd_bits: ldo < N");
+    GD_CHECK_ARG(target_bits && ldbits >= (N + 31) / 32, "linear_loss_fwd_bits: target bitmap missing / ldbits < ceil(N/32)");
+    hipStream_t s = (hipStream_t)stream;
+    const int cls = pick_class(M, N, true, t_gemm_prec);
+    GdGemm g = {};
+    g.bf16 = (t_gemm_prec == GDMCF_GEMM_BF16);
+    g.A = A; g.lda = lda; g.B = W; g.ldb = ldw; g.M = M; g.N = N; g.K = K; g.splits = 1;
+    g.m_fastest = gd_cdiv(M, gd_gemm_tile_m(cls)) <= gd_cdiv(N, gd_gemm_tile_n(cls));
+    g.bias = bias; g.aux = nullptr; g.ldaux = 0; g.aux_bits = target_bits; g.ldbits = ldbits; g.r0 = alpha; g.out2 = out;
+    g.ldout2 = ldo; g.prof_tag = 2;
+    g.C = diff; g.ldc = ldd; g.rowpart = rowpart; g.ld_rowpart = gdmcf_loss_tiles(N);
+    attach_result_shadow(g);
+    attach_shadows(g, GD_LAY_KC, GD_LAY_KC);
+    int rc = gd_gemm_launch(GD_LAY_KC, GD_LAY_KC, GD_EPI_LOSS, cls, g, s);
+    if (rc) return rc;
+    return gd_rowpart_reduce(rowpart, g.ld_rowpart, M, g.tiles_n, rowsum, s);
+}
+
 int gdmcf_linear_posterior_fwd_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
                                    const float* x_t, int64_t ldxt, const float* c1, const float* c2, const float* r1,
                                    const float* r2, const float* sigma, const float* z, int64_t ldz, int M, int N,

@@ -66,6 +66,35 @@ class DeviceCSR:
                                                       out.stride(0), _lib.stream_ptr()))
         return out
 
+    def batch(self, row_ids):
+        """The same rows, left sparse (see CsrBatch)."""
+        return CsrBatch(self, row_ids)
+
+
+class CsrBatch:
+    """A batch of interaction rows that stays sparse: rows `row_ids` of a DeviceCSR.  Hand it to
+    `GaussianDiffusion.training_losses` in place of the dense `[B, n_items]` tensor of the reference's loop
+    (main.py:343-346): the input builder then reads the few hundred bytes of CSR per row instead of a dense row, and the loss
+    takes its {0,1} target from bitmaps (gdmcf_dnn_prep_input_csr_f32 / gdmcf_linear_loss_fwd_bits_f32; same arithmetic,
+    bit-identical losses and gradients).  Configurations that need the dense row (F.normalize, the eps target, the
+    one-hot variants, values other than 1) densify it themselves (`dense()`)."""
+
+    def __init__(self, csr, row_ids):
+        self.csr = csr
+        self.row_ids = row_ids.to(device=csr.device, dtype=torch.int64).contiguous()
+        self.shape = (self.row_ids.numel(), csr.shape[1])
+        self.device = csr.device
+        self.is_cuda = csr.device.type == "cuda"
+
+    def size(self, dim=None):
+        return self.shape if dim is None else self.shape[dim]
+
+    def dim(self):
+        return 2
+
+    def dense(self, out=None):
+        return self.csr.rows(self.row_ids, out=out)
+
 
 class DeviceBatchLoader:
     """Iterates (dense_batch_on_device, index) like DataLoader(DataDiffusion(dense), batch_size, shuffle,

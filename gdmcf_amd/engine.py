@@ -210,6 +210,35 @@ class DenoiserEngine:
         _lib.check(rc)
         return x, noise, keep  # keep the (possibly converted) inputs alive until the stream has consumed them
 
+    def _prep_csr(self, bufs, batch, ts, ca, cb, noise, drop_mask, training):
+        """First-layer input straight from the device CSR rows of `batch` (data_utils.CsrBatch): no dense x0 anywhere; the
+        rows' bitmaps go to bufs.x0bits for the loss epilogue."""
+        m, lib = self.model, self.lib
+        B, I = batch.shape
+        if getattr(bufs, "x0bits", None) is None:
+            bufs.x0bits = torch.zeros(B, (I + 31) // 32, dtype=torch.int32, device=batch.device)
+        noise_mode = 0
+        if ca is not None:
+            noise_mode = 1 if noise is not None else 2
+            if noise is not None and (noise.dtype != torch.float32 or noise.stride(-1) != 1):
+                noise = noise.float().contiguous()
+        p = float(m.drop.p)
+        drop_mode, keep = 0, None
+        if drop_mask is not None:
+            drop_mode = 1
+            keep = (drop_mask if drop_mask.dtype == torch.uint8 else (drop_mask != 0).to(torch.uint8)).contiguous()
+        elif training and p > 0.0:
+            drop_mode = 2
+        self.offset += 1
+        c = batch.csr
+        _lib.check(lib.gdmcf_dnn_prep_input_csr_f32(
+            c.indptr.data_ptr(), c.indices.data_ptr(), batch.row_ids.data_ptr(), _lib.ptr(ts), _lib.ptr(ca), _lib.ptr(cb),
+            noise_mode, _lib.ptr(noise), noise.stride(0) if noise is not None else 0, drop_mode, _lib.ptr(keep),
+            keep.stride(0) if keep is not None else 0, p, self.seed, self.offset, m.emb_layer.weight.data_ptr(),
+            m.emb_layer.bias.data_ptr(), self.E, B, I, bufs.xin.data_ptr(), bufs.xin.stride(0), bufs.temb.data_ptr(),
+            bufs.x0bits.data_ptr(), bufs.x0bits.stride(0), _lib.stream_ptr()))
+        return batch, noise, keep
+
     def _hidden_forward(self, bufs, layers, B, xin=None):
         """All layers but the last; returns (A, lda, K) feeding the last layer."""
         lib, st = self.lib, _lib.stream_ptr()
@@ -230,7 +259,8 @@ class DenoiserEngine:
     @_with_precision
     def train_forward(self, spec):
         x0, ts = spec["x_start"], spec["ts"]
-        B, dev = x0.shape[0], x0.device
+        csr = spec.get("csr")
+        B, dev = (csr.shape[0], csr.device) if csr is not None else (x0.shape[0], x0.device)
         layers = self._layers()
         bufs = self.buffers(B, dev)
         self._shadows_on(bufs, layers)
@@ -242,8 +272,11 @@ class DenoiserEngine:
             if bufs.xt is None:
                 bufs.xt = torch.zeros(B, bufs.ldi, dtype=torch.float32, device=dev)
             xt_out = bufs.xt
-        keepalive = self._prep(bufs, x0, ts, spec["ca"], spec["cb"], spec["noise"], spec["drop_mask"],
-                               self.model.training, xt_out=xt_out)
+        if csr is not None:
+            keepalive = self._prep_csr(bufs, csr, ts, spec["ca"], spec["cb"], spec["noise"], spec["drop_mask"], self.model.training)
+        else:
+            keepalive = self._prep(bufs, x0, ts, spec["ca"], spec["cb"], spec["noise"], spec["drop_mask"],
+                                   self.model.training, xt_out=xt_out)
         x0c = keepalive[0]
         alpha = None
         if eps_mode:
@@ -261,10 +294,16 @@ class DenoiserEngine:
         w, bias, _ = layers[-1]
         N, K = w.shape
         self._use_weight(w)
-        _lib.check(lib.gdmcf_linear_loss_fwd_f32(A.data_ptr(), lda, w.data_ptr(), w.stride(0), bias.data_ptr(),
-                                                 target.data_ptr(), target.stride(0), _lib.ptr(alpha), B, N, K, None,
-                                                 0, bufs.diff.data_ptr(), bufs.ldi, bufs.rowpart.data_ptr(),
-                                                 bufs.rowsum.data_ptr(), st))
+        if csr is not None:  # the target rows are bitmaps written by the CSR-fed input builder
+            _lib.check(lib.gdmcf_linear_loss_fwd_bits_f32(A.data_ptr(), lda, w.data_ptr(), w.stride(0), bias.data_ptr(),
+                                                          bufs.x0bits.data_ptr(), bufs.x0bits.stride(0), None, B, N, K, None,
+                                                          0, bufs.diff.data_ptr(), bufs.ldi, bufs.rowpart.data_ptr(),
+                                                          bufs.rowsum.data_ptr(), st))
+        else:
+            _lib.check(lib.gdmcf_linear_loss_fwd_f32(A.data_ptr(), lda, w.data_ptr(), w.stride(0), bias.data_ptr(),
+                                                     target.data_ptr(), target.stride(0), _lib.ptr(alpha), B, N, K, None,
+                                                     0, bufs.diff.data_ptr(), bufs.ldi, bufs.rowpart.data_ptr(),
+                                                     bufs.rowsum.data_ptr(), st))
         loss = torch.empty(B, dtype=torch.float64, device=dev)
         pt = spec["pt"]
         _lib.check(lib.gdmcf_row_loss_finish_f64(bufs.rowsum.data_ptr(), rowdiv.data_ptr(), _lib.ptr(alpha),

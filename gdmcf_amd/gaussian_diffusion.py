@@ -214,6 +214,16 @@ class GaussianDiffusion(nn.Module):
         _lib.require_gpu(x_start, "x_start")
         if not isinstance(model, DNN):
             raise TypeError("gdmcf_amd.GaussianDiffusion.training_losses needs a gdmcf_amd.DNN denoiser")
+        from .data_utils import CsrBatch
+        csr_batch = None
+        if isinstance(x_start, CsrBatch):
+            # rows left sparse: only what the CSR-fed kernels cover, otherwise densify here
+            sparse_ok = (self.mean_type == ModelMeanType.START_X and not model.norm and x_start.csr.values is None
+                         and self.rng == "philox")
+            if sparse_ok:
+                csr_batch = x_start
+            else:
+                x_start = x_start.dense()
         batch_size, device = x_start.size(0), x_start.device
         assert x_start.dim() == 2 and x_start.size(1) == model.in_dims[0], "x_start must be [B, n_items]"
         if ts is None:
@@ -241,7 +251,8 @@ class GaussianDiffusion(nn.Module):
             # the reference leaves `loss` undefined here (NameError); DiffRec semantics: unit weights on the mse
             # (for the eps target that also means no x0-likelihood term on the t == 0 rows)
             weight_t = self._weights["one"]
-        spec = dict(x_start=x_start, ts=ts, pt=pt, ca=ca, cb=cb, noise=noise, drop_mask=drop_mask, eps_mode=eps_mode,
+        spec = dict(x_start=None if csr_batch is not None else x_start, csr=csr_batch, ts=ts, pt=pt, ca=ca, cb=cb, noise=noise,
+                    drop_mask=drop_mask, eps_mode=eps_mode,
                     weight_t=weight_t, T=self.steps, H=self.history_num_per_term, Lt_history=self.Lt_history,
                     Lt_count=self.Lt_count, update_history=self.update_history, t0_likelihood=(reweight == True))  # noqa: E712
         if eps_mode:

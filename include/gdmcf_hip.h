@@ -96,6 +96,17 @@ int gdmcf_dnn_prep_input_f32(const float* x, int64_t ldx, const int64_t* ts, con
                              const float* emb_b, int E, int B, int I, float* xin, int64_t ldxin,
                              float* xt_out, int64_t ldxt, float* temb_out, float* rownorm_ws,
                              void* stream);
+/* The same builder fed from a device-resident CSR matrix of {0,1} interactions instead of dense
+ * rows: row b of the batch is row rows[b] of (indptr int64, indices int32).  Nothing dense is read: a workgroup marks its
+ * 4096 columns of the row in an LDS bitmap and builds x_t = ca*x0 + cb*noise, dropout, the embedding columns from it
+ * (same arithmetic and the same Philox streams as the dense entry: identical xin).  bits_out (optional, uint32
+ * [B, ldbits], ldbits >= ceil(I/32)) receives the rows as bitmaps -- the target of gdmcf_linear_loss_fwd_bits_f32.
+ * No F.normalize here (it needs the dense row twice): densify (gdmcf_densify_rows_f32) and use the dense entry.        */
+int gdmcf_dnn_prep_input_csr_f32(const int64_t* indptr, const int32_t* indices, const int64_t* rows, const int64_t* ts,
+                                 const float* ca, const float* cb, int noise_mode, const float* noise, int64_t ldn,
+                                 int drop_mode, const uint8_t* keep, int64_t ldkeep, float drop_p, uint64_t seed,
+                                 uint64_t offset, const float* emb_w, const float* emb_b, int E, int B, int I, float* xin,
+                                 int64_t ldxin, float* temb_out, uint32_t* bits_out, int64_t ldbits, void* stream);
 
 /* ---- one-hot rows with discrete transition noise (first slice) -------------------
  * replaces GaussianDiffusionDiscrete.apply_noise (gaussian_diffusion.py:770-831: get_Qt_bar :597-614,
@@ -172,6 +183,13 @@ int gdmcf_linear_loss_fwd_f32(const float* A, int64_t lda, const float* W, int64
                               const float* alpha, int M, int N, int K, float* out, int64_t ldo,
                               float* diff, int64_t ldd, float* rowpart, float* rowsum,
                               void* stream);
+/* The same product with the target given as BITMAPS of {0,1} rows (word n>>5 of row m, bit n&31; row stride ldbits words)
+ * instead of a dense float matrix: the CSR input path (gdmcf_dnn_prep_input_csr_f32 writes the bitmaps) never densifies
+ * the batch.  x0-target training only (the eps target is the noise); results are bit-identical to the dense entry.    */
+int gdmcf_linear_loss_fwd_bits_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
+                                   const uint32_t* target_bits, int64_t ldbits, const float* alpha, int M, int N, int K,
+                                   float* out, int64_t ldo, float* diff, int64_t ldd, float* rowpart, float* rowsum,
+                                   void* stream);
 /* Last layer fused with the reverse-diffusion posterior mean (gaussian_diffusion.py:473-515,
  * :451-471, :518-523, :210-217):  out = A @ W^T + bias
  *   pred = eps_mode ? r1[t]*x_t - r2[t]*out : out ;  mean = c1[t]*pred + c2[t]*x_t

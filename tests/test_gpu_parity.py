@@ -875,6 +875,86 @@ def test_bf16_shadows_stay_in_sync():
     check(eng._wshadow[id(model.out_layers[0].weight)][0], model.out_layers[0].weight)
 
 
+@pytest.mark.parametrize("gemm_dtype", ["f32", "bf16"])
+def test_sparse_rows_train_exactly_like_dense_rows(gemm_dtype):
+    """CSR input path (gdmcf_dnn_prep_input_csr_f32 + gdmcf_linear_loss_fwd_bits_f32): handing
+    `training_losses` the rows as a data_utils.CsrBatch gives bit-identical per-row losses, gradients, Lt-history and
+    weights after the step as handing it the densified rows -- with in-kernel Philox noise / dropout (same seed, same
+    offsets) and with injected noise / dropout masks, at a ragged width (odd I, rows crossing the 4096-column workgroup
+    span, an empty row, a full row)."""
+    import scipy.sparse as sp
+    from gdmcf_amd.data_utils import DeviceCSR
+    rng = np.random.default_rng(7)
+    U, I, hid, T, B = 300, 9003, 48, 5, 37
+    dense = (rng.random((U, I)) < 0.004).astype(np.float32)
+    dense[5] = 0.0
+    dense[6] = 1.0
+    dcsr = DeviceCSR(sp.csr_matrix(dense), DEV)
+    ids = torch.from_numpy(rng.permutation(U)[:B].astype(np.int64))
+    ids[0], ids[1] = 5, 6
+    g = torch.Generator().manual_seed(3)
+    noise = torch.randn(B, I, generator=g)
+    keep = (torch.rand(B, I, generator=g) < 0.5).to(torch.uint8)
+    ts = torch.randint(0, T, (B,), generator=g)
+    for inject in (False, True):
+        out = []
+        for sparse in (False, True):
+            torch.manual_seed(11)
+            model = gdmcf_amd.DNN([I, hid], [hid, I], 10, gemm_dtype=gemm_dtype).to(DEV).train()
+            d = gdmcf_amd.GaussianDiffusion(ModelMeanType.START_X, "linear-var", 0.1, 0.001, 0.01, T, DEV)
+            opt = gdmcf_amd.FusedAdamW(model.parameters(), lr=1e-3)
+            x = dcsr.batch(ids) if sparse else dcsr.rows(ids)
+            kw = dict(ts=cu(ts), pt=torch.ones(B, dtype=torch.float64, device=DEV))
+            if inject:
+                kw.update(noise=cu(noise), drop_mask=cu(keep))
+            opt.zero_grad()
+            terms = d.training_losses(model, x, True, **kw)
+            terms["loss"].mean().backward()
+            grads = [p.grad.clone() for p in model.parameters()]
+            opt.step()
+            out.append((terms["loss"].detach().clone(), grads, [p.detach().clone() for p in model.parameters()],
+                        d.Lt_history.clone(), d.Lt_count.clone()))
+        (l0, g0, w0, h0, c0), (l1, g1, w1, h1, c1) = out
+        assert torch.equal(l0, l1) and torch.equal(h0, h1) and torch.equal(c0, c1)
+        for a, b in zip(g0 + w0, g1 + w1):
+            assert torch.equal(a, b)
+    # what cannot stay sparse densifies by itself: eps target, F.normalize
+    torch.manual_seed(11)
+    model = gdmcf_amd.DNN([I, hid], [hid, I], 10, norm=True).to(DEV).train()
+    d = gdmcf_amd.GaussianDiffusion(ModelMeanType.EPSILON, "linear-var", 0.1, 0.001, 0.01, T, DEV)
+    a = d.training_losses(model, dcsr.batch(ids), True, ts=cu(ts), pt=torch.ones(B, dtype=torch.float64, device=DEV),
+                          noise=cu(noise), drop_mask=cu(keep))["loss"]
+    b = d.training_losses(model, dcsr.rows(ids), True, ts=cu(ts), pt=torch.ones(B, dtype=torch.float64, device=DEV),
+                          noise=cu(noise), drop_mask=cu(keep))["loss"]
+    assert torch.equal(a.detach(), b.detach())
+
+
+def test_sparse_rows_match_the_reference_fixture():
+    """The CSR input path against the reference's own numbers: the `ragged_x0` fixture's rows fed as a CsrBatch."""
+    import scipy.sparse as sp
+    from gdmcf_amd.data_utils import DeviceCSR
+    fx = H.load("train_ragged_x0")
+    meta = H.train_meta(fx)
+    model, diff = gpu_model(meta, fx).train(), gpu_diffusion(meta)
+    diff.Lt_history.copy_(torch.from_numpy(fx["Lt_history0"]))
+    diff.Lt_count.copy_(torch.from_numpy(fx["Lt_count0"]))
+    opt = gdmcf_amd.FusedAdamW(model.parameters(), lr=meta["lr"], weight_decay=meta["wd"])
+    for s in range(meta["n_steps"]):
+        inp = H.step_inputs(fx, s)
+        dcsr = DeviceCSR(sp.csr_matrix(inp["x"].numpy()), DEV)
+        opt.zero_grad()
+        terms = diff.training_losses(model, dcsr.batch(torch.arange(meta["B"])), True, ts=cu(inp["ts"]), pt=cu(inp["pt"]),
+                                     noise=cu(inp["noise"]), drop_mask=cu(inp["drop_mask"]))
+        loss = terms["loss"].mean()
+        loss.backward()
+        assert abs(float(loss.detach()) - float(fx[f"s{s}.loss"])) <= 1e-4 * abs(float(fx[f"s{s}.loss"]))
+        np.testing.assert_allclose(terms["loss"].detach().cpu().numpy(), fx[f"s{s}.loss_vec"], rtol=1e-4)
+        if s == 0:
+            for k, v in model.named_parameters():
+                assert H.relerr(v.grad.cpu().numpy(), fx["g0." + k]) < 2e-4, k
+        opt.step()
+
+
 def test_device_metrics_equal_the_reference_loop():
     """gdmcf_topn_metrics_f64 (device) == computeTopNAccuracy (the reference's Python loop, pinned by the golden
     vectors in the CPU suite): identical 4-decimal results on random rankings incl. users with empty ground truth,
