@@ -600,6 +600,40 @@ def test_spmm_isolated_nodes_and_non_finite_strangers(gen, monkeypatch):
     np.testing.assert_array_equal(got[iso], (E0[iso] * np.float32(1.0 / (L + 1))))
 
 
+@pytest.mark.parametrize("gen", ["1", "3"])
+def test_spmm_random_graphs_against_float64(gen, monkeypatch):
+    """Random bipartite graphs with awkward degree patterns (hub users AND hub items, isolated nodes on both sides, a
+    single edge, more items than users) through LightGCN.propagate_through_layers on both kernel generations, against the
+    float64 evaluation of the same float32 adjacency."""
+    monkeypatch.setenv("GDMCF_SPMM_GEN", gen)
+    rng = np.random.default_rng(int(gen))
+    for trial in range(12):
+        U, It = int(rng.integers(2, 400)), int(rng.integers(2, 600))
+        d = int(rng.choice([8, 64, 128]))
+        nnz = int(rng.integers(1, 6000))
+        users = np.minimum(rng.zipf(1.4, nnz) - 1, U - 1) if trial % 2 else rng.integers(0, U, nnz)
+        items = np.minimum(rng.zipf(1.2, nnz) - 1, It - 1) if trial % 3 else rng.integers(0, It, nnz)
+        if trial == 0:
+            users, items = np.array([0]), np.array([0])
+        L = int(rng.integers(1, 4))
+        A = O.lightgcn_norm_adj(users, items, U, It)
+        E0 = rng.standard_normal((U + It, d)).astype(np.float32)
+        m = gdmcf_amd.LightGCN({"user_id_idx": users, "item_id_idx": items}, U, It, L, d, device=DEV)
+        with torch.no_grad():
+            m.E0.weight.copy_(torch.from_numpy(E0))
+        m = m.to(DEV)
+        with torch.no_grad():
+            fu, fi, _, _ = m.propagate_through_layers()
+        A64 = A.astype(np.float64)
+        cur = acc = E0.astype(np.float64)
+        for _ in range(L):
+            cur = A64 @ cur
+            acc = acc + cur
+        ref = acc / (L + 1)
+        got = np.concatenate([fu.cpu().numpy(), fi.cpu().numpy()])
+        np.testing.assert_allclose(got, ref, rtol=0, atol=2e-5 * max(1.0, np.abs(ref).max()), err_msg=f"trial {trial}")
+
+
 def test_lt_history_kernel_matches_serial_fifo():
     """The parallel rank-based FIFO update == the reference's row-by-row loop (gaussian_diffusion.py:355-368)."""
     from gdmcf_amd import _lib
