@@ -536,6 +536,7 @@ def main():
             out["bpr"] = bpr
         print(json.dumps(out))
     if dist.is_initialized():
+        dist.barrier()  # rank 0 runs the extra legs (SpMM, evaluation path) alone: leave together
         dist.destroy_process_group()
 
 

@@ -211,12 +211,27 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GdGemm
                     if (has_z) sgv[e] = g.r4[mc];
                 }
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if (EPI == GD_EPI_LOSS && g.aux_bits)  // {0,1} target rows kept as bitmaps (CSR input path)
-                        av[e][j] = ((g.aux_bits[(int64_t)mc * g.ldbits + (ncl[j] >> 5)] >> (ncl[j] & 31)) & 1u) ? 1.f : 0.f;
-                    else
+                if (EPI == GD_EPI_LOSS && g.aux_bits) {
+                    // {0,1} target rows kept as bitmaps (CSR input path).  The wave's columns start at a multiple of 32 and
+                    // lane r owns column 16*j + r of it: columns j and j^1 share a word -> one load per 32 columns and row
+                    // (the words are shared by the 16 lanes of the row: a broadcast load)
+                    static_assert(EPI != GD_EPI_LOSS || TN % 2 == 0, "bitmap target: a wave's columns must start at a multiple of 32");
+                    const int cbase = n0 + wn0;
+                    uint32_t wv[(TN + 1) / 2];
+#pragma unroll
+                    for (int jj = 0; jj < (TN + 1) / 2; ++jj)
+                        wv[jj] = g.aux_bits[(int64_t)mc * g.ldbits + min((int64_t)((cbase >> 5) + jj), g.ldbits - 1)];
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        av[e][j] = ((wv[j >> 1] >> (16 * (j & 1) + r)) & 1u) ? 1.f : 0.f;
+                        zv[e][j] = 0.f;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
                         av[e][j] = g.aux[(int64_t)mc * g.ldaux + ncl[j]];
-                    zv[e][j] = has_z ? g.aux2[(int64_t)mc * g.ldaux2 + ncl[j]] : 0.f;
+                        zv[e][j] = has_z ? g.aux2[(int64_t)mc * g.ldaux2 + ncl[j]] : 0.f;
+                    }
                 }
             }
 #pragma unroll
