@@ -421,6 +421,12 @@ class GaussianDiffusionDiscrete(GaussianDiffusion):
                 graph = torch.zeros(B, x0.shape[1], dtype=torch.uint8, device=dev)
                 deg = x0.sum(dim=1)
                 degp = (deg / deg.max()).float().contiguous()  # :710-711 (a batch without any interaction gives nan, as there)
+            eps_mode = self.mean_type == ModelMeanType.EPSILON
+            if self.mean_type not in (ModelMeanType.START_X, ModelMeanType.EPSILON):
+                raise NotImplementedError(self.mean_type)
+            # per-step coefficient vectors [T, B] of the fused posterior epilogue (reference :451-471, :495-498), once
+            tabs = {k: self._t32[k][: self.steps, None].expand(self.steps, B).contiguous() for k in ("c1", "c2", "r1", "r2", "sigma")} \
+                if self.noise_scale != 0.0 else None
             for n, i in enumerate(list(range(self.steps))[::-1]):
                 t = torch.full((B,), i, dtype=torch.int64, device=dev)
                 kw = dict(index=index) if self.indexIn else {}
@@ -433,18 +439,20 @@ class GaussianDiffusionDiscrete(GaussianDiffusion):
                     kw["graph"] = graph
                     if capture is not None:
                         capture.setdefault("graph", []).append(graph.clone())
-                out = model(x_t, t, x_tU, **kw)
-                pred = out if self.mean_type == ModelMeanType.START_X else self._predict_xstart_from_eps(x_t, t, eps=out)
-                mean, _, logvar = self.q_posterior_mean_variance(x_start=pred, x_t=x_t, t=t)
+                # posterior mean (and the sampling noise) inside the epilogue of the model's output GEMM: no [B, I] model
+                # output, no element-wise passes over it
+                po = dict(c1=tabs["c1"][i], c2=tabs["c2"][i], want_pred=capture is not None)
+                if eps_mode:
+                    po.update(r1=tabs["r1"][i], r2=tabs["r2"][i])
+                if sampling_noise and i != 0:
+                    z = step_noise[n] if step_noise is not None else torch.randn_like(x_t)
+                    po.update(sigma=tabs["sigma"][i], z=z.float().contiguous())
+                x_in = x_t if (x_t.dtype == torch.float32 and x_t.is_contiguous()) else x_t.float().contiguous()
+                x_next, pred = model(x_in, t, x_tU, posterior=po, **kw)
                 if capture is not None:
                     capture.setdefault("pred_xstart", []).append(pred)
-                    capture.setdefault("mean", []).append(mean)
-                if sampling_noise:
-                    z = step_noise[n] if step_noise is not None else torch.randn_like(x_t)
-                    nz = (t != 0).float().view(-1, 1)
-                    x_t = mean + nz * torch.exp(0.5 * logvar) * z
-                else:
-                    x_t = mean
+                    capture.setdefault("mean", []).append(x_next if not (sampling_noise and i != 0) else None)
+                x_t = x_next
             del keep
             self.last_graph = graph
             return x_t

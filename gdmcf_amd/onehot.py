@@ -366,7 +366,30 @@ class OneHotEngine:
         return res
 
     # -- plain forward (evaluation / reverse loop) ----------------------------------------------------------------------
-    def forward_plain(self, x, timesteps, x_U, training, drop_mask=None, drop_mask_U=None):
+    def _last_layer(self, A_ptr, lda, w_ptr, ldw, bias_ptr, act, B, N, K, x_t, posterior, bufs, st):
+        """The layer that produces the model output: plain (`out`), or -- reverse loop -- with the posterior mean of
+        reference gaussian_diffusion.py:451-471 / :495-498 fused into the GEMM epilogue (`posterior` = dict of per-row
+        coefficient vectors c1, c2[, r1, r2][, sigma, z], want_pred): returns (x_{t-1}, pred_xstart or None)."""
+        lib, dev = self.lib, x_t.device
+        if posterior is None:
+            res = torch.empty(B, N, dtype=torch.float32, device=dev)
+            _lib.check(lib.gdmcf_linear_fwd_f32(A_ptr, lda, w_ptr, ldw, bias_ptr, act, B, N, K, res.data_ptr(), res.stride(0),
+                                                bufs.ws.data_ptr(), bufs.ws_bytes, st))
+            return res
+        if act != 0:
+            raise RuntimeError("fused posterior: the output layer must be linear")
+        po = posterior
+        xn = torch.empty(B, N, dtype=torch.float32, device=dev)
+        pred = torch.empty(B, N, dtype=torch.float32, device=dev) if po.get("want_pred") else None
+        z = po.get("z")
+        _lib.check(lib.gdmcf_linear_posterior_fwd_f32(
+            A_ptr, lda, w_ptr, ldw, bias_ptr, x_t.data_ptr(), x_t.stride(0), po["c1"].data_ptr(), po["c2"].data_ptr(),
+            _lib.ptr(po.get("r1")), _lib.ptr(po.get("r2")), _lib.ptr(po.get("sigma")), _lib.ptr(z),
+            z.stride(0) if z is not None else 0, B, N, K, xn.data_ptr(), xn.stride(0), _lib.ptr(pred),
+            pred.stride(0) if pred is not None else 0, st))
+        return xn, pred
+
+    def forward_plain(self, x, timesteps, x_U, training, drop_mask=None, drop_mask_U=None, posterior=None):
         prev = self.lib.gdmcf_gemm_precision(self._precision())
         try:
             B, dev = x.shape[0], x.device
@@ -388,9 +411,8 @@ class OneHotEngine:
             A, lda = self._hidden(bufs, br1, br2, out, B)
             w, bias, act = out[-1]
             N, K = w.shape
-            res = torch.empty(B, N, dtype=torch.float32, device=dev)
-            _lib.check(lib.gdmcf_linear_fwd_f32(A.data_ptr(), lda, w.data_ptr(), w.stride(0), bias.data_ptr(), act, B, N, K,
-                                                res.data_ptr(), res.stride(0), bufs.ws.data_ptr(), bufs.ws_bytes, st))
+            res = self._last_layer(A.data_ptr(), lda, w.data_ptr(), w.stride(0), bias.data_ptr(), act, B, N, K, x, posterior,
+                                   bufs, st)
             del keep
             return res
         finally:
@@ -450,12 +472,13 @@ class DNNOneHot(nn.Module):
     def param_list(self):
         return list(self.parameters())
 
-    def forward(self, x, timesteps, x_U, drop_mask=None, drop_mask_U=None):
+    def forward(self, x, timesteps, x_U, drop_mask=None, drop_mask_U=None, posterior=None):
         """model(x_t, t, x_tU) of the reference's evaluation path.  Training goes through
         GaussianDiffusionDiscrete.training_losses (fused forward + loss with its own backward); this plain forward
-        carries no autograd graph."""
+        carries no autograd graph.  `posterior` (reverse loop, see OneHotEngine._last_layer): return (x_{t-1}, pred_xstart)
+        with the posterior mean fused into the output GEMM instead of the raw output."""
         _lib.require_gpu(x, "DNNOneHot input")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
             raise RuntimeError("gdmcf_amd.DNNOneHot: the plain forward is not differentiable; train through "
                                "GaussianDiffusionDiscrete.training_losses (or call under torch.no_grad())")
-        return self.engine.forward_plain(x, timesteps, x_U, self.training, drop_mask, drop_mask_U)
+        return self.engine.forward_plain(x, timesteps, x_U, self.training, drop_mask, drop_mask_U, posterior=posterior)

@@ -161,7 +161,7 @@ class OneHotEmbeddingEngine(OneHotEngine):
         sv["keepalive"] = (sv["keepalive"], gc)
         return res + [dV, dWu]
 
-    def forward_plain(self, x, timesteps, x_U, training, drop_mask=None, drop_mask_U=None, index=None):
+    def forward_plain(self, x, timesteps, x_U, training, drop_mask=None, drop_mask_U=None, index=None, posterior=None):
         prev = self.lib.gdmcf_gemm_precision(self._precision())
         try:
             B, dev = x.shape[0], x.device
@@ -182,10 +182,8 @@ class OneHotEmbeddingEngine(OneHotEngine):
             keep = (self._prep(bufs, x, self.I, bufs.xin1, ts, None, None, None, drop_mask, training),
                     self._prep(bufs, xu, 2 * self.I, bufs.xin2, ts, None, None, None, drop_mask_U, training))
             self._scores_operands(bufs, br1, br2, B, index)
-            res = torch.empty(B, self.I, dtype=torch.float32, device=dev)
-            _lib.check(lib.gdmcf_linear_fwd_f32(bufs.uhat.data_ptr(), bufs.uhat.stride(0), bufs.Vhat.data_ptr(),
-                                                bufs.Vhat.stride(0), None, 0, B, self.I, bufs.D, res.data_ptr(), res.stride(0),
-                                                bufs.ws.data_ptr(), bufs.ws_bytes, st))
+            res = self._last_layer(bufs.uhat.data_ptr(), bufs.uhat.stride(0), bufs.Vhat.data_ptr(), bufs.Vhat.stride(0), None,
+                                   0, B, self.I, bufs.D, x, posterior, bufs, st)
             del keep
             return res
         finally:
@@ -249,11 +247,12 @@ class DNNOneHotEmbedding(DNNOneHot):
             torch.autograd.graph.increment_version(p_)  # cached V/|v| and shadows are keyed on the version counter
         return fu, fi
 
-    def forward(self, x, timesteps, x_U, index=None, graph=None, RCloss=False, drop_mask=None, drop_mask_U=None):
+    def forward(self, x, timesteps, x_U, index=None, graph=None, RCloss=False, drop_mask=None, drop_mask_U=None, posterior=None):
         """model(x_t, t, x_tU, index=..., graph=...) of the reference's evaluation path (`graph` is accepted and, as in the
-        reference, unused).  Training goes through GaussianDiffusionDiscrete.training_losses."""
+        reference, unused).  Training goes through GaussianDiffusionDiscrete.training_losses.  `posterior`: see
+        DNNOneHot.forward (the reverse loop's posterior mean fused into the score GEMM)."""
         _lib.require_gpu(x, "DNNOneHotEmbedding input")
         if RCloss or (torch.is_grad_enabled() and self.training and any(p.requires_grad for p in self.parameters())):
             raise RuntimeError("gdmcf_amd.DNNOneHotEmbedding: the plain forward is not differentiable and carries no "
                                "NT-Xent term; train through GaussianDiffusionDiscrete.training_losses")
-        return self.engine.forward_plain(x, timesteps, x_U, self.training, drop_mask, drop_mask_U, index=index)
+        return self.engine.forward_plain(x, timesteps, x_U, self.training, drop_mask, drop_mask_U, index=index, posterior=posterior)
