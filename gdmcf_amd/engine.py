@@ -72,6 +72,15 @@ class DenoiserEngine:
         # next step starts: train_forward waits per layer, right before the first GEMM that reads the weight, so the
         # last layer's gather travels under the first layers' GEMMs.  Every other entry point waits for all up front.
         self.weight_waiters = {}
+        # opt-in (GDMCF_GEMM_SIDE=1), single GPU: the last layer's weight-gradient GEMM on a second stream beside the
+        # input-gradient GEMM (both only read dZ; each fills the other's partial last round of workgroups).  Measured
+        # 1.692 -> 1.673 ms per Yelp-shape step, 4.276 -> 4.251 ms at the Amazon-Book shape, bit-identical results.  Off by
+        # default: two GEMMs sharing the chip cannot be timed one by one (HIP events / rocprof show 0.44 + 0.35 ms for the
+        # pair instead of 0.26 + 0.23), and the per-kernel roofline is what bench.py reports.
+        import os as _os
+        self._gemm_side = _os.environ.get("GDMCF_GEMM_SIDE", "0") == "1"
+        self._side2 = None
+        self._side2_used = False
 
     def _use_weight(self, w):
         fn = self.weight_waiters.pop(id(w), None) if self.weight_waiters else None
@@ -413,8 +422,19 @@ class DenoiserEngine:
                 dW = None
             else:
                 dW = torch.empty_like(w)
-                _lib.check(lib.gdmcf_linear_bwd_weight_f32(dz.data_ptr(), lddz, A_use.data_ptr(), lda_use, _lib.ptr(rs),
-                                                           B, N, K, dW.data_ptr(), dW.stride(0), db.data_ptr(), 0, st))
+                if self._gemm_side and self.grad_sink is None and li == L - 1 and L > 1:
+                    # the last layer's weight-gradient GEMM on a second stream, beside the input-gradient GEMM
+                    if self._side2 is None:
+                        self._side2 = torch.cuda.Stream()
+                    self._side2.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(self._side2):
+                        _lib.check(lib.gdmcf_linear_bwd_weight_f32(dz.data_ptr(), lddz, A_use.data_ptr(), lda_use, _lib.ptr(rs),
+                                                                   B, N, K, dW.data_ptr(), dW.stride(0), db.data_ptr(), 0,
+                                                                   _lib.stream_ptr()))
+                    self._side2_used = True
+                else:
+                    _lib.check(lib.gdmcf_linear_bwd_weight_f32(dz.data_ptr(), lddz, A_use.data_ptr(), lda_use, _lib.ptr(rs),
+                                                               B, N, K, dW.data_ptr(), dW.stride(0), db.data_ptr(), 0, st))
             grads_w[li], grads_b[li] = dW, db
             if self.grad_sink is not None:
                 self.grad_sink(w, dW)
@@ -435,6 +455,9 @@ class DenoiserEngine:
                 weight_grad(li, w, bias, A_prev, lda_prev, N, K)
                 nxt = input_grad(li, w, A_prev, lda_prev, N, K)
             dz, lddz, rs = nxt
+        if self._side2_used:  # everything that consumes the gradients is ordered behind the side stream
+            torch.cuda.current_stream().wait_stream(self._side2)
+            self._side2_used = False
         if self.grad_sink is not None:
             self.grad_sink(m.emb_layer.weight, dWe)
             self.grad_sink(m.emb_layer.bias, dbe)
