@@ -76,6 +76,7 @@ _SIGNATURES = {
     "gdmcf_graph_guided_step_u8": (c_int, [P, c_int64, P, c_int, c_int, c_float, P, c_int64, P, P, c_int, c_uint64, c_uint64, P,
                                            c_int64, P, P]),
     "gdmcf_debug_spmm_stamps": (c_int, [c_int, P]),
+    "gdmcf_row_loss_finish_mean_f64": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, P, P, c_int, P, P, P, P, P, P]),
     "gdmcf_dnn_prep_input_csr_f32": (c_int, [P, P, P, P, P, P, c_int, P, c_int64, c_int, P, c_int64, c_float, c_uint64, c_uint64,
                                              P, P, c_int, c_int, c_int, P, c_int64, P, P, c_int64, P]),
     "gdmcf_linear_loss_fwd_bits_f32": (c_int, [P, c_int64, P, c_int64, P, P, c_int64, P, c_int, c_int, c_int, P, c_int64, P,

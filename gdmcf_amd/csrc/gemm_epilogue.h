@@ -210,7 +210,6 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GdGemm
                     }
                     if (has_z) sgv[e] = g.r4[mc];
                 }
-#pragma unroll
                 if (EPI == GD_EPI_LOSS && g.aux_bits) {
                     // {0,1} target rows kept as bitmaps (CSR input path).  The wave's columns start at a multiple of 32 and
                     // lane r owns column 16*j + r of it: columns j and j^1 share a word -> one load per 32 columns and row

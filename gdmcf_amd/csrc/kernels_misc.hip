@@ -711,16 +711,31 @@ __global__ __launch_bounds__(256) void row_loss_finish_kernel(const float* __res
                                                               const double* __restrict__ weight_t,
                                                               const double* __restrict__ pt, int B, int T, int H,
                                                               double* hist, int64_t* cnt, int update,
-                                                              double* __restrict__ lu, double* __restrict__ loss) {
+                                                              double* __restrict__ lu, double* __restrict__ loss,
+                                                              double* __restrict__ loss_mean, float* __restrict__ rowscale_mean,
+                                                              float inv_b) {
     extern __shared__ __attribute__((aligned(16))) unsigned char fin_lds[];
+    double part = 0.0;
     for (int b = threadIdx.x; b < B; b += 256) {
         const float mse = rowsum[b] / rowdiv[b];  // f32 mean, as mean_flat on f32 (:335)
         const double l = weight_t[ts[b]] * (double)mse;  // f64 weight * f32 mse -> f64 (:352)
         lu[b] = l;
-        loss[b] = l / pt[b];  // (:370)
-        if (gradcoef)
-            gradcoef[b] = (float)(2.0 * (alpha ? (double)alpha[b] : 1.0) * weight_t[ts[b]] /
-                                  (pt[b] * (double)rowdiv[b]));
+        const double lb = l / pt[b];  // (:370)
+        loss[b] = lb;
+        part += lb;
+        if (gradcoef) {
+            const float gc = (float)(2.0 * (alpha ? (double)alpha[b] : 1.0) * weight_t[ts[b]] / (pt[b] * (double)rowdiv[b]));
+            gradcoef[b] = gc;
+            // the mean reduction of main.py:348 has the constant upstream gradient 1/B: the row scale of its backward
+            if (rowscale_mean) rowscale_mean[b] = gc * inv_b;
+        }
+    }
+    if (loss_mean) {  // losses["loss"].mean() (main.py:348) in float64, fixed order: lane-strided sums, xor tree, waves 0..3
+        double* s_part = reinterpret_cast<double*>(fin_lds);  // the FIFO update below re-initialises what it uses
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+        if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = part;
+        __syncthreads();
+        if (threadIdx.x == 0) *loss_mean = (((s_part[0] + s_part[1]) + s_part[2]) + s_part[3]) / (double)B;
     }
     __syncthreads();
     if (update) lt_history_parallel(ts, lu, B, T, H, hist, cnt, fin_lds);
@@ -1138,7 +1153,16 @@ int gdmcf_row_loss_finish_f64(const float* rowsum, const float* rowdiv, const fl
                               const double* weight_t, const double* pt, int B, int T, int H, double* Lt_history,
                               int64_t* Lt_count, int update_history, double* loss_unscaled, double* loss,
                               float* gradcoef, void* stream) {
+    return gdmcf_row_loss_finish_mean_f64(rowsum, rowdiv, alpha, ts, weight_t, pt, B, T, H, Lt_history, Lt_count, update_history,
+                                          loss_unscaled, loss, gradcoef, nullptr, nullptr, stream);
+}
+
+int gdmcf_row_loss_finish_mean_f64(const float* rowsum, const float* rowdiv, const float* alpha, const int64_t* ts,
+                                   const double* weight_t, const double* pt, int B, int T, int H, double* Lt_history,
+                                   int64_t* Lt_count, int update_history, double* loss_unscaled, double* loss,
+                                   float* gradcoef, double* loss_mean, float* rowscale_mean, void* stream) {
     GD_CHECK_SHAPE(B > 0 && T > 0 && H > 0, "row_loss_finish: bad shape");
+    GD_CHECK_ARG(!rowscale_mean || gradcoef, "row_loss_finish: rowscale_mean needs gradcoef");
     const size_t lds = (size_t)T * H * 8 + (size_t)T * 8 + (size_t)B * 4 + 16;
     GD_CHECK_ARG(lds <= 150 * 1024, "row_loss_finish: T*H and B too large for the LDS-resident FIFO update (150 KiB)");
     static bool attr_set = false;
@@ -1151,7 +1175,8 @@ int gdmcf_row_loss_finish_f64(const float* rowsum, const float* rowdiv, const fl
         attr_set = true;
     }
     hipLaunchKernelGGL(row_loss_finish_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, rowsum, rowdiv, alpha,
-                       gradcoef, ts, weight_t, pt, B, T, H, Lt_history, Lt_count, update_history, loss_unscaled, loss);
+                       gradcoef, ts, weight_t, pt, B, T, H, Lt_history, Lt_count, update_history, loss_unscaled, loss,
+                       loss_mean, rowscale_mean, 1.0f / (float)B);
     return gd_launch_status("row_loss_finish");
 }
 

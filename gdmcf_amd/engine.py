@@ -315,11 +315,17 @@ class DenoiserEngine:
                                                      bufs.rowsum.data_ptr(), st))
         loss = torch.empty(B, dtype=torch.float64, device=dev)
         pt = spec["pt"]
-        _lib.check(lib.gdmcf_row_loss_finish_f64(bufs.rowsum.data_ptr(), rowdiv.data_ptr(), _lib.ptr(alpha),
-                                                 ts.data_ptr(), spec["weight_t"].data_ptr(), pt.data_ptr(), B,
-                                                 spec["T"], spec["H"], spec["Lt_history"].data_ptr(),
-                                                 spec["Lt_count"].data_ptr(), int(spec["update_history"]),
-                                                 bufs.lu.data_ptr(), loss.data_ptr(), bufs.gradcoef.data_ptr(), st))
+        # the tail also emits mean(loss) and gradcoef/B: the reference's step takes the mean next (main.py:348), and its
+        # backward scales every row by 1/B -- two launches less per step (DataParallelStep uses both)
+        self.last_loss_mean = torch.empty((), dtype=torch.float64, device=dev)
+        if getattr(bufs, "rowscale_mean", None) is None:
+            bufs.rowscale_mean = torch.zeros(B, dtype=torch.float32, device=dev)
+        _lib.check(lib.gdmcf_row_loss_finish_mean_f64(bufs.rowsum.data_ptr(), rowdiv.data_ptr(), _lib.ptr(alpha),
+                                                      ts.data_ptr(), spec["weight_t"].data_ptr(), pt.data_ptr(), B,
+                                                      spec["T"], spec["H"], spec["Lt_history"].data_ptr(),
+                                                      spec["Lt_count"].data_ptr(), int(spec["update_history"]),
+                                                      bufs.lu.data_ptr(), loss.data_ptr(), bufs.gradcoef.data_ptr(),
+                                                      self.last_loss_mean.data_ptr(), bufs.rowscale_mean.data_ptr(), st))
         self._saved = dict(kind="train", B=B, bufs=bufs, layers=layers, keepalive=(keepalive, target, alpha, rowdiv, pt))
         return loss
 
@@ -331,7 +337,9 @@ class DenoiserEngine:
         if sv is None or sv.get("kind") != "train":
             raise RuntimeError("gdmcf_amd: train_backward without a preceding training_losses")
         bufs = sv["bufs"]
-        if isinstance(gloss, float):
+        if isinstance(gloss, float) and gloss == 1.0 / sv["B"] and getattr(bufs, "rowscale_mean", None) is not None:
+            rowscale = bufs.rowscale_mean  # gradcoef * (float)(1/B), written by the loss tail: same bits as the product below
+        elif isinstance(gloss, float):
             rowscale = bufs.gradcoef * gloss
         else:
             rowscale = (gloss.to(torch.float32) * bufs.gradcoef).contiguous()

@@ -314,7 +314,9 @@ class DataParallelStep:
             # autograd graph (same kernels on the same values; saves four tiny elementwise launches per step)
             with torch.no_grad():
                 losses = self.diffusion.training_losses(self.model, batch, reweight, **rand)
-            loss = losses["loss"].mean()
+            loss = getattr(eng, "last_loss_mean", None)  # written by the loss tail kernel (fixed-order float64 mean)
+            if loss is None:
+                loss = losses["loss"].mean()
             grads = eng.train_backward(1.0 / losses["loss"].numel())
             for p, g in zip(self.model.param_list(), grads):
                 if g is not None:  # None: already handed to the gradient sink
@@ -323,6 +325,8 @@ class DataParallelStep:
             losses = self.diffusion.training_losses(self.model, batch, reweight, **rand)
             loss = losses["loss"].mean()
             loss.backward()
+            if getattr(eng, "last_loss_mean", None) is not None:
+                loss = eng.last_loss_mean  # report the same (fixed-order) mean on every path
         if self.exchange:
             d = self.diffusion
             if getattr(self.model.engine, "grad_sink", None) is not None:

@@ -268,6 +268,13 @@ int gdmcf_row_loss_finish_f64(const float* rowsum, const float* rowdiv, const fl
                               int T, int H, double* Lt_history, int64_t* Lt_count,
                               int update_history, double* loss_unscaled, double* loss,
                               float* gradcoef, void* stream);
+/* The same tail, additionally emitting what the reference's step computes next (main.py:348-350): loss_mean (optional,
+ * float64 scalar) = mean_b loss[b], summed in a fixed order, and rowscale_mean[b] (optional, float32) = gradcoef[b] *
+ * (float)(1/B) -- the per-row scale of the backward of that mean -- so that the step needs no reduction / scaling launch. */
+int gdmcf_row_loss_finish_mean_f64(const float* rowsum, const float* rowdiv, const float* alpha, const int64_t* ts,
+                                   const double* weight_t, const double* pt, int B, int T, int H, double* Lt_history,
+                                   int64_t* Lt_count, int update_history, double* loss_unscaled, double* loss,
+                                   float* gradcoef, double* loss_mean, float* rowscale_mean, void* stream);
 int gdmcf_lt_history_update(const int64_t* ts, const double* loss_unscaled, int B, int T, int H,
                             double* Lt_history, int64_t* Lt_count, void* stream);
 

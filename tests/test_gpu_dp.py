@@ -115,7 +115,9 @@ def test_single_process_early_update_equals_sequential_step():
         i = inputs(s)
         l1.append(float(step(i["x"], True, ts=i["ts"], pt=torch.ones(B2, device=dev), noise=i["noise"], drop_mask=i["keep"])))
     torch.cuda.synchronize()
-    assert l0 == l1
+    # the reported scalar: torch's mean of the float64 row losses vs the loss-tail kernel's fixed-order mean of the same
+    # values (last bit may differ); everything the step COMPUTES WITH is compared bit for bit below
+    np.testing.assert_allclose(l0, l1, rtol=1e-14, atol=0)
     for a, b in zip(m0.parameters(), m1.parameters()):
         assert torch.equal(a, b)
         assert torch.equal(o0.state[a]["exp_avg_sq"], o1.state[b]["exp_avg_sq"]) and o0.state[a]["step"] == o1.state[b]["step"]
