@@ -222,7 +222,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GdGemm
                         wv[jj] = g.aux_bits[(int64_t)mc * g.ldbits + min((int64_t)((cbase >> 5) + jj), g.ldbits - 1)];
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
-                        av[e][j] = ((wv[j >> 1] >> (16 * (j & 1) + r)) & 1u) ? 1.f : 0.f;
+                        av[e][j] = (float)((wv[j >> 1] >> (16 * (j & 1) + r)) & 1u);  // v_bfe_u32 + v_cvt_f32_u32
                         zv[e][j] = 0.f;
                     }
                 } else {

@@ -27,6 +27,15 @@ def test_capi_exports_every_declared_symbol():
     assert lib.gdmcf_version() == 1
 
 
+def test_library_is_built_from_the_current_sources():
+    """The in-tree libgdmcf_hip.so (the file that travels to the GPU box) was built from the sources as they are now: a
+    header that stopped compiling once went unnoticed because every later run loaded the previous binary."""
+    from gdmcf_amd import build as b
+    stamp = os.path.join(b.CSRC, ".build_stamp")
+    assert os.path.exists(b.LIB) and os.path.exists(stamp), "run python -m gdmcf_amd.build"
+    assert open(stamp).read() == b._digest(), "sources changed since libgdmcf_hip.so was built: run python -m gdmcf_amd.build"
+
+
 def test_schedule_build_matches_reference_tables():
     fx = H.load("schedules")
     kinds = {"linear": 0, "linear-var": 1, "cosine": 2, "binomial": 3}
