@@ -1,0 +1,38 @@
+import sys, os, numpy as np, torch, time
+sys.path.insert(0, os.getcwd())
+import gdmcf_amd
+from gdmcf_amd import data
+# 1) SpMM determinism soak: 600 propagations, all bit-identical
+cfg = data.SHAPES["yelp"]; indptr, indices, I = data.synth_csr("yelp", seed=0); U = cfg["n_users"]
+users = np.repeat(np.arange(U), np.diff(indptr))
+torch.manual_seed(0)
+m = gdmcf_amd.LightGCN({"user_id_idx": users, "item_id_idx": indices}, U, I, 3, 64, device="cuda:0").to("cuda:0")
+with torch.no_grad():
+    ref = torch.cat(m.propagate_through_layers()[:2]).clone()
+    bad = 0
+    for i in range(600):
+        out = torch.cat(m.propagate_through_layers()[:2])
+        bad += int(not torch.equal(out, ref))
+print("spmm soak: mismatching runs", bad, "of 600; finite", bool(torch.isfinite(ref).all()))
+# 2) training soak on sparse rows: 1500 steps, loss finite and decreasing, two identical runs
+import scipy.sparse as sp
+from gdmcf_amd.data_utils import DeviceCSR
+n = 4000
+ip, ix = indptr[:n + 1], indices[:indptr[n]]
+dcsr = DeviceCSR(sp.csr_matrix((np.ones(len(ix), np.float32), ix, ip), shape=(n, I)), "cuda:0")
+def run():
+    torch.manual_seed(1)
+    model = gdmcf_amd.DNN([I, 1000], [1000, I], 10).to("cuda:0").train()
+    d = gdmcf_amd.GaussianDiffusion(gdmcf_amd.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, 5, "cuda:0")
+    opt = gdmcf_amd.FusedAdamW(model.parameters(), lr=1e-4)
+    step = gdmcf_amd.parallel.DataParallelStep(d, model, opt)
+    losses = []
+    for s in range(1500):
+        ids = torch.arange((s % 10) * 400, (s % 10) * 400 + 400)
+        losses.append(step(dcsr.batch(ids), True))
+    torch.cuda.synchronize()
+    return torch.stack(losses).cpu().numpy(), [p.detach().clone() for p in model.parameters()]
+t = time.time(); l1, w1 = run(); t1 = time.time() - t
+l2, w2 = run()
+print("train soak: 1500 steps in %.1f s; loss first %.4f last %.4f; finite %s; reruns identical: losses %s weights %s" % (
+    t1, l1[:10].mean(), l1[-10:].mean(), bool(np.isfinite(l1).all()), bool((l1 == l2).all()), all(torch.equal(a, b) for a, b in zip(w1, w2))))
