@@ -3,6 +3,8 @@
     python examples/train_synthetic.py --users 8000 --epochs 3            # fp32
     python examples/train_synthetic.py --users 8000 --epochs 3 --bf16     # bf16 GEMM inputs
     python examples/train_synthetic.py --users 8000 --epochs 3 --backbone onehot   # one-hot variant (DNNOneHot)
+    python examples/train_synthetic.py --users 4000 --epochs 2 --backbone onehot-emb --hidden 256 --lightgcn-init 50
+                                                                                   # LightGCN BPR -> tables handed to the denoiser
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         examples/train_synthetic.py --users 64000 --epochs 3               # data parallel: one process per GPU (RCCL)
 
@@ -37,6 +39,10 @@ def main():
     ap.add_argument("--backbone", default="dnn", choices=["dnn", "onehot", "onehot-emb", "onehot-gcn"],
                     help="onehot: GaussianDiffusionDiscrete(CatOneHot=True) + DNNOneHot; onehot-emb: + user / item embedding "
                          "tables (DNNOneHotEmbedding, indexIn); both fp32")
+    ap.add_argument("--lightgcn-init", type=int, default=0, metavar="STEPS",
+                    help="onehot-emb / onehot-gcn: first train a LightGCN (latent dim = --hidden) on the training graph for "
+                         "STEPS BPR steps (HIP SpMM propagation, reference lightGCN.py:273-338) and hand its propagated tables "
+                         "to the backbone's embedding_user / embedding_item (load_lightgcn_embeddings)")
     args = ap.parse_args()
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
     dev = torch.device(f"cuda:{local}")
@@ -71,6 +77,30 @@ def main():
         model = gdmcf_amd.DNN([I, args.hidden], [args.hidden, I], 10, time_type="cat", norm=False,
                               gemm_dtype="bf16" if args.bf16 else "f32").to(dev)
         diffusion = gdmcf_amd.GaussianDiffusion(gdmcf_amd.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, args.T, dev)
+    if args.lightgcn_init > 0 and args.backbone in ("onehot-emb", "onehot-gcn"):
+        # "fed by the LightGCN propagation" (north star): BPR-train the graph model on the same interactions, then
+        # initialise the denoiser's user / item tables from mean_l(A~^l E0)
+        from gdmcf_amd.lightgcn import bpr_loss, sample_bpr_batch
+        coo = train.tocoo()
+        lg = gdmcf_amd.LightGCN({"user_id_idx": coo.row, "item_id_idx": coo.col}, U, I, 3, args.hidden, device=dev).to(dev)
+        lopt = torch.optim.Adam(lg.parameters(), lr=0.005)
+        tr = train.tocsr()
+        active = np.nonzero(np.diff(tr.indptr) > 0)[0]
+        t0 = time.perf_counter()
+        for s_ in range(args.lightgcn_init):
+            bu = np.sort(rng.choice(active, min(1024, len(active)), replace=False))
+            deg = tr.indptr[bu + 1] - tr.indptr[bu]
+            bp = tr.indices[tr.indptr[bu] + (rng.random(len(bu)) * deg).astype(np.int64)]
+            bn = rng.integers(0, I, len(bu))
+            bu_, bp_, bn_ = (torch.from_numpy(np.asarray(a, dtype=np.int64)).to(dev) for a in (bu, bp, bn))
+            lopt.zero_grad()
+            mf, reg = bpr_loss(bu_, *lg(bu_, bp_, bn_))
+            (mf + 1e-4 * reg).backward()
+            lopt.step()
+        torch.cuda.synchronize()
+        model.load_lightgcn_embeddings(lg)
+        say(f"LightGCN: {args.lightgcn_init} BPR steps in {time.perf_counter() - t0:.2f} s (last mf loss {float(mf.detach()):.4f}); "
+            f"tables handed to {type(model).__name__}", flush=True)
     opt = gdmcf_amd.FusedAdamW(model.parameters(), lr=args.lr, weight_decay=0.0)
     gen = torch.Generator().manual_seed(0)
     from gdmcf_amd.parallel import DataParallelStep
