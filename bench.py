@@ -100,6 +100,7 @@ def parse():
                     help="single GPU: update the two large weights inside the weight-gradient GEMM epilogue "
                          "(FusedAdamW.fuse_into_backward); same update rule, gradient never materialised")
     ap.add_argument("--no-fused-leg", action="store_true", help="N = 1: skip the extra leg with AdamW fused into the dW epilogues")
+    ap.add_argument("--no-graph-leg", action="store_true", help="N = 1: skip the extra leg that replays the step from a hipGraph")
     ap.add_argument("--bpr", action="store_true", help="also time a LightGCN BPR training step (reported under 'bpr')")
     ap.add_argument("--backbone", default="dnn", choices=["dnn", "onehot", "onehot-emb", "onehot-gcn"],
                     help="dnn: the plain denoiser (BASELINE configs); onehot: GaussianDiffusionDiscrete(CatOneHot=True) + "
@@ -443,6 +444,31 @@ def main():
                          "epilogues (bench.py --fuse-optimizer makes it the main line)")
         opt.fuse_into_backward(model, min_numel=1 << 62)  # off again
 
+    # ---- N = 1: the same step captured once in a hipGraph and replayed (gdmcf_amd/graph.py: counters and AdamW scalars in
+    # device memory, batch = a fixed id buffer over the resident CSR matrix; bit-identical to the eager step by test).
+    # `host_enqueue_ms` is what the host spends per step: one 3 KB id copy + one graph launch. ----
+    graph_leg = None
+    if world == 1 and args.backbone == "dnn" and sparse_rows and not args.fuse_optimizer and not args.rehearse_dp \
+            and not args.no_graph_leg:
+        from gdmcf_amd.graph import GraphedTrainStep
+        try:
+            with GraphedTrainStep(diffusion, model, opt, dcsr, B, warmup=3) as gstep:
+                for i in range(max(5, args.warmup // 4)):
+                    gstep(row_ids[i % n_pool])
+                sync()
+                t1 = time.perf_counter()
+                for i in range(args.steps):
+                    loss_g = gstep(row_ids[i % n_pool])
+                hg = time.perf_counter() - t1
+                sync()
+                eg = time.perf_counter() - t1
+            graph_leg = dict(ms_per_step=round(1e3 * eg / args.steps, 4), users_per_s=round(B * args.steps / eg, 1),
+                             host_enqueue_ms=round(1e3 * hg / args.steps, 4), eager_host_enqueue_ms=round(1e3 * host_el / args.steps, 4),
+                             steps=args.steps, final_loss=float(loss_g),
+                             what="the training step replayed from one hipGraph (gdmcf_amd.graph.GraphedTrainStep)")
+        except Exception as exc:  # reported, never fatal for the main line
+            graph_leg = dict(error=f"{type(exc).__name__}: {exc}"[:300])
+
     # ---- roofline of the dominant kernel (rank 0's events) ----
     roofline, klist = None, []
     for tag, d in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"]):
@@ -519,7 +545,7 @@ def main():
                        "batch_rows": "device CSR rows (CsrBatch)" if sparse_rows else "dense rows densified from the device CSR"},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": klist, "final_loss": final_loss,
             "host_enqueue_ms_per_step": round(1e3 * host_el / args.steps, 4),
-            "replicas_in_sync": in_sync, "dp_autotune": dp_autotune, "strong_scaling": strong_leg, "fused_optimizer_leg": fused_leg,
+            "replicas_in_sync": in_sync, "dp_autotune": dp_autotune, "strong_scaling": strong_leg, "fused_optimizer_leg": fused_leg, "graph_leg": graph_leg,
             "ranks_in_group": dist.get_world_size() if dist.is_initialized() else 1,
             "optimizer": "FusedAdamW" + (" fused into the dW GEMM epilogues" if (args.fuse_optimizer and world == 1) else
                                          " (row-sharded over the ranks: reduce-scatter, AdamW on 1/N rows, deferred all-gather)"

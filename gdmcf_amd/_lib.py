@@ -76,6 +76,12 @@ _SIGNATURES = {
     "gdmcf_graph_guided_step_u8": (c_int, [P, c_int64, P, c_int, c_int, c_float, P, c_int64, P, P, c_int, c_uint64, c_uint64, P,
                                            c_int64, P, P]),
     "gdmcf_debug_spmm_stamps": (c_int, [c_int, P]),
+    "gdmcf_graph_state_bytes": (c_int, []),
+    "gdmcf_adam_hyper_bytes": (c_int, []),
+    "gdmcf_graph_state_init": (c_int, [P, c_uint64, c_uint64, c_int64, c_int64, c_int64, P]),
+    "gdmcf_adam_hyper_fill": (c_int, [P, c_int, c_float, c_float, c_float, c_float, c_float, c_int64, c_float]),
+    "gdmcf_graph_state_bind": (c_int, [P]),
+    "gdmcf_graph_state_tick": (c_int, [P, P]),
     "gdmcf_row_loss_finish_mean_f64": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, P, P, c_int, P, P, P, P, P, P]),
     "gdmcf_dnn_prep_input_csr_f32": (c_int, [P, P, P, P, P, P, c_int, P, c_int64, c_int, P, c_int64, c_float, c_uint64, c_uint64,
                                              P, P, c_int, c_int, c_int, P, c_int64, P, P, c_int64, P]),

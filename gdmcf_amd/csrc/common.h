@@ -89,6 +89,21 @@ __device__ __forceinline__ void gd_adam_elem(float& p, float g, float& m, float&
     p = p + (h.neg_step * m) / denom;
 }
 
+// ---- graph step state (kernels_misc.hip: gdmcf_graph_state_*) ---------------------------------------------------------
+// When a training step is captured in a hipGraph its kernel ARGUMENTS are frozen; what changes from step to step (the
+// Philox offsets of the input builder and of the timestep sampler, the AdamW bias corrections) therefore lives in device
+// memory: a block of this layout, advanced by gdmcf_graph_state_tick at the start of every step (eager or replayed).
+struct GdStepState {
+    uint64_t prep_offset;  // Philox offset of the next input-builder launch
+    uint64_t ts_offset;    // ... of the next timestep draw
+    int64_t adam_step;     // optimiser steps taken
+    int64_t table_first;   // hyper_table[k] belongs to optimiser step table_first + k
+    int64_t table_len;
+    const GdAdamHyper* hyper_table;  // host-computed scalars of the coming steps (bit-identical to the eager path)
+    GdAdamHyper hyper;               // the current step's
+};
+extern thread_local const GdStepState* t_gd_step_state;  // bound by gdmcf_graph_state_bind; NULL = by-value arguments
+
 struct GdGemm {
     const float* A;
     int64_t lda;

@@ -58,6 +58,7 @@ struct PrepArgs {
     float drop_scale;  // 1/(1-p)
     uint32_t keep_thresh;  // Philox: keep iff u < thresh
     uint64_t seed, offset;
+    const GdStepState* step_state;  // graph mode: the Philox offset is read from the device (NULL: `offset`)
     const float* rownorm;  // [B] L2 norms of x_t rows (normalize) or NULL
     const float* emb_w;
     const float* emb_b;
@@ -136,7 +137,8 @@ __device__ __forceinline__ void xt4(const PrepArgs& a, int b, int col, float ca,
     }
 }
 
-__global__ __launch_bounds__(256) void prep_rowss_kernel(const PrepArgs a, float* __restrict__ rownorm) {
+__global__ __launch_bounds__(256) void prep_rowss_kernel(PrepArgs a, float* __restrict__ rownorm) {
+    if (a.step_state) a.offset = a.step_state->prep_offset;
     const int b = blockIdx.x;
     float ca = 1.f, cb = 0.f;
     if (a.ca) {
@@ -162,7 +164,8 @@ __global__ __launch_bounds__(256) void prep_rowss_kernel(const PrepArgs a, float
 // are fetched once per thread and each workgroup moves 16 KB in and out instead of 4 KB.
 constexpr int PREP_G = 4;
 
-__global__ __launch_bounds__(256) void prep_input_kernel(const PrepArgs a) {
+__global__ __launch_bounds__(256) void prep_input_kernel(PrepArgs a) {
+    if (a.step_state) a.offset = a.step_state->prep_offset;
     const int b = blockIdx.y;
     const int64_t t = a.ts ? a.ts[b] : 0;
     float ca = 1.f, cb = 0.f;
@@ -756,7 +759,8 @@ __global__ __launch_bounds__(256) void sample_timesteps_kernel(const double* __r
                                                                const int64_t* __restrict__ cnt, int T, int H, int B,
                                                                double uniform_prob, uint64_t seed, uint64_t offset,
                                                                int64_t* __restrict__ ts, double* __restrict__ pt,
-                                                               double* __restrict__ p_out) {
+                                                               double* __restrict__ p_out, const GdStepState* step_state) {
+    if (step_state) offset = step_state->ts_offset;
     extern __shared__ __attribute__((aligned(16))) unsigned char st_lds[];
     double* p = reinterpret_cast<double*>(st_lds);  // [T] probabilities, then inclusive CDF in cdf[]
     double* cdf = p + T;
@@ -836,7 +840,8 @@ typedef GdAdamHyper AdamHyper;
 // stored, rounded to bfloat16, into its zero-padded 2-D shadow (gdmcf_bf16_shadow_set)
 template <bool NT_>
 __global__ __launch_bounds__(256) void adamw_kernel(const int64_t* __restrict__ table, int n_tensors,
-                                                    const AdamHyper h, const int64_t* __restrict__ stab) {
+                                                    AdamHyper h, const int64_t* __restrict__ stab, const GdStepState* step_state) {
+    if (step_state) h = step_state->hyper;  // graph mode: this step's scalars from the device
     int t = 0;
     for (int i = 1; i < n_tensors; ++i)
         if ((int64_t)blockIdx.x >= table[i * 6 + 5]) t = i;
@@ -975,7 +980,7 @@ int gdmcf_dnn_prep_input_f32(const float* x, int64_t ldx, const int64_t* ts, con
     a.ldn = ldn; a.drop_mode = drop_mode; a.keep = keep; a.ldkeep = ldkeep; a.drop_scale = 1.0f / (1.0f - drop_p);
     const double th = (1.0 - (double)drop_p) * 4294967296.0;
     a.keep_thresh = th >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)th;
-    a.seed = seed; a.offset = offset; a.rownorm = nullptr; a.emb_w = emb_w; a.emb_b = emb_b; a.E = E; a.B = B;
+    a.seed = seed; a.offset = offset; a.step_state = t_gd_step_state; a.rownorm = nullptr; a.emb_w = emb_w; a.emb_b = emb_b; a.E = E; a.B = B;
     a.I = I; a.xin = xin; a.ldxin = ldxin; a.xt_out = xt_out; a.ldxt = ldxt; a.temb_out = temb_out;
     a.xin16 = nullptr; a.ldxin16 = 0;
     a.csr_indptr = nullptr; a.csr_indices = nullptr; a.csr_rows = nullptr; a.bits_out = nullptr; a.ldbits = 0;
@@ -1023,7 +1028,7 @@ int gdmcf_dnn_prep_input_csr_f32(const int64_t* indptr, const int32_t* indices, 
     a.ldn = ldn; a.drop_mode = drop_mode; a.keep = keep; a.ldkeep = ldkeep; a.drop_scale = 1.0f / (1.0f - drop_p);
     const double th = (1.0 - (double)drop_p) * 4294967296.0;
     a.keep_thresh = th >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)th;
-    a.seed = seed; a.offset = offset; a.rownorm = nullptr; a.emb_w = emb_w; a.emb_b = emb_b; a.E = E; a.B = B;
+    a.seed = seed; a.offset = offset; a.step_state = t_gd_step_state; a.rownorm = nullptr; a.emb_w = emb_w; a.emb_b = emb_b; a.E = E; a.B = B;
     a.I = I; a.xin = xin; a.ldxin = ldxin; a.xt_out = nullptr; a.ldxt = 0; a.temb_out = temb_out;
     a.xin16 = nullptr; a.ldxin16 = 0;
     a.csr_indptr = indptr; a.csr_indices = indices; a.csr_rows = rows; a.bits_out = bits_out; a.ldbits = ldbits;
@@ -1205,7 +1210,7 @@ int gdmcf_sample_timesteps(const double* Lt_history, const int64_t* Lt_count, in
     GD_CHECK_SHAPE(B > 0 && T > 0 && H > 0, "sample_timesteps: bad shape");
     GD_CHECK_ARG(T <= 4096, "sample_timesteps: T > 4096 unsupported");
     hipLaunchKernelGGL(sample_timesteps_kernel, dim3(1), dim3(256), (size_t)T * 16, (hipStream_t)stream, Lt_history,
-                       Lt_count, T, H, B, uniform_prob, seed, offset, ts, pt, p_out);
+                       Lt_count, T, H, B, uniform_prob, seed, offset, ts, pt, p_out, t_gd_step_state);
     return gd_launch_status("sample_timesteps");
 }
 
@@ -1222,10 +1227,10 @@ static int adamw_launch(const int64_t* table, const int64_t* shadow_table, int n
         static const bool nt = !(getenv("GDMCF_ADAMW_NT") && atoi(getenv("GDMCF_ADAMW_NT")) == 0);
         if (nt)
             hipLaunchKernelGGL(adamw_kernel<true>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, table, n_tensors, h,
-                               shadow_table);
+                               shadow_table, t_gd_step_state);
         else
             hipLaunchKernelGGL(adamw_kernel<false>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, table, n_tensors,
-                               h, shadow_table);
+                               h, shadow_table, t_gd_step_state);
     }
     return gd_launch_status("adamw");
 }
@@ -1276,6 +1281,54 @@ GdAdamHyper gd_adam_hyper(float lr, float beta1, float beta2, float eps, float w
     h.grad_scale = grad_scale;
     return h;
 }
+
+// ---- graph step state ---------------------------------------------------------------------------------------------------
+thread_local const GdStepState* t_gd_step_state = nullptr;
+
+__global__ void graph_state_tick_kernel(GdStepState* st) {
+    st->prep_offset += 1;
+    st->ts_offset += 1;
+    st->adam_step += 1;
+    int64_t k = st->adam_step - st->table_first;
+    k = k < 0 ? 0 : (k >= st->table_len ? st->table_len - 1 : k);  // the host refills the table before it runs out
+    st->hyper = st->hyper_table[k];
+}
+
+extern "C" {
+
+int gdmcf_graph_state_bytes(void) { return (int)sizeof(GdStepState); }
+int gdmcf_adam_hyper_bytes(void) { return (int)sizeof(GdAdamHyper); }
+
+int gdmcf_graph_state_bind(const void* state_dev) {
+    t_gd_step_state = static_cast<const GdStepState*>(state_dev);
+    return GDMCF_OK;
+}
+
+int gdmcf_graph_state_init(void* state_host, uint64_t prep_offset, uint64_t ts_offset, int64_t adam_step, int64_t table_first,
+                           int64_t table_len, const void* hyper_table_dev) {
+    GD_CHECK_ARG(state_host && hyper_table_dev && table_len > 0, "graph_state_init: null pointer / empty table");
+    GdStepState* st = static_cast<GdStepState*>(state_host);
+    st->prep_offset = prep_offset; st->ts_offset = ts_offset; st->adam_step = adam_step; st->table_first = table_first;
+    st->table_len = table_len; st->hyper_table = static_cast<const GdAdamHyper*>(hyper_table_dev);
+    st->hyper = GdAdamHyper{};
+    return GDMCF_OK;
+}
+
+int gdmcf_adam_hyper_fill(void* out_host, int n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                          int64_t first_step, float grad_scale) {
+    GD_CHECK_ARG(out_host && n > 0 && first_step >= 1, "adam_hyper_fill: bad arguments");
+    GdAdamHyper* o = static_cast<GdAdamHyper*>(out_host);
+    for (int k = 0; k < n; ++k) o[k] = gd_adam_hyper(lr, beta1, beta2, eps, weight_decay, (int)(first_step + k), grad_scale);
+    return GDMCF_OK;
+}
+
+int gdmcf_graph_state_tick(void* state_dev, void* stream) {
+    GD_CHECK_ARG(state_dev, "graph_state_tick: null state");
+    hipLaunchKernelGGL(graph_state_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, static_cast<GdStepState*>(state_dev));
+    return gd_launch_status("graph_state_tick");
+}
+
+}  // extern "C"
 
 // ---- internal helpers used by linear.hip ---------------------------------------------------------
 int gd_splitk_reduce(const float* slabs, int64_t slab_stride, int splits, int64_t ld_slab, int M, int N, int mode,

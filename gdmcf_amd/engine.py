@@ -72,6 +72,10 @@ class DenoiserEngine:
         # next step starts: train_forward waits per layer, right before the first GEMM that reads the weight, so the
         # last layer's gather travels under the first layers' GEMMs.  Every other entry point waits for all up front.
         self.weight_waiters = {}
+        # gradients in persistent buffers (one per parameter, reused every step) instead of fresh tensors: constant
+        # addresses for a step captured in a hipGraph (gdmcf_amd/graph.py); a `.grad` kept across steps is overwritten
+        self.static_grads = False
+        self._grad_bufs = {}
         # opt-in (GDMCF_GEMM_SIDE=1), single GPU: the last layer's weight-gradient GEMM on a second stream beside the
         # input-gradient GEMM (both only read dZ; each fills the other's partial last round of workgroups).  Measured
         # 1.692 -> 1.673 ms per Yelp-shape step, 4.276 -> 4.251 ms at the Amazon-Book shape, bit-identical results.  Off by
@@ -81,6 +85,14 @@ class DenoiserEngine:
         self._gemm_side = _os.environ.get("GDMCF_GEMM_SIDE", "0") == "1"
         self._side2 = None
         self._side2_used = False
+
+    def _grad_like(self, p):
+        if not self.static_grads:
+            return torch.empty_like(p)
+        g = self._grad_bufs.get(id(p))
+        if g is None or g.shape != p.shape or g.device != p.device:
+            g = self._grad_bufs[id(p)] = torch.empty_like(p)
+        return g
 
     def _use_weight(self, w):
         fn = self.weight_waiters.pop(id(w), None) if self.weight_waiters else None
@@ -404,15 +416,15 @@ class DenoiserEngine:
                                                           dprev.data_ptr(), dprev.stride(0), bufs.ws.data_ptr(),
                                                           bufs.ws_bytes, st))
                 return dprev, dprev.stride(0), None
-            dWe = torch.empty_like(m.emb_layer.weight)
-            dbe = torch.empty_like(m.emb_layer.bias)
+            dWe = self._grad_like(m.emb_layer.weight)
+            dbe = self._grad_like(m.emb_layer.bias)
             _lib.check(lib.gdmcf_emb_bwd_f32(dz.data_ptr(), lddz, w.data_ptr(), w.stride(0), self.I, self.E,
                                              bufs.temb.data_ptr(), B, w.shape[0], bufs.demb.data_ptr(), dWe.data_ptr(),
                                              dbe.data_ptr(), st))
             return None, 0, None
 
         def weight_grad(li, w, bias, A_prev, lda_prev, N, K):
-            db = torch.empty_like(bias)
+            db = self._grad_like(bias)
             A_use, lda_use = A_prev, lda_prev
             if rs is not None:
                 # (rs . dZ)^T A == dZ^T (rs . A): scale the small activation instead of the big dZ
@@ -429,7 +441,7 @@ class DenoiserEngine:
                     torch.autograd.graph.increment_version(w)  # updated in the GEMM epilogue (bf16: shadow too)
                 dW = None
             else:
-                dW = torch.empty_like(w)
+                dW = self._grad_like(w)
                 if self._gemm_side and self.grad_sink is None and li == L - 1 and L > 1:
                     # the last layer's weight-gradient GEMM on a second stream, beside the input-gradient GEMM
                     if self._side2 is None:

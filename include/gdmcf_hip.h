@@ -388,6 +388,23 @@ int gdmcf_spmm_stream_f32(const int32_t* wdesc, int n_waves, const int32_t* cw, 
  * recording 8 int64 per wave -- start, first gather, end of pieces, end (100 MHz ticks), units, batches, XCC id, block --,
  * (n_waves, host buffer) copies them out and stops.                                                                     */
 int gdmcf_debug_spmm_stamps(int n_waves, long long* host_out);
+/* ---- graph step state: what changes from step to step, in device memory (hipGraph replay freezes kernel arguments) ----
+ * A training step captured in a hipGraph (gdmcf_amd/graph.py) replays the SAME launches; the Philox offsets of the input
+ * builder / timestep sampler and the AdamW bias corrections therefore come from a device block (opaque,
+ * gdmcf_graph_state_bytes() bytes, filled on the host by gdmcf_graph_state_init and copied to the device by the caller)
+ * that gdmcf_graph_state_tick advances by one step: offsets + 1, optimiser step + 1, scalars of that step taken from a
+ * host-computed table (gdmcf_adam_hyper_fill: n entries of gdmcf_adam_hyper_bytes() bytes for steps first_step ..., the
+ * same double-precision formulas as gdmcf_adamw_f32 -> bit-identical updates).  While a block is bound to the calling
+ * thread (gdmcf_graph_state_bind; NULL unbinds) gdmcf_dnn_prep_input(_csr)_f32, gdmcf_sample_timesteps and gdmcf_adamw_*
+ * ignore their offset / step arguments and read the block instead.                                                      */
+int gdmcf_graph_state_bytes(void);
+int gdmcf_adam_hyper_bytes(void);
+int gdmcf_graph_state_init(void* state_host, uint64_t prep_offset, uint64_t ts_offset, int64_t adam_step, int64_t table_first,
+                           int64_t table_len, const void* hyper_table_dev);
+int gdmcf_adam_hyper_fill(void* out_host, int n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                          int64_t first_step, float grad_scale);
+int gdmcf_graph_state_bind(const void* state_dev);
+int gdmcf_graph_state_tick(void* state_dev, void* stream);
 /* out = acc * scale */
 int gdmcf_scale_f32(const float* acc, int64_t n, float scale, float* out, void* stream);
 

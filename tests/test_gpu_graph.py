@@ -1,0 +1,76 @@
+"""The training step replayed from a hipGraph (gdmcf_amd/graph.py) against the eager step: same kernels, same Philox
+offsets, same AdamW scalars -> bit-identical losses, weights, moments and Lt-history."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import gdmcf_amd
+from gdmcf_amd.gaussian_diffusion import ModelMeanType
+
+DEV = torch.device("cuda:0")
+
+
+def _setup(gemm_dtype, seed=5):
+    import scipy.sparse as sp
+    from gdmcf_amd.data_utils import DeviceCSR
+    rng = np.random.default_rng(seed)
+    U, I, hid, T = 500, 6001, 96, 7
+    dense = (rng.random((U, I)) < 0.006).astype(np.float32)
+    dcsr = DeviceCSR(sp.csr_matrix(dense), DEV)
+    torch.manual_seed(21)
+    model = gdmcf_amd.DNN([I, hid], [hid, I], 10, gemm_dtype=gemm_dtype).to(DEV).train()
+    diff = gdmcf_amd.GaussianDiffusion(ModelMeanType.START_X, "linear-var", 0.1, 0.001, 0.01, T, DEV)
+    opt = gdmcf_amd.FusedAdamW(model.parameters(), lr=1e-3, weight_decay=0.01)
+    return dcsr, model, diff, opt
+
+
+def _state(model, diff, opt):
+    out = [p.detach().clone() for p in model.parameters()]
+    for p in model.parameters():
+        out += [opt.state[p]["exp_avg"].clone(), opt.state[p]["exp_avg_sq"].clone()]
+    return out + [diff.Lt_history.clone(), diff.Lt_count.clone()]
+
+
+@pytest.mark.parametrize("gemm_dtype,table_steps", [("f32", 8192), ("bf16", 8192), ("f32", 4)])
+def test_graph_replay_equals_eager_steps(gemm_dtype, table_steps):
+    from gdmcf_amd.graph import GraphedTrainStep
+    from gdmcf_amd.parallel import DataParallelStep
+    B, n_graph, n_after = 64, 14, 3
+    batches = [torch.from_numpy(np.random.default_rng(100 + k).permutation(500)[:B].astype(np.int64)) for k in range(n_graph + n_after)]
+
+    dcsr, model, diff, opt = _setup(gemm_dtype)
+    step = DataParallelStep(diff, model, opt)
+    eager_losses = [step(dcsr.batch(b.to(DEV)), True).clone() for b in batches]
+    eager = _state(model, diff, opt)
+
+    dcsr, model, diff, opt = _setup(gemm_dtype)
+    losses = []
+    with GraphedTrainStep(diff, model, opt, dcsr, B, warmup=3, table_steps=table_steps) as gstep:
+        for b in batches[:n_graph]:
+            losses.append(gstep(b))
+        assert gstep.graph is not None
+    # the counters came back: eager steps continue where the graph stopped
+    assert model.engine.offset == n_graph and diff._ts_calls == n_graph
+    assert {int(opt.state[p]["step"]) for p in model.parameters()} == {n_graph}
+    step = DataParallelStep(diff, model, opt)
+    for b in batches[n_graph:]:
+        losses.append(step(dcsr.batch(b.to(DEV)), True).clone())
+    for k, (a, b) in enumerate(zip(eager_losses, losses)):
+        assert torch.equal(a, b), (k, float(a), float(b))
+    for a, b in zip(eager, _state(model, diff, opt)):
+        assert torch.equal(a, b)
+
+
+def test_graph_step_rejects_what_it_cannot_capture():
+    from gdmcf_amd.graph import GraphedTrainStep
+    dcsr, model, diff, opt = _setup("f32")
+    with pytest.raises(ValueError):
+        with GraphedTrainStep(diff, model, opt, dcsr, 32) as g:
+            g(torch.arange(31))
+    eps = gdmcf_amd.GaussianDiffusion(ModelMeanType.EPSILON, "linear-var", 0.1, 0.001, 0.01, 5, DEV)
+    with pytest.raises(NotImplementedError):
+        GraphedTrainStep(eps, model, opt, dcsr, 32)
+    with pytest.raises(NotImplementedError):
+        GraphedTrainStep(diff, model, torch.optim.AdamW(model.parameters()), dcsr, 32)
