@@ -100,6 +100,7 @@ def parse():
                     help="single GPU: update the two large weights inside the weight-gradient GEMM epilogue "
                          "(FusedAdamW.fuse_into_backward); same update rule, gradient never materialised")
     ap.add_argument("--no-fused-leg", action="store_true", help="N = 1: skip the extra leg with AdamW fused into the dW epilogues")
+    ap.add_argument("--no-f32x3-leg", action="store_true", help="N = 1, fp32: skip the extra leg with gemm_dtype='f32x3'")
     ap.add_argument("--no-graph-leg", action="store_true", help="N = 1: skip the extra leg that replays the step from a hipGraph")
     ap.add_argument("--bpr", action="store_true", help="also time a LightGCN BPR training step (reported under 'bpr')")
     ap.add_argument("--backbone", default="dnn", choices=["dnn", "onehot", "onehot-emb", "onehot-gcn"],
@@ -469,6 +470,28 @@ def main():
         except Exception as exc:  # reported, never fatal for the main line
             graph_leg = dict(error=f"{type(exc).__name__}: {exc}"[:300])
 
+    # ---- N = 1, fp32: the same step with the dense products in "f32x3" mode (float32 operands split on chip into three
+    # bfloat16 terms, six bf16 MFMAs per block, f32 accumulate: f32-level error -- tests/test_gpu_split.py measures it against
+    # float64 beside the native f32 MFMA kernels).  Reported beside the main line, which stays on v_mfma_f32_16x16x4_f32. ----
+    x3_leg = None
+    if world == 1 and args.backbone == "dnn" and args.gemm_dtype == "f32" and not args.fuse_optimizer and not args.rehearse_dp \
+            and not args.no_f32x3_leg:
+        model.gemm_dtype = "f32x3"
+        try:
+            for i in range(max(3, args.warmup // 4)):
+                step(rows_of(i % n_pool), True)
+            sync()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                loss_x = step(rows_of(i % n_pool), True)
+            sync()
+            ex = time.perf_counter() - t1
+            x3_leg = dict(ms_per_step=round(1e3 * ex / args.steps, 4), users_per_s=round(B * args.steps / ex, 1), steps=args.steps,
+                          final_loss=float(loss_x), what="dense products as three-term bf16 splits on the bf16 matrix pipe "
+                          "(DNN(gemm_dtype='f32x3'), gemm_split.hip); f32-level error, opt-in")
+        finally:
+            model.gemm_dtype = "f32"
+
     # ---- roofline of the dominant kernel (rank 0's events) ----
     roofline, klist = None, []
     for tag, d in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"]):
@@ -545,7 +568,7 @@ def main():
                        "batch_rows": "device CSR rows (CsrBatch)" if sparse_rows else "dense rows densified from the device CSR"},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": klist, "final_loss": final_loss,
             "host_enqueue_ms_per_step": round(1e3 * host_el / args.steps, 4),
-            "replicas_in_sync": in_sync, "dp_autotune": dp_autotune, "strong_scaling": strong_leg, "fused_optimizer_leg": fused_leg, "graph_leg": graph_leg,
+            "replicas_in_sync": in_sync, "dp_autotune": dp_autotune, "strong_scaling": strong_leg, "fused_optimizer_leg": fused_leg, "graph_leg": graph_leg, "f32x3_leg": x3_leg,
             "ranks_in_group": dist.get_world_size() if dist.is_initialized() else 1,
             "optimizer": "FusedAdamW" + (" fused into the dW GEMM epilogues" if (args.fuse_optimizer and world == 1) else
                                          " (row-sharded over the ranks: reduce-scatter, AdamW on 1/N rows, deferred all-gather)"

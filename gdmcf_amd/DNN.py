@@ -53,7 +53,7 @@ class DNN(nn.Module):
 
     def __init__(self, in_dims, out_dims, emb_size, time_type="cat", norm=False, dropout=0.5, gemm_dtype="f32"):
         super().__init__()
-        if gemm_dtype not in ("f32", "bf16"):
+        if gemm_dtype not in ("f32", "bf16", "f32x3"):
             raise ValueError("Unimplemented GEMM input precision %s" % gemm_dtype)
         self.gemm_dtype = gemm_dtype
         self.in_dims = list(in_dims)

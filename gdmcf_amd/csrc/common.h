@@ -145,13 +145,16 @@ struct GdGemm {
     int64_t ldb16;
     void* C16;
     int64_t ldc16;
+    int dbg;   // timing ablations of gemm_split.hip (GDMCF_SPLIT_DBG; 0 in production)
     int bf16;  // 1: operands rounded to bfloat16 on the way to LDS, bf16 MFMA, f32 accumulate (gemm_bf16.hip)
+               // 2: operands split into three bfloat16 terms, six bf16 MFMAs per product block (gemm_split.hip)
 };
 
 // shape classes: 0 = "batch-M" (BM=80, BN=128), 1 = square 128x128, 2 = small 64x64,
 //                3 = bf16 only: 208x256 on 8 waves (batch-sized M, see gemm_bf16.hip)
 int gd_gemm_launch(int layA, int layB, int epi, int shape_class, GdGemm& g, hipStream_t s);
 int gd_gemm_bf16_launch(int layA, int layB, int epi, int shape_class, GdGemm& g, hipStream_t s);  // g.bf16 != 0
+int gd_gemm_split_launch(int layA, int layB, int epi, int shape_class, GdGemm& g, hipStream_t s);  // g.bf16 == 2 (gemm_split.hip)
 int gd_gemm_small_launch(int layA, int layB, int epi, GdGemm& g, hipStream_t s);  // degenerate shapes (gemm_small.hip)
 int gd_gemm_tile_m(int shape_class);
 int gd_gemm_tile_n(int shape_class);

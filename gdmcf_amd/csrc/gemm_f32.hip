@@ -703,6 +703,7 @@ int launch_class(int cls, GdGemm& g, hipStream_t s) {
 
 }  // namespace
 
+// (class 3: bf16 only; class 4 = 208x128: three-term split only -- gemm_split.hip)
 int gd_gemm_tile_m(int cls) { return cls == 0 ? 80 : (cls == 1 ? 128 : (cls == 2 ? 64 : 208)); }
 int gd_gemm_tile_n(int cls) { return cls == 2 ? 64 : (cls == 3 ? 256 : 128); }
 int gd_gemm_bk(int layA, int layB) { return (layA == GD_LAY_MC && layB == GD_LAY_MC) ? 16 : 32; }
@@ -716,6 +717,7 @@ int gd_pick_shape_class(int M, int N) {
 }
 
 int gd_gemm_launch(int layA, int layB, int epi, int cls, GdGemm& g, hipStream_t s) {
+    if (g.bf16 == 2) return gd_gemm_split_launch(layA, layB, epi, cls, g, s);
     if (g.bf16) return gd_gemm_bf16_launch(layA, layB, epi, cls, g, s);
     // the branch-free edge loader clamps 16-byte vectors onto valid elements: it needs >= 4 elements along the
     // contiguous axis of every operand (K for K-contiguous operands, rows for row-contiguous ones); anything smaller

@@ -30,6 +30,12 @@ int pick_class(int M, int N, bool fused, int prec) {
         const long rounds = (tiles + 255) / 256;
         if (pad * 10 <= (long)M * 11 && pad / 208 <= 2 && (!fused || tiles * 100 >= rounds * 256 * 85)) return 3;
     }
+    // three-term split: 2.67x the matrix-pipe rate needs ~40 FLOP per operand byte from L2 -- batch-sized M takes 208-row
+    // tiles (208x128: 39.6 FLOP/B against 24.6 at 80x128), one 129 KB-LDS workgroup per CU
+    if (prec == GDMCF_GEMM_F32X3 && M > 128 && N >= 128) {
+        const long pad = (long)gd_cdiv(M, 208) * 208;
+        if (pad * 10 <= (long)M * 11) return 4;
+    }
     return gd_pick_shape_class(M, N);
 }
 
@@ -50,14 +56,14 @@ int pick_class_dw(int M, int N, int prec) {
 // result written by a fused epilogue (BIAS_ACT without split-K, LOSS): keep its bf16 shadow in sync
 void attach_result_shadow(GdGemm& g) {
     GdShadow c;
-    if (g.bf16 && gd_shadow_lookup(g.C, &c) && c.rows == g.M && c.cols >= g.N) {  // x_next lands in a wider xin buffer
+    if (g.bf16 == 1 && gd_shadow_lookup(g.C, &c) && c.rows == g.M && c.cols >= g.N) {  // x_next lands in a wider xin buffer
         g.C16 = c.p16;
         g.ldc16 = c.ld16;
     }
 }
 
 void attach_shadows(GdGemm& g, int layA, int layB) {
-    if (!g.bf16) return;
+    if (g.bf16 != 1) return;
     GdShadow a, b;
     if (!gd_shadow_lookup(g.A, &a) || !gd_shadow_lookup(g.B, &b)) return;
     const bool okA = layA == GD_LAY_KC ? (a.rows == g.M && a.cols == g.K) : (a.rows == g.K && a.cols == g.M);
@@ -71,7 +77,7 @@ void attach_shadows(GdGemm& g, int layA, int layB) {
 int pick_splits(int M, int N, int K, int cls, int prec) {
     const int bk = prec == GDMCF_GEMM_BF16 ? 64 : 32;
     const int tiles = gd_cdiv(M, gd_gemm_tile_m(cls)) * gd_cdiv(N, gd_gemm_tile_n(cls));
-    int s = (cls == 3 ? 256 : TARGET_WGS) / tiles;
+    int s = (cls >= 3 ? 256 : TARGET_WGS) / tiles;  // classes 3 and 4: one workgroup per CU
     const int max_by_k = K / (8 * bk);  // keep >= 8 K-tiles per split
     if (s > max_by_k) s = max_by_k;
     if (s < 1) s = 1;
@@ -88,7 +94,7 @@ extern "C" {
 
 int gdmcf_gemm_precision(int mode) {
     const int prev = t_gemm_prec;
-    if (mode == GDMCF_GEMM_F32 || mode == GDMCF_GEMM_BF16) t_gemm_prec = mode;
+    if (mode == GDMCF_GEMM_F32 || mode == GDMCF_GEMM_BF16 || mode == GDMCF_GEMM_F32X3) t_gemm_prec = mode;
     return prev;
 }
 
@@ -96,7 +102,7 @@ size_t gdmcf_linear_ws_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     // forward: slabs [splits][M][round4(N)];  backward-input: slabs [splits][M][round4(K)]
     size_t need = 0;
-    for (int prec = GDMCF_GEMM_F32; prec <= GDMCF_GEMM_BF16; ++prec) {  // the caller may switch precision later
+    for (int prec = GDMCF_GEMM_F32; prec <= GDMCF_GEMM_F32X3; ++prec) {  // the caller may switch precision later
         const int cf = pick_class(M, N, false, prec), cb = pick_class(M, K, false, prec);
         const size_t f = (size_t)pick_splits(M, N, K, cf, prec) * M * round4(N);
         const size_t b = (size_t)pick_splits(M, K, N, cb, prec) * M * round4(K);
@@ -116,7 +122,7 @@ int gdmcf_linear_fwd_f32(const float* A, int64_t lda, const float* W, int64_t ld
     const int cls = pick_class(M, N, false, t_gemm_prec);
     const int splits = pick_splits(M, N, K, cls, t_gemm_prec);
     GdGemm g = {};
-    g.bf16 = (t_gemm_prec == GDMCF_GEMM_BF16);
+    g.bf16 = t_gemm_prec;  // 0 f32, 1 bf16, 2 three-term split
     g.A = A; g.lda = lda; g.B = W; g.ldb = ldw; g.M = M; g.N = N; g.K = K;
     g.m_fastest = gd_cdiv(M, gd_gemm_tile_m(cls)) <= gd_cdiv(N, gd_gemm_tile_n(cls));
     g.bias = bias; g.act = act; g.prof_tag = 1;
@@ -149,7 +155,7 @@ int gdmcf_linear_loss_fwd_f32(const float* A, int64_t lda, const float* W, int64
     hipStream_t s = (hipStream_t)stream;
     const int cls = pick_class(M, N, true, t_gemm_prec);
     GdGemm g = {};
-    g.bf16 = (t_gemm_prec == GDMCF_GEMM_BF16);
+    g.bf16 = t_gemm_prec;  // 0 f32, 1 bf16, 2 three-term split
     g.A = A; g.lda = lda; g.B = W; g.ldb = ldw; g.M = M; g.N = N; g.K = K; g.splits = 1;
     g.m_fastest = gd_cdiv(M, gd_gemm_tile_m(cls)) <= gd_cdiv(N, gd_gemm_tile_n(cls));
     g.bias = bias; g.aux = target; g.ldaux = ldt; g.r0 = alpha; g.out2 = out; g.ldout2 = ldo;
@@ -172,7 +178,7 @@ int gdmcf_linear_loss_fwd_bits_f32(const float* A, int64_t lda, const float* W, 
     hipStream_t s = (hipStream_t)stream;
     const int cls = pick_class(M, N, true, t_gemm_prec);
     GdGemm g = {};
-    g.bf16 = (t_gemm_prec == GDMCF_GEMM_BF16);
+    g.bf16 = t_gemm_prec;  // 0 f32, 1 bf16, 2 three-term split
     g.A = A; g.lda = lda; g.B = W; g.ldb = ldw; g.M = M; g.N = N; g.K = K; g.splits = 1;
     g.m_fastest = gd_cdiv(M, gd_gemm_tile_m(cls)) <= gd_cdiv(N, gd_gemm_tile_n(cls));
     g.bias = bias; g.aux = nullptr; g.ldaux = 0; g.aux_bits = target_bits; g.ldbits = ldbits; g.r0 = alpha; g.out2 = out;
@@ -196,7 +202,7 @@ int gdmcf_linear_posterior_fwd_f32(const float* A, int64_t lda, const float* W, 
     hipStream_t s = (hipStream_t)stream;
     const int cls = pick_class(M, N, true, t_gemm_prec);
     GdGemm g = {};
-    g.bf16 = (t_gemm_prec == GDMCF_GEMM_BF16);
+    g.bf16 = t_gemm_prec;  // 0 f32, 1 bf16, 2 three-term split
     g.A = A; g.lda = lda; g.B = W; g.ldb = ldw; g.M = M; g.N = N; g.K = K; g.splits = 1;
     g.m_fastest = gd_cdiv(M, gd_gemm_tile_m(cls)) <= gd_cdiv(N, gd_gemm_tile_n(cls));
     g.bias = bias; g.aux = x_t; g.ldaux = ldxt; g.aux2 = z; g.ldaux2 = ldz;
@@ -223,7 +229,7 @@ int gdmcf_linear_bwd_input_f32(const float* dZ, int64_t lddz, const float* W, in
         return GDMCF_E_WORKSPACE;
     }
     GdGemm g = {};
-    g.bf16 = (t_gemm_prec == GDMCF_GEMM_BF16);
+    g.bf16 = t_gemm_prec;  // 0 f32, 1 bf16, 2 three-term split
     g.A = dZ; g.lda = lddz; g.B = W; g.ldb = ldw; g.M = M; g.N = K; g.K = N;
     g.m_fastest = gd_cdiv(M, gd_gemm_tile_m(cls)) <= gd_cdiv(K, gd_gemm_tile_n(cls));
     g.splits = splits; g.C = (float*)ws; g.ldc = lds_; g.slab_stride = (int64_t)M * lds_; g.prof_tag = 4;
@@ -243,7 +249,7 @@ int gdmcf_linear_bwd_weight_f32(const float* dZ, int64_t lddz, const float* A, i
     // dW[N x K_in] = dZ[M x N]^T * A[M x K_in]  -> gemm (N, K, reduction M), both operands row-contiguous
     const int cls = pick_class_dw(N, K, t_gemm_prec);
     GdGemm g = {};
-    g.bf16 = (t_gemm_prec == GDMCF_GEMM_BF16);
+    g.bf16 = t_gemm_prec;  // 0 f32, 1 bf16, 2 three-term split
     g.A = dZ; g.lda = lddz; g.B = A; g.ldb = lda; g.M = N; g.N = K; g.K = M; g.splits = 1;
     g.m_fastest = gd_cdiv(N, gd_gemm_tile_m(cls)) <= gd_cdiv(K, gd_gemm_tile_n(cls));
     g.C = dW; g.ldc = lddw; g.accumulate = accumulate; g.prof_tag = 5;
@@ -263,7 +269,7 @@ int gdmcf_linear_bwd_weight_adamw_f32(const float* dZ, int64_t lddz, const float
     hipStream_t s = (hipStream_t)stream;
     const int cls = pick_class_dw(N, K, t_gemm_prec);
     GdGemm g = {};
-    g.bf16 = (t_gemm_prec == GDMCF_GEMM_BF16);
+    g.bf16 = t_gemm_prec;  // 0 f32, 1 bf16, 2 three-term split
     g.A = dZ; g.lda = lddz; g.B = A; g.ldb = lda; g.M = N; g.N = K; g.K = M; g.splits = 1;
     g.m_fastest = gd_cdiv(N, gd_gemm_tile_m(cls)) <= gd_cdiv(K, gd_gemm_tile_n(cls));
     g.C = W; g.ldc = ldw; g.aux = exp_avg; g.aux2 = exp_avg_sq; g.prof_tag = 5;

@@ -28,7 +28,7 @@ class _Bufs:
     pass
 
 
-_GEMM_MODES = {"f32": 0, "bf16": 1}  # include/gdmcf_hip.h GDMCF_GEMM_F32 / GDMCF_GEMM_BF16
+_GEMM_MODES = {"f32": 0, "bf16": 1, "f32x3": 2}  # include/gdmcf_hip.h GDMCF_GEMM_F32 / _BF16 / _F32X3
 
 
 def _with_precision(fn):
@@ -109,7 +109,8 @@ class DenoiserEngine:
 
     @property
     def gemm_dtype(self):
-        """"f32": exact-f32 MFMA products (parity path);  "bf16": operands rounded to bf16 on chip, f32 accumulate."""
+        """"f32": exact-f32 MFMA products (parity path);  "bf16": operands rounded to bf16 on chip, f32 accumulate;
+        "f32x3": float32 products from six bf16 MFMAs of three-term operand splits (f32-level error, gemm_split.hip)."""
         return getattr(self.model, "gemm_dtype", "f32")
 
     def manual_seed(self, seed):

@@ -68,7 +68,7 @@ class OneHotEngine:
 
     def _precision(self):
         """GDMCF_GEMM_F32 (0) or GDMCF_GEMM_BF16 (1: operands rounded to bf16 on their way to LDS -- no shadows here)."""
-        return 1 if getattr(self.model, "gemm_dtype", "f32") == "bf16" else 0
+        return {"f32": 0, "bf16": 1, "f32x3": 2}[getattr(self.model, "gemm_dtype", "f32")]
 
     # -- layers -------------------------------------------------------------------------------------------------------
     def _chains(self):
@@ -425,7 +425,7 @@ class DNNOneHot(nn.Module):
 
     def __init__(self, in_dims, out_dims, emb_size, time_type="cat", norm=False, dropout=0.5, gemm_dtype="f32"):
         super().__init__()
-        if gemm_dtype not in ("f32", "bf16"):
+        if gemm_dtype not in ("f32", "bf16", "f32x3"):
             raise ValueError("Unimplemented GEMM input precision %s" % gemm_dtype)
         self.gemm_dtype = gemm_dtype  # "bf16": dense products on the bf16 matrix pipe, f32 accumulate / state (§4.4)
         self.in_dims = in_dims

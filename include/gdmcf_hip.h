@@ -149,8 +149,12 @@ int gdmcf_dnn_emb_cols_f32(const int64_t* ts, const float* emb_w, const float* e
  * outside the enum only queries).  GDMCF_GEMM_BF16: both operands of each product are rounded to bfloat16
  * (nearest-even) on chip and multiplied on the bf16 matrix pipe with float32 accumulation; all tensors in HBM
  * (weights, activations, gradients, optimiser state) stay float32.  Replaces what the reference would obtain
- * with torch.autocast(dtype=torch.bfloat16) around models/DNN.py:79-86 -- the reference itself runs fp32.    */
-enum { GDMCF_GEMM_F32 = 0, GDMCF_GEMM_BF16 = 1 };
+ * with torch.autocast(dtype=torch.bfloat16) around models/DNN.py:79-86 -- the reference itself runs fp32.
+ * GDMCF_GEMM_F32X3: float32 products on the bf16 matrix pipe -- every operand is split on chip into three bfloat16
+ * terms (a = a0 + a1 + a2, exact to 2^-26 |a|) and each product is assembled from the six partial products above
+ * 2^-25 |a b| with float32 accumulation: float32-level error (no operand is rounded), 2.67x the matrix-pipe rate of
+ * v_mfma_f32_16x16x4_f32; non-finite inputs give NaN.  No shadows, nothing extra in HBM.                     */
+enum { GDMCF_GEMM_F32 = 0, GDMCF_GEMM_BF16 = 1, GDMCF_GEMM_F32X3 = 2 };
 int gdmcf_gemm_precision(int mode);
 /* bf16 shadows (GDMCF_GEMM_BF16 only): a shadow is a bfloat16 copy of a float32 matrix that the library may
  * stream INSTEAD of the float32 matrix when that matrix is an operand of a dense product (half the bytes, no

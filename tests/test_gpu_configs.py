@@ -42,10 +42,11 @@ def _pair(I, dims, T, gemm_dtype="f32", seed=0):
     return om.train(), model.to(DEV).train(), od, gd
 
 
-@pytest.mark.parametrize("gemm_dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("gemm_dtype", ["f32", "bf16", "f32x3"])
 def test_amazon_book_shape_step_matches_oracle(gemm_dtype):
     """BASELINE configs[2]: Amazon-Book shape, one full train step (B=400, I=94 949, dims=[1000], T=5) against the f32
-    oracle, in the parity precision and with bf16 GEMM inputs (reference main.py:345-351, gaussian_diffusion.py:276-371)."""
+    oracle, in the parity precision and with bf16 GEMM inputs (reference main.py:345-351, gaussian_diffusion.py:276-371).
+    "f32x3" (float32 products from three-term bf16 splits, gemm_split.hip) is held to the f32 tolerances."""
     B, I, hid, T = 400, 94949, 1000, 5
     om, model, od, gd = _pair(I, [hid], T, gemm_dtype)
     x, ts, noise, keep = _inputs(B, I, T, 0.00025)
@@ -58,7 +59,7 @@ def test_amazon_book_shape_step_matches_oracle(gemm_dtype):
     gl = terms["loss"].mean()
     gl.backward()
     rel = abs(float(gl) - float(oloss)) / abs(float(oloss))
-    f32 = gemm_dtype == "f32"
+    f32 = gemm_dtype != "bf16"
     assert rel <= (1e-4 if f32 else 1.5e-4), (gemm_dtype, rel)
     np.testing.assert_allclose(terms["loss"].detach().cpu().numpy(), ovec.numpy(), rtol=1e-4 if f32 else 1.5e-3)
     for (k, p), (_, q) in zip(model.named_parameters(), om.named_parameters()):

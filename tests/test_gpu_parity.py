@@ -1166,17 +1166,19 @@ def test_lightgcn_bpr_step_gradients_match_oracle():
     assert np.mean(losses[-5:]) < np.mean(losses[:5])
 
 
-@pytest.mark.parametrize("prec", ["f32", "bf16", "bf16-shadows"])
+@pytest.mark.parametrize("prec", ["f32", "bf16", "bf16-shadows", "f32x3"])
 def test_linear_entry_points_random_shapes(prec):
     """Adversarial shapes for the branch-free edge loaders (clamped addresses, in-register shifts, K tails,
     odd leading dimensions, split-K on/off): every dense entry point of the C ABI vs float64 matmul.
     bf16 mode (gdmcf_gemm_precision): the same, against float64 matmul of the bfloat16-rounded operands --
-    bf16 x bf16 products are exact in f32, so the only difference left is f32 accumulation order."""
+    bf16 x bf16 products are exact in f32, so the only difference left is f32 accumulation order.
+    f32x3 mode (three-term bf16 split of both operands, six bf16 MFMAs per block: gemm_split.hip): held to the SAME
+    reference and tolerance as the native f32 kernels -- no operand is rounded."""
     from gdmcf_amd import _lib
     lib = _lib.load()
-    prev = lib.gdmcf_gemm_precision(0 if prec == "f32" else 1)
+    prev = lib.gdmcf_gemm_precision({"f32": 0, "bf16": 1, "bf16-shadows": 1, "f32x3": 2}[prec])
     try:
-        _linear_entry_points_random_shapes(lib, "bf16" if prec != "f32" else "f32", shadows=(prec == "bf16-shadows"))
+        _linear_entry_points_random_shapes(lib, "bf16" if prec.startswith("bf16") else "f32", shadows=(prec == "bf16-shadows"))
     finally:
         lib.gdmcf_gemm_precision(prev)
         lib.gdmcf_bf16_shadow_clear(None)
