@@ -214,6 +214,16 @@ struct Stage16<GD_LAY_KC, R, NT> {
         for (int i = 0; i < NL; ++i) {
             const int u = tid + i * NT;
             const int row = min(row0 + min(u >> 3, R - 1), rows_total - 1);
+            reg[i] = *reinterpret_cast<const u32x4*>(src + (int64_t)row * ld + k0 + ((u & 7) << 3));
+        }
+    }
+    // the same loads as inline asm (uncounted by hipcc): the two-stage ring of the K-contiguous x K-contiguous products
+    __device__ __forceinline__ void load_asm(const unsigned short* __restrict__ src, int64_t ld, int row0, int rows_total,
+                                             int k0, int tid) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int u = tid + i * NT;
+            const int row = min(row0 + min(u >> 3, R - 1), rows_total - 1);
             reg[i] = gload16_u(src + (int64_t)row * ld + k0 + ((u & 7) << 3));
         }
     }
@@ -246,15 +256,8 @@ struct Stage16<GD_LAY_MC, R, NT> {
             const int col = min(row0 + (rg << 3), (int)ld - 8);  // groups beyond the matrix read padding of this row
             const unsigned short* p = src + (int64_t)(k0 + (kg << 3)) * ld + col;
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) reg[i][kk] = gload16_u(p + (int64_t)kk * ld);
+            for (int kk = 0; kk < 8; ++kk) reg[i][kk] = *reinterpret_cast<const u32x4*>(p + (int64_t)kk * ld);
         }
-    }
-    static constexpr int LOADS = NL * 8;
-    __device__ __forceinline__ void pin() {
-#pragma unroll
-        for (int i = 0; i < NL; ++i)
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk) asm volatile("" : "+v"(reg[i][kk]));
     }
     // 8x8 transpose of 16-bit values: image row (rg*8 + mm) slot kg holds k = kg*8 .. kg*8+7 of source row mm
     __device__ __forceinline__ void store(char* img, int tid) const {
@@ -343,11 +346,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(const
         char* const L0 = lds;
         char* const L1 = lds + STAGE_BYTES;
         if (nt > 0) {
-            sa0.load(A16, g.lda16, m0, g.M, kbeg, tid);
-            sb0.load(B16, g.ldb16, n0, g.N, kbeg, tid);
+            sa0.load_asm(A16, g.lda16, m0, g.M, kbeg, tid);
+            sb0.load_asm(B16, g.ldb16, n0, g.N, kbeg, tid);
             if (nt > 1) {
-                sa1.load(A16, g.lda16, m0, g.M, kbeg + BK, tid);
-                sb1.load(B16, g.ldb16, n0, g.N, kbeg + BK, tid);
+                sa1.load_asm(A16, g.lda16, m0, g.M, kbeg + BK, tid);
+                sb1.load_asm(B16, g.ldb16, n0, g.N, kbeg + BK, tid);
                 GD_WAIT_VM(LPT);
             } else {
                 GD_WAIT_VM(0);
@@ -362,8 +365,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(const
             // even tile `it` in L0; stage-1 registers hold tile it+1 (in flight); stage-0 registers are free
             const bool ld2 = it + 2 < nt;
             if (ld2) {
-                sa0.load(A16, g.lda16, m0, g.M, kbeg + (it + 2) * BK, tid);
-                sb0.load(B16, g.ldb16, n0, g.N, kbeg + (it + 2) * BK, tid);
+                sa0.load_asm(A16, g.lda16, m0, g.M, kbeg + (it + 2) * BK, tid);
+                sb0.load_asm(B16, g.ldb16, n0, g.N, kbeg + (it + 2) * BK, tid);
             }
             compute(L0);
             if (it + 1 < nt) {
@@ -377,8 +380,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(const
             if (it + 1 < nt) {
                 const bool ld3 = it + 3 < nt;
                 if (ld3) {
-                    sa1.load(A16, g.lda16, m0, g.M, kbeg + (it + 3) * BK, tid);
-                    sb1.load(B16, g.ldb16, n0, g.N, kbeg + (it + 3) * BK, tid);
+                    sa1.load_asm(A16, g.lda16, m0, g.M, kbeg + (it + 3) * BK, tid);
+                    sb1.load_asm(B16, g.ldb16, n0, g.N, kbeg + (it + 3) * BK, tid);
                 }
                 compute(L1);
                 if (ld2) {
@@ -407,9 +410,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(const
         };
         auto store_tile = [&](char* img, int k0) {
             if constexpr (S16) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the shadow loads are asm: hipcc does not wait for them
-                sa.pin();
-                sb.pin();
                 sa.store(img, tid);
                 sb.store(img + A_BYTES, tid);
             } else {

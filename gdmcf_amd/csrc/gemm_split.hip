@@ -449,6 +449,7 @@ __global__ __launch_bounds__(512, 2) void gemm_split_spec_kernel(const GdGemm g)
     const int kend = min(g.K, kbeg + g.kchunk);
     const int nt = (kend - kbeg + BK - 1) / BK;
 
+    if (g.dbg & (loader ? 32 : 16)) __builtin_amdgcn_s_setprio(1);  // ablation: issue priority for one of the two roles
     if (loader) {
         using Slot = RingSlot<LAYA, LAYB, BM, BN, NT>;
         Slot ring[NSTG];

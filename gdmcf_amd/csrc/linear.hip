@@ -43,6 +43,8 @@ int pick_class(int M, int N, bool fused, int prec) {
 // both dimensions are large and the last round of workgroups is mostly full (measured 0.397 -> 0.374 ms on the
 // Amazon-Book shape; the kernel is bound by getting the f32 operands through L1, not by MFMA).
 int pick_class_dw(int M, int N, int prec) {
+    static const int forced = getenv("GDMCF_BF16_DW_CLASS") ? atoi(getenv("GDMCF_BF16_DW_CLASS")) : -1;  // tuning knob
+    if (prec == GDMCF_GEMM_BF16 && forced >= 0) return forced;
     if (prec == GDMCF_GEMM_BF16 && M >= 416 && N >= 512) {
         const long tiles = (long)gd_cdiv(M, 208) * gd_cdiv(N, 256);
         const long rounds = (tiles + 255) / 256;
