@@ -2,6 +2,8 @@
 
     python examples/train_synthetic.py --users 8000 --epochs 3            # fp32
     python examples/train_synthetic.py --users 8000 --epochs 3 --bf16     # bf16 GEMM inputs
+    python examples/train_synthetic.py --users 8000 --epochs 3 --graph    # CSR rows, one hipGraph launch per batch
+    python examples/train_synthetic.py --users 8000 --epochs 3 --gemm f32x3   # f32 products from three-term bf16 splits
     python examples/train_synthetic.py --users 8000 --epochs 3 --backbone onehot   # one-hot variant (DNNOneHot)
     python examples/train_synthetic.py --users 4000 --epochs 2 --backbone onehot-emb --hidden 256 --lightgcn-init 50
                                                                                    # LightGCN BPR -> tables handed to the denoiser
@@ -36,6 +38,10 @@ def main():
     ap.add_argument("--T", type=int, default=5)
     ap.add_argument("--lr", type=float, default=1e-4)
     ap.add_argument("--bf16", action="store_true")
+    ap.add_argument("--gemm", default=None, choices=["f32", "bf16", "f32x3"],
+                    help="GEMM mode of the DNN denoiser (f32x3: float32 products from three-term bf16 splits, DESIGN 4.4b)")
+    ap.add_argument("--sparse-rows", action="store_true", help="feed the training rows as CSR batches (never densified)")
+    ap.add_argument("--graph", action="store_true", help="replay the training step from one hipGraph (single GPU, dnn backbone)")
     ap.add_argument("--backbone", default="dnn", choices=["dnn", "onehot", "onehot-emb", "onehot-gcn"],
                     help="onehot: GaussianDiffusionDiscrete(CatOneHot=True) + DNNOneHot; onehot-emb: + user / item embedding "
                          "tables (DNNOneHotEmbedding, indexIn); both fp32")
@@ -75,7 +81,7 @@ def main():
         diffusion.indexIn = args.backbone != "onehot"  # main.py:241, :245
     else:
         model = gdmcf_amd.DNN([I, args.hidden], [args.hidden, I], 10, time_type="cat", norm=False,
-                              gemm_dtype="bf16" if args.bf16 else "f32").to(dev)
+                              gemm_dtype=args.gemm or ("bf16" if args.bf16 else "f32")).to(dev)
         diffusion = gdmcf_amd.GaussianDiffusion(gdmcf_amd.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, args.T, dev)
     if args.lightgcn_init > 0 and args.backbone in ("onehot-emb", "onehot-gcn"):
         # "fed by the LightGCN propagation" (north star): BPR-train the graph model on the same interactions, then
@@ -105,13 +111,22 @@ def main():
     gen = torch.Generator().manual_seed(0)
     from gdmcf_amd.parallel import DataParallelStep
     step = DataParallelStep(diffusion, model, opt)  # broadcasts rank 0's weights when world > 1
+    gstep = None
+    if args.graph:
+        from gdmcf_amd.data_utils import DeviceCSR
+        from gdmcf_amd.graph import GraphedTrainStep
+        my_train = DeviceCSR(my_train, dev)
+        gstep = GraphedTrainStep(diffusion, model, opt, my_train, args.batch)
     topN = [10, 20, 50, 100]
     for epoch in range(args.epochs):
         t0 = time.perf_counter()
-        total, count = driver.train_one_epoch(diffusion, model, opt, my_train, args.batch, dev, generator=gen, step=step)
+        total, count = driver.train_one_epoch(diffusion, model, opt, my_train, args.batch, dev, generator=gen, step=step,
+                                              sparse=args.sparse_rows, graph_step=gstep)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         say(f"epoch {epoch}: mean loss {total / max(count, 1):.4f}, {world * count * args.batch / dt:,.0f} users/s", flush=True)
+    if gstep is not None:
+        gstep.close()
     if rank == 0:
         t0 = time.perf_counter()
         res = driver.evaluate(diffusion, model, train, test, train, topN, 0, False, args.batch, dev)

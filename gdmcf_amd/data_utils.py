@@ -100,9 +100,13 @@ class DeviceBatchLoader:
     """Iterates (dense_batch_on_device, index) like DataLoader(DataDiffusion(dense), batch_size, shuffle,
     drop_last) does in the reference (main.py:153-156), without host densification or PCIe traffic."""
 
-    def __init__(self, csr, batch_size, shuffle=False, drop_last=False, device="cuda", generator=None, n_users=None):
+    def __init__(self, csr, batch_size, shuffle=False, drop_last=False, device="cuda", generator=None, n_users=None,
+                 sparse=False, ids_only=False):
+        """sparse=True yields the rows as `CsrBatch` (never densified: `training_losses` takes them as they are);
+        ids_only=True yields (None, index) for a consumer that gathers the rows itself (graph.GraphedTrainStep)."""
         self.csr = csr if isinstance(csr, DeviceCSR) else DeviceCSR(csr, device)
         self.batch_size, self.shuffle, self.drop_last, self.generator = batch_size, shuffle, drop_last, generator
+        self.sparse, self.ids_only = sparse, ids_only
         self.n = self.csr.shape[0] if n_users is None else min(n_users, self.csr.shape[0])
 
     def __len__(self):
@@ -114,4 +118,7 @@ class DeviceBatchLoader:
             idx = order[lo:lo + self.batch_size]
             if self.drop_last and idx.numel() < self.batch_size:
                 return
-            yield self.csr.rows(idx), idx
+            if self.ids_only:
+                yield None, idx
+            else:
+                yield (self.csr.batch(idx) if self.sparse else self.csr.rows(idx)), idx

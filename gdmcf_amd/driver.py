@@ -24,17 +24,22 @@ def dense_rows(csr, rows, device):
 
 
 def train_one_epoch(diffusion, model, optimizer, train_csr, batch_size, device, reweight=True, shuffle=True,
-                    drop_last=True, generator=None, step=None):
+                    drop_last=True, generator=None, step=None, sparse=False, graph_step=None):
     """One pass over the users of `train_csr`.  Returns (sum of batch losses, number of batches), the two
-    numbers the reference prints per epoch (main.py:377)."""
+    numbers the reference prints per epoch (main.py:377).  sparse=True hands `training_losses` the rows as a CsrBatch
+    (bit-identical, no densify launch); graph_step = a graph.GraphedTrainStep over the same matrix replays the whole
+    step from one hipGraph per batch (drop_last is then forced: the captured batch size is fixed)."""
     model.train()
-    loader = DeviceBatchLoader(train_csr, batch_size, shuffle=shuffle, drop_last=drop_last, device=device,
-                               generator=generator)
-    step = step or DataParallelStep(diffusion, model, optimizer)
+    loader = DeviceBatchLoader(train_csr, batch_size, shuffle=shuffle, drop_last=drop_last or graph_step is not None,
+                               device=device, generator=generator, sparse=sparse, ids_only=graph_step is not None)
+    step = step or (None if graph_step is not None else DataParallelStep(diffusion, model, optimizer))
     total, count = None, 0
     with_index = bool(getattr(diffusion, "indexIn", False))  # embedding backbones need the users' ids (main.py:346)
     for batch, index in loader:
-        loss = step(batch, reweight, index=index) if with_index else step(batch, reweight)
+        if graph_step is not None:
+            loss = graph_step(index)
+        else:
+            loss = step(batch, reweight, index=index) if with_index else step(batch, reweight)
         total = loss if total is None else total + loss
         count += 1
     return (float(total) if total is not None else 0.0), count
