@@ -1087,6 +1087,45 @@ def test_device_batch_loader_matches_dense_rows():
         np.testing.assert_array_equal(batch.cpu().numpy(), np.asarray(big[idx.numpy()].todense(), dtype=np.float32))
         seen.extend(idx.tolist())
     assert len(set(seen)) == 256
+    # the same batches as CSR rows (never densified) and as bare row ids (for graph.GraphedTrainStep)
+    mk = lambda **kw: data_utils.DeviceBatchLoader(big, 64, shuffle=True, drop_last=True, device=DEV,
+                                                   generator=torch.Generator().manual_seed(0), **kw)
+    for (dense, i0), (sparse, i1), (none, i2) in zip(mk(), mk(sparse=True), mk(ids_only=True)):
+        assert torch.equal(i0, i1) and torch.equal(i0, i2) and none is None
+        assert isinstance(sparse, data_utils.CsrBatch) and torch.equal(sparse.dense(), dense)
+
+
+def test_driver_epoch_is_the_same_dense_sparse_and_graphed():
+    """driver.train_one_epoch with dense rows, with CSR rows (sparse=True) and with the step replayed from a hipGraph
+    (graph_step=): same epoch loss and the same weights bit for bit (what examples/train_synthetic.py --sparse-rows /
+    --graph run)."""
+    import scipy.sparse as sp
+    from gdmcf_amd import data_utils, driver
+    from gdmcf_amd.graph import GraphedTrainStep
+    U, I, B = 640, 3001, 64
+    csr = sp.random(U, I, density=0.01, format="csr", random_state=3, data_rvs=lambda n: np.ones(n)).astype(np.float32)
+    out = []
+    for mode in ("dense", "sparse", "graph"):
+        torch.manual_seed(2)
+        model = gdmcf_amd.DNN([I, 96], [96, I], 10).to(DEV)
+        diff = gdmcf_amd.GaussianDiffusion(ModelMeanType.START_X, "linear-var", 0.1, 0.001, 0.01, 5, DEV)
+        opt = gdmcf_amd.FusedAdamW(model.parameters(), lr=1e-3)
+        dcsr = data_utils.DeviceCSR(csr, DEV)
+        gen = torch.Generator().manual_seed(9)
+        gstep = GraphedTrainStep(diff, model, opt, dcsr, B) if mode == "graph" else None
+        tot = 0.0
+        for _ in range(2):
+            t, n = driver.train_one_epoch(diff, model, opt, dcsr, B, DEV, generator=gen, sparse=(mode == "sparse"), graph_step=gstep)
+            assert n == U // B
+            tot += t
+        if gstep is not None:
+            gstep.close()
+        out.append((tot, [p.detach().clone() for p in model.parameters()], diff.Lt_history.clone()))
+    for tot, ws, hist in out[1:]:
+        assert tot == out[0][0]
+        assert torch.equal(hist, out[0][2])
+        for a, b in zip(ws, out[0][1]):
+            assert torch.equal(a, b)
 
 
 def test_checkpoint_resume_is_bit_exact(tmp_path):
