@@ -36,3 +36,33 @@ t = time.time(); l1, w1 = run(); t1 = time.time() - t
 l2, w2 = run()
 print("train soak: 1500 steps in %.1f s; loss first %.4f last %.4f; finite %s; reruns identical: losses %s weights %s" % (
     t1, l1[:10].mean(), l1[-10:].mean(), bool(np.isfinite(l1).all()), bool((l1 == l2).all()), all(torch.equal(a, b) for a, b in zip(w1, w2))))
+# 3) the same 1500 steps replayed from a hipGraph (graph.GraphedTrainStep, AdamW table refilled every 256 steps): equal to the
+#    eager run bit for bit; 4) in f32x3 mode: finite, decreasing, reruns identical, final loss within 1e-4 of the f32 run
+from gdmcf_amd.graph import GraphedTrainStep
+def run_graph(table_steps=256):
+    torch.manual_seed(1)
+    model = gdmcf_amd.DNN([I, 1000], [1000, I], 10).to("cuda:0").train()
+    d = gdmcf_amd.GaussianDiffusion(gdmcf_amd.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, 5, "cuda:0")
+    opt = gdmcf_amd.FusedAdamW(model.parameters(), lr=1e-4)
+    losses = []
+    with GraphedTrainStep(d, model, opt, dcsr, 400, table_steps=table_steps) as g:
+        for s in range(1500):
+            losses.append(g(torch.arange((s % 10) * 400, (s % 10) * 400 + 400)))
+    torch.cuda.synchronize()
+    return torch.stack(losses).cpu().numpy(), [p.detach().clone() for p in model.parameters()]
+t = time.time(); l3, w3 = run_graph(); t3 = time.time() - t
+print("graph soak: 1500 replayed steps in %.1f s; equal to the eager run: losses %s weights %s" % (
+    t3, bool((l1 == l3).all()), all(torch.equal(a, b) for a, b in zip(w1, w3))))
+def run_x3():
+    torch.manual_seed(1)
+    model = gdmcf_amd.DNN([I, 1000], [1000, I], 10, gemm_dtype="f32x3").to("cuda:0").train()
+    d = gdmcf_amd.GaussianDiffusion(gdmcf_amd.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, 5, "cuda:0")
+    opt = gdmcf_amd.FusedAdamW(model.parameters(), lr=1e-4)
+    step = gdmcf_amd.parallel.DataParallelStep(d, model, opt)
+    losses = [step(dcsr.batch(torch.arange((s % 10) * 400, (s % 10) * 400 + 400)), True) for s in range(1500)]
+    torch.cuda.synchronize()
+    return torch.stack(losses).cpu().numpy(), [p.detach().clone() for p in model.parameters()]
+l4, w4 = run_x3(); l5, w5 = run_x3()
+print("f32x3 soak: loss first %.4f last %.4f; finite %s; reruns identical %s; max relative loss difference to the f32 run %.2e" % (
+    l4[:10].mean(), l4[-10:].mean(), bool(np.isfinite(l4).all()), bool((l4 == l5).all()) and all(torch.equal(a, b) for a, b in zip(w4, w5)),
+    float(np.abs(l4 - l1).max() / np.abs(l1).max())))
