@@ -281,6 +281,68 @@ struct Stage16<GD_LAY_MC, R, NT> {
     }
 };
 
+// Both shadows row-contiguous (the weight gradients): ONE (8-row group, 8-deep k group) unit per thread and ring slot --
+// threads [0, BM) take A's units, the top BN threads B's -- instead of both operands' units piled on the low threads:
+// 32 staging registers per slot (two slots fit), and every wave stages.
+template <int BM, int BN, int NT>
+struct Stage16Pair {
+    static_assert(BM + BN <= NT, "one unit per thread");
+    static constexpr int LOADS = 8;
+    u32x4 reg[8];
+    __device__ __forceinline__ void load_asm(const GdGemm& g, int m0, int n0, int k0, int tid) {
+        const bool isA = tid < BM;
+        const int u = isA ? tid : max(tid - (NT - BN), 0);
+        const int kg = u & 7, rg = u >> 3;
+        const int64_t ld = isA ? g.lda16 : g.ldb16;
+        const int col = min((isA ? m0 : n0) + (rg << 3), (int)ld - 8);  // groups beyond the matrix read padding of this row
+        const unsigned short* p = static_cast<const unsigned short*>(isA ? g.A16 : g.B16) + (int64_t)(k0 + (kg << 3)) * ld + col;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) reg[kk] = gload16_u(p + (int64_t)kk * ld);
+    }
+    __device__ __forceinline__ void pin() {
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) asm volatile("" : "+v"(reg[kk]));
+    }
+    __device__ __forceinline__ void store(char* img, int tid) const {
+        const bool isA = tid < BM;
+        if (!isA && tid < NT - BN) return;
+        const int u = isA ? tid : tid - (NT - BN);
+        const int kg = u & 7, rg = u >> 3;
+        char* base = img + (isA ? 0 : BM * 128);
+#pragma unroll
+        for (int mm = 0; mm < 8; ++mm) {
+            const int d = mm >> 1;
+            const unsigned sel = (mm & 1) ? 0x07060302u : 0x05040100u;
+            u32x4 w;
+            w.x = __builtin_amdgcn_perm(reg[1][d], reg[0][d], sel);
+            w.y = __builtin_amdgcn_perm(reg[3][d], reg[2][d], sel);
+            w.z = __builtin_amdgcn_perm(reg[5][d], reg[4][d], sel);
+            w.w = __builtin_amdgcn_perm(reg[7][d], reg[6][d], sel);
+            *reinterpret_cast<u32x4*>(base + img_off((rg << 3) + mm, kg)) = w;
+        }
+    }
+};
+
+// one slot of the shadow path's register ring
+template <int BM, int BN, int NT>
+struct SlotKK {
+    Stage16<GD_LAY_KC, BM, NT> a;
+    Stage16<GD_LAY_KC, BN, NT> b;
+    static constexpr int LOADS = Stage16<GD_LAY_KC, BM, NT>::LOADS + Stage16<GD_LAY_KC, BN, NT>::LOADS;
+    __device__ __forceinline__ void load_asm(const GdGemm& g, int m0, int n0, int k0, int tid) {
+        a.load_asm(static_cast<const unsigned short*>(g.A16), g.lda16, m0, g.M, k0, tid);
+        b.load_asm(static_cast<const unsigned short*>(g.B16), g.ldb16, n0, g.N, k0, tid);
+    }
+    __device__ __forceinline__ void pin() {
+        a.pin();
+        b.pin();
+    }
+    __device__ __forceinline__ void store(char* img, int tid) const {
+        a.store(img, tid);
+        b.store(img + BM * 128, tid);
+    }
+};
+
 template <int LAYA, int LAYB, int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool S16>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(const GdGemm g) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;
@@ -332,64 +394,52 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(const
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
     };
-    if constexpr (S16 && LAYA == GD_LAY_KC && LAYB == GD_LAY_KC) {
-        // two register stages: tiles it+1 and it+2 are in flight while tile it is multiplied (see gload16_u).  Measured on
-        // the Amazon-Book shape: forward 0.128 -> 0.115 ms, fused-loss forward 0.246 -> 0.233 ms.  Row-contiguous shadows
-        // (8 x 16 bytes per unit for the in-register transpose) keep one stage: a second one spills.
-        Stage16<LAYA, BM, NT> sa0, sa1;
-        Stage16<LAYB, BN, NT> sb0, sb1;
-        constexpr int LPT = Stage16<LAYA, BM, NT>::LOADS + Stage16<LAYB, BN, NT>::LOADS;
+    constexpr bool RING_KK = S16 && LAYA == GD_LAY_KC && LAYB == GD_LAY_KC;
+    constexpr bool RING_MM = S16 && LAYA == GD_LAY_MC && LAYB == GD_LAY_MC && BM + BN <= NT;
+    if constexpr (RING_KK || RING_MM) {
+        // two register slots: tiles it+1 and it+2 are in flight while tile it is multiplied (see gload16_u).  Measured on
+        // the Amazon-Book shape: forward 0.128 -> 0.115 ms, fused-loss forward 0.246 -> 0.233 ms, weight gradients (paired
+        // units, Stage16Pair) 0.269 -> 0.203 ms; Yelp shape weight gradients 0.187 -> 0.080 ms.  The K-contiguous x
+        // row-contiguous product (dh) keeps the single-slot loop below: with two slots of 48 registers the 208x256 kernel
+        // spills (0.132 -> 0.160 ms).
+        using Slot = typename std::conditional<RING_KK, SlotKK<BM, BN, NT>, Stage16Pair<BM, BN, NT>>::type;
+        Slot s0, s1;
+        constexpr int LPT = Slot::LOADS;
         static_assert(LPT <= 63, "vmcnt is a 6-bit counter");
-        const unsigned short* A16 = static_cast<const unsigned short*>(g.A16);
-        const unsigned short* B16 = static_cast<const unsigned short*>(g.B16);
 #define GD_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
         char* const L0 = lds;
         char* const L1 = lds + STAGE_BYTES;
         if (nt > 0) {
-            sa0.load_asm(A16, g.lda16, m0, g.M, kbeg, tid);
-            sb0.load_asm(B16, g.ldb16, n0, g.N, kbeg, tid);
+            s0.load_asm(g, m0, n0, kbeg, tid);
             if (nt > 1) {
-                sa1.load_asm(A16, g.lda16, m0, g.M, kbeg + BK, tid);
-                sb1.load_asm(B16, g.ldb16, n0, g.N, kbeg + BK, tid);
+                s1.load_asm(g, m0, n0, kbeg + BK, tid);
                 GD_WAIT_VM(LPT);
             } else {
                 GD_WAIT_VM(0);
             }
-            sa0.pin();
-            sb0.pin();
-            sa0.store(L0, tid);
-            sb0.store(L0 + A_BYTES, tid);
+            s0.pin();
+            s0.store(L0, tid);
         }
         __syncthreads();
         for (int it = 0; it < nt; it += 2) {
-            // even tile `it` in L0; stage-1 registers hold tile it+1 (in flight); stage-0 registers are free
+            // even tile `it` in L0; slot 1 holds tile it+1 (in flight); slot 0 is free
             const bool ld2 = it + 2 < nt;
-            if (ld2) {
-                sa0.load_asm(A16, g.lda16, m0, g.M, kbeg + (it + 2) * BK, tid);
-                sb0.load_asm(B16, g.ldb16, n0, g.N, kbeg + (it + 2) * BK, tid);
-            }
+            if (ld2) s0.load_asm(g, m0, n0, kbeg + (it + 2) * BK, tid);
             compute(L0);
             if (it + 1 < nt) {
                 if (ld2) GD_WAIT_VM(LPT); else GD_WAIT_VM(0);
-                sa1.pin();
-                sb1.pin();
-                sa1.store(L1, tid);
-                sb1.store(L1 + A_BYTES, tid);
+                s1.pin();
+                s1.store(L1, tid);
             }
             __syncthreads();
             if (it + 1 < nt) {
                 const bool ld3 = it + 3 < nt;
-                if (ld3) {
-                    sa1.load_asm(A16, g.lda16, m0, g.M, kbeg + (it + 3) * BK, tid);
-                    sb1.load_asm(B16, g.ldb16, n0, g.N, kbeg + (it + 3) * BK, tid);
-                }
+                if (ld3) s1.load_asm(g, m0, n0, kbeg + (it + 3) * BK, tid);
                 compute(L1);
                 if (ld2) {
                     if (ld3) GD_WAIT_VM(LPT); else GD_WAIT_VM(0);
-                    sa0.pin();
-                    sb0.pin();
-                    sa0.store(L0, tid);
-                    sb0.store(L0 + A_BYTES, tid);
+                    s0.pin();
+                    s0.store(L0, tid);
                 }
                 __syncthreads();
             }
