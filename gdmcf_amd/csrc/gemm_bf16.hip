@@ -482,7 +482,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(const
             __syncthreads();
         }
     }
-    if constexpr (EPI == GD_EPI_ADAMW)  // (plain result stores measured equal with and without the LDS round trip)
+    if constexpr (EPI == GD_EPI_ADAMW || (EPI == GD_EPI_STORE && S16))
         gemm_epilogue_rows<BM, BN, TM, TN, WAVES_M, WAVES_N, EPI, 64 * (BM + BN), NT>(acc, g, m0, n0, wn0, r, q, wave, tid,
                                                                                      smem);
     else
