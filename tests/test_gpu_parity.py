@@ -1297,7 +1297,7 @@ def _linear_entry_points_random_shapes(lib, prec, shadows=False, shapes=None, se
                                        rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("dtype", ["f32", "bf16", "f32x3"])
 @pytest.mark.parametrize("shape", [(1280, 256, 64), (1301, 255, 48)])
 def test_fused_optimizer_row_epilogue_matches_separate_pass(shape, dtype):
     """fuse_into_backward at shapes that take the 128x128 wave-specialised f32 kernel / the bf16 kernels, whose fused
