@@ -344,7 +344,7 @@ struct SlotKK {
 };
 
 template <int LAYA, int LAYB, int BM, int BN, int WAVES_M, int WAVES_N, int EPI, bool S16>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void gemm_bf16_kernel(const GdGemm g) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_bf16_kernel(const GdGemm g) {
     constexpr int NT = 64 * WAVES_M * WAVES_N;
     constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
     constexpr int TM = WTM / 16, TN = WTN / 16;

@@ -24,4 +24,5 @@ for line in r.stderr.splitlines():
 dem = subprocess.run(["c++filt"], input="\n".join(rows), capture_output=True, text=True).stdout.splitlines()
 for name, d in zip(dem, rows.values()):
     if flt in name:
-        print(f"{d.get('VGPRs', -1):4d} vgpr {d.get('VGPRs Spill', 0):4d} spill  occ {d.get('Occupancy', -1)}  {name[:150]}")
+        print(f"{d.get('VGPRs', -1):4d} vgpr {d.get('AGPRs', 0):4d} agpr {d.get('VGPRs Spill', 0):4d} spill  occ {d.get('Occupancy', -1)}  "
+              f"lds {d.get('LDS Size', 0)}  {name[:150]}")
