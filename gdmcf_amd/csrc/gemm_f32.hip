@@ -660,8 +660,12 @@ int launch_one(GdGemm& g, hipStream_t s) {
         // / 0.272 ms for 2 / 3 / 4 / 6 stages on the Yelp dW products -- the kernel is not load-latency bound
         static const int nstg = getenv("GDMCF_SPEC_STAGES") ? atoi(getenv("GDMCF_SPEC_STAGES")) : 2;
         if (spec) {
-            kern = nstg == 4 ? gemm_f32_spec_kernel<LAYA, LAYB, BM, BN, BK, WM, WN, EPI, 4>
-                             : gemm_f32_spec_kernel<LAYA, LAYB, BM, BN, BK, WM, WN, EPI, 2>;
+            kern = gemm_f32_spec_kernel<LAYA, LAYB, BM, BN, BK, WM, WN, EPI, 2>;
+            // (four stages of 32-deep tiles do not fit the loader waves' registers: with asm loads a spilled stage register
+            // would be read before its data arrives -- the build refuses kernels of this file that spill, gdmcf_amd/build.py)
+            if constexpr (BK == 16) {
+                if (nstg == 4) kern = gemm_f32_spec_kernel<LAYA, LAYB, BM, BN, BK, WM, WN, EPI, 4>;
+            }
         }
     }
     static bool attr_set = false;
