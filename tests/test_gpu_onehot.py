@@ -313,7 +313,7 @@ def test_onehot_backbones_with_bf16_gemm_inputs(backbone):
     if backbone == "onehot-emb":
         rand["index"] = torch.randperm(U, generator=g)[:B]
     res = {}
-    for dtype in ("f32", "bf16"):
+    for dtype in ("f32", "bf16", "f32x3"):
         torch.manual_seed(11)
         if backbone == "onehot":
             m = gdmcf_amd.DNNOneHot([I, hid], [hid, I], 10, gemm_dtype=dtype)
@@ -328,6 +328,10 @@ def test_onehot_backbones_with_bf16_gemm_inputs(backbone):
     assert abs(res["bf16"][0] - res["f32"][0]) <= 2e-3 * abs(res["f32"][0]) and res["bf16"][0] != res["f32"][0]
     for a, b in zip(res["bf16"][1], res["f32"][1]):
         assert H.relerr(a.cpu().numpy(), b.cpu().numpy()) < 5e-2
+    # "f32x3" (float32 products from three-term bf16 splits) is no rounding mode: f32-level agreement
+    assert abs(res["f32x3"][0] - res["f32"][0]) <= 2e-6 * abs(res["f32"][0])
+    for a, b in zip(res["f32x3"][1], res["f32"][1]):
+        assert H.relerr(a.cpu().numpy(), b.cpu().numpy()) < 2e-5
 
 
 @pytest.mark.parametrize("layers", [2, 1, 0])
