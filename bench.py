@@ -100,7 +100,10 @@ def parse():
                     help="single GPU: update the two large weights inside the weight-gradient GEMM epilogue "
                          "(FusedAdamW.fuse_into_backward); same update rule, gradient never materialised")
     ap.add_argument("--no-fused-leg", action="store_true", help="N = 1: skip the extra leg with AdamW fused into the dW epilogues")
-    ap.add_argument("--no-f32x3-leg", action="store_true", help="N = 1, fp32: skip the extra leg with gemm_dtype='f32x3'")
+    ap.add_argument("--f32x3-leg", action="store_true",
+                    help="N = 1, fp32: also time the step with gemm_dtype='f32x3' (opt-in product mode, DESIGN 4.4b)")
+    ap.add_argument("--no-configs2-leg", action="store_true",
+                    help="N = 1: skip the BASELINE configs[2] leg (Amazon-Book shape, bf16 GEMM inputs, B = 400)")
     ap.add_argument("--no-graph-leg", action="store_true", help="N = 1: skip the extra leg that replays the step from a hipGraph")
     ap.add_argument("--bpr", action="store_true", help="also time a LightGCN BPR training step (reported under 'bpr')")
     ap.add_argument("--backbone", default="dnn", choices=["dnn", "onehot", "onehot-emb", "onehot-gcn"],
@@ -129,6 +132,12 @@ def parse():
     return args
 
 
+def default_line_only(args):
+    """the command the driver runs (plain denoiser, Yelp shape, fp32, no variant flags): only that line carries the extra legs"""
+    return (args.backbone == "dnn" and args.workload == "yelp" and args.gemm_dtype == "f32" and not args.rehearse_dp
+            and not args.fuse_optimizer and not args.global_batch and args.batch == 400 and args.hidden == 1000)
+
+
 def collect_prof(lib, cap=65536):
     tags = (ctypes.c_int * cap)()
     ms = (ctypes.c_float * cap)()
@@ -141,6 +150,37 @@ def collect_prof(lib, cap=65536):
         d["work"] += float(work[i])
         d["n"] += 1
     return out
+
+
+def kernel_table(kernels, gemm_dtype, B, hid, I, steps, n_profiled, el):
+    """One entry per tagged kernel (HIP-event totals of the profiled steps), largest share of the step first: achieved
+    rate on the ALGORITHMIC work, the peak that bounds it, the fraction, the average launch and its share of the step."""
+    klist = []
+    for tag, d in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"]):
+        sec = d["ms"] * 1e-3
+        extra = {}
+        if tag in GEMM_TAGS and gemm_dtype == "bf16":
+            # bf16 products at batch 400 are bound by moving operands and results, not by the matrix pipe: report
+            # the HBM fraction on the compulsory bytes (each operand and the result once) and the bf16-MFMA
+            # fraction beside it.
+            E_ = 10
+            ob = 2.0  # operands are streamed from their bf16 shadows (2 B/elem); results and the loss target are f32
+            per_launch = {1: ob * (B + hid) * (I + E_) + 4.0 * B * hid,
+                          2: ob * (B * hid + I * hid) + 4.0 * 2 * B * I + 2.0 * B * I,
+                          3: ob * (B * hid + I * hid) + 4.0 * 2 * B * I,
+                          4: ob * (B * I + I * hid) + 4.0 * B * hid,
+                          5: (ob * (B * I + 2 * B * hid + B * (I + E_)) + 4.0 * (I * hid + hid * (I + E_))) / 2.0}[tag]
+            ach, peak, unit, bound = per_launch * d["n"] / sec / 1e9, PEAK_HBM_GBPS, "GB/s", "hbm"
+            extra = dict(mfma_tflops=round(d["work"] / sec / 1e12, 1),
+                         mfma_frac=round(d["work"] / sec / 1e12 / PEAK_BF16_MATRIX_TFLOPS, 4))
+        elif tag in GEMM_TAGS:
+            ach, peak, unit, bound = d["work"] / sec / 1e12, PEAK_F32_MATRIX_TFLOPS, "TFLOP/s", "mfma"
+        else:
+            ach, peak, unit, bound = d["work"] / sec / 1e9, PEAK_HBM_GBPS, "GB/s", "hbm"
+        klist.append(dict(kernel=TAGS.get(tag, str(tag)), bound=bound, achieved=round(ach, 2), peak=peak, unit=unit,
+                          frac=round(ach / peak, 4), avg_ms=round(d["ms"] / d["n"], 4), launches=d["n"],
+                          share_of_step=round(d["ms"] * steps / max(n_profiled, 1) / (el * 1e3), 4), **extra))
+    return klist
 
 
 def cpu_baseline(args, I, x_batches, seconds):
@@ -404,6 +444,21 @@ def main():
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         in_sync = bool(torch.equal(lo, hi))
 
+    # ---- the evaluation-path and SpMM legs run on the model as the main line left it (`final_loss` describes it); the extra
+    # N = 1 legs below keep training it and come afterwards.  At N > 1 rank 0 runs them alone, after the collective legs. ----
+    legs = {}
+
+    def eval_legs():
+        if args.spmm and (rank == 0 or (world > 1 and args.spmm_sharded)):
+            legs["spmm"] = bench_spmm(gdmcf_amd, lib, args.workload, dev, world=world if args.spmm_sharded else 1)
+        if args.bpr and rank == 0:
+            legs["bpr"] = bench_bpr(gdmcf_amd, args.workload, dev)
+        if args.sampling and rank == 0:
+            legs["sampling"] = bench_sampling(gdmcf_amd, lib, model, diffusion, x_dev[0], sub_ptr[:B + 1], sub_idx, dev)
+
+    if world == 1:
+        eval_legs()
+
     # ---- N > 1: strong-scaling leg (BASELINE configs[3] as stated: global batch 400 split over the ranks) ----
     strong_leg = None
     if world > 1 and not strong and not args.no_strong_leg and 400 % world == 0:
@@ -423,7 +478,9 @@ def main():
         ts_ = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=dev)
         dist.all_reduce(ts_, op=dist.ReduceOp.MAX)
         strong_leg = dict(global_batch=400, batch_per_gpu=Bs, steps=args.steps, ms_per_step=round(1e3 * float(ts_) / args.steps, 4),
-                          users_per_s=round(400 * args.steps / float(ts_), 1), scaling="strong")
+                          users_per_s=round(400 * args.steps / float(ts_), 1), scaling="strong",
+                          what=f"BASELINE configs[3]: Yelp_clean batch=400 steps=5 split over {world} GPUs ({Bs} rows per GPU), "
+                               "data parallel, RCCL gradient exchange over xGMI")
         step.flush()
 
     # ---- N = 1: the same step with AdamW inside the weight-gradient GEMM epilogues (FusedAdamW.fuse_into_backward:
@@ -475,7 +532,7 @@ def main():
     # float64 beside the native f32 MFMA kernels).  Reported beside the main line, which stays on v_mfma_f32_16x16x4_f32. ----
     x3_leg = None
     if world == 1 and args.backbone == "dnn" and args.gemm_dtype == "f32" and not args.fuse_optimizer and not args.rehearse_dp \
-            and not args.no_f32x3_leg:
+            and args.f32x3_leg:
         model.gemm_dtype = "f32x3"
         try:
             for i in range(max(3, args.warmup // 4)):
@@ -493,32 +550,8 @@ def main():
             model.gemm_dtype = "f32"
 
     # ---- roofline of the dominant kernel (rank 0's events) ----
-    roofline, klist = None, []
-    for tag, d in sorted(kernels.items(), key=lambda kv: -kv[1]["ms"]):
-        sec = d["ms"] * 1e-3
-        extra = {}
-        if tag in GEMM_TAGS and args.gemm_dtype == "bf16":
-            # bf16 products at batch 400 are bound by moving operands and results, not by the matrix pipe: report
-            # the HBM fraction on the compulsory bytes (each operand and the result once) and the bf16-MFMA
-            # fraction beside it.
-            E_ = 10
-            ob = 2.0  # operands are streamed from their bf16 shadows (2 B/elem); results and the loss target are f32
-            per_launch = {1: ob * (B + hid) * (I + E_) + 4.0 * B * hid,
-                          2: ob * (B * hid + I * hid) + 4.0 * 2 * B * I + 2.0 * B * I,
-                          3: ob * (B * hid + I * hid) + 4.0 * 2 * B * I,
-                          4: ob * (B * I + I * hid) + 4.0 * B * hid,
-                          5: (ob * (B * I + 2 * B * hid + B * (I + E_)) + 4.0 * (I * hid + hid * (I + E_))) / 2.0}[tag]
-            ach, peak, unit, bound = per_launch * d["n"] / sec / 1e9, PEAK_HBM_GBPS, "GB/s", "hbm"
-            extra = dict(mfma_tflops=round(d["work"] / sec / 1e12, 1),
-                         mfma_frac=round(d["work"] / sec / 1e12 / PEAK_BF16_MATRIX_TFLOPS, 4))
-        elif tag in GEMM_TAGS:
-            ach, peak, unit, bound = d["work"] / sec / 1e12, PEAK_F32_MATRIX_TFLOPS, "TFLOP/s", "mfma"
-        else:
-            ach, peak, unit, bound = d["work"] / sec / 1e9, PEAK_HBM_GBPS, "GB/s", "hbm"
-        e = dict(kernel=TAGS.get(tag, str(tag)), bound=bound, achieved=round(ach, 2), peak=peak, unit=unit,
-                 frac=round(ach / peak, 4), avg_ms=round(d["ms"] / d["n"], 4), launches=d["n"],
-                 share_of_step=round(d["ms"] * args.steps / max(n_profiled, 1) / (el * 1e3), 4), **extra)
-        klist.append(e)
+    roofline = None
+    klist = kernel_table(kernels, args.gemm_dtype, B, hid, I, args.steps, n_profiled, el)
     if klist:
         k0 = klist[0]
         traffic, traffic_note = measured_traffic(k0["kernel"], args.workload, args.gemm_dtype)
@@ -530,17 +563,17 @@ def main():
                         algorithmic_unit=("2*M*N*K FLOP per launch" if k0["bound"] == "mfma" else
                                           "compulsory bytes per launch (operands and results once; AdamW 28 B/param)"))
 
-    spmm = None
-    if args.spmm and (rank == 0 or (world > 1 and args.spmm_sharded)):
-        spmm = bench_spmm(gdmcf_amd, lib, args.workload, dev, world=world if args.spmm_sharded else 1)
+    if world > 1:
+        eval_legs()
+    spmm, bpr, sampling = legs.get("spmm"), legs.get("bpr"), legs.get("sampling")
 
-    bpr = None
-    if args.bpr and rank == 0:
-        bpr = bench_bpr(gdmcf_amd, args.workload, dev)
-
-    sampling = None
-    if args.sampling and rank == 0:
-        sampling = bench_sampling(gdmcf_amd, lib, model, diffusion, x_dev[0], sub_ptr[:B + 1], sub_idx, dev)
+    # ---- N = 1, default line: BASELINE configs[2] (Amazon-Book shape, bf16 GEMM inputs) so that the driver's record carries it ----
+    configs2_leg = None
+    if world == 1 and default_line_only(args) and not args.no_configs2_leg:
+        try:
+            configs2_leg = bench_configs2(gdmcf_amd, lib, dev, args.steps, max(3, args.warmup // 4))
+        except Exception as exc:  # reported, never fatal for the main line
+            configs2_leg = dict(error=f"{type(exc).__name__}: {exc}"[:300])
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -569,6 +602,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "kernels": klist, "final_loss": final_loss,
             "host_enqueue_ms_per_step": round(1e3 * host_el / args.steps, 4),
             "replicas_in_sync": in_sync, "dp_autotune": dp_autotune, "strong_scaling": strong_leg, "fused_optimizer_leg": fused_leg, "graph_leg": graph_leg, "f32x3_leg": x3_leg,
+            "configs2_leg": configs2_leg,
             "ranks_in_group": dist.get_world_size() if dist.is_initialized() else 1,
             "optimizer": "FusedAdamW" + (" fused into the dW GEMM epilogues" if (args.fuse_optimizer and world == 1) else
                                          " (row-sharded over the ranks: reduce-scatter, AdamW on 1/N rows, deferred all-gather)"
@@ -616,6 +650,64 @@ def bench_sampling(gdmcf_amd, lib, model, diffusion, x, indptr, indices, dev, it
             out[name + "_avg_ms"] = round(d["ms"] / d["n"], 4)
             if tag == 9:
                 out["topk_GBps"] = round(d["work"] / (d["ms"] * 1e-3) / 1e9, 1)
+    return out
+
+
+def bench_configs2(gdmcf_amd, lib, dev, steps, warmup, B=400, hid=1000, T=5, prof_every=4):
+    """BASELINE configs[2] beside the main line: "Amazon-Book_clean batch=400 dims=[1000] steps=5, 1xMI355X, bf16 denoiser GEMM
+    on MFMA" -- the same training step (zero_grad -> training_losses -> mean -> backward -> AdamW.step) on synthetic rows of
+    the Amazon-Book shape (I = 94 949), dense products with bf16-rounded inputs on v_mfma_f32_16x16x32_bf16, f32 accumulation,
+    f32 master weights / gradients / AdamW state.  Own model, own optimizer, own rows; kernels timed with HIP events like
+    the main line.  Also timed: the same step with AdamW inside the weight-gradient epilogues."""
+    import scipy.sparse as sp
+    from gdmcf_amd import data
+    from gdmcf_amd.data_utils import DeviceCSR
+    from gdmcf_amd.parallel import DataParallelStep
+    n_pool = 4
+    indptr, indices, I = data.synth_csr("amazon-book", n_rows=n_pool * B, seed=0)
+    dcsr = DeviceCSR(sp.csr_matrix((np.ones(len(indices), np.float32), indices, indptr), shape=(n_pool * B, I)), dev)
+    row_ids = [torch.arange(i * B, (i + 1) * B, device=dev) for i in range(n_pool)]
+    torch.manual_seed(0)
+    model = gdmcf_amd.DNN([I, hid], [hid, I], 10, time_type="cat", norm=False, gemm_dtype="bf16").to(dev).train()
+    diffusion = gdmcf_amd.GaussianDiffusion(gdmcf_amd.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, T, dev)
+    opt = gdmcf_amd.FusedAdamW(model.parameters(), lr=1e-5, weight_decay=0.0)
+    step = DataParallelStep(diffusion, model, opt)
+    torch.manual_seed(4321)
+
+    def timed(n, prof):
+        for i in range(max(3, warmup)):
+            step(dcsr.batch(row_ids[i % n_pool]), True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            if prof:
+                lib.gdmcf_prof_enable(1 if i % prof_every == 0 else 2)
+            loss = step(dcsr.batch(row_ids[i % n_pool]), True)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        k = collect_prof(lib) if prof else {}
+        lib.gdmcf_prof_enable(0)
+        return el, k, float(loss)
+
+    el, kernels, loss = timed(steps, True)
+    klist = kernel_table(kernels, "bf16", B, hid, I, steps, len(range(0, steps, prof_every)), el)
+    opt.fuse_into_backward(model)
+    elf, _, lossf = timed(steps, False)
+    opt.fuse_into_backward(model, min_numel=1 << 62)
+    k0 = klist[0] if klist else None
+    out = dict(what="BASELINE configs[2]: Amazon-Book-shape synthetic rows, batch=400, dims=[1000], T=5, bf16 denoiser GEMM inputs on "
+                    "the bf16 MFMA (f32 accumulate, f32 master weights and AdamW state), 1 GPU",
+               n_items=I, dtype="bf16", steps=steps, ms_per_step=round(1e3 * el / steps, 4), users_per_s=round(B * steps / el, 1),
+               final_loss=loss, kernels=klist,
+               dominant_kernel=None if k0 is None else dict(
+                   kernel=k0["kernel"], bound=k0["bound"], achieved=k0["achieved"], peak=k0["peak"], unit=k0["unit"], frac=k0["frac"],
+                   avg_ms=k0["avg_ms"], share_of_step=k0["share_of_step"],
+                   algorithmic_unit="AdamW: 30 B/param (28 + the bf16 shadow of the two large weights); products: operands "
+                                    "(bf16 shadows) and results once"),
+               fused_optimizer=dict(ms_per_step=round(1e3 * elf / steps, 4), users_per_s=round(B * steps / elf, 1), final_loss=lossf,
+                                    what="AdamW of the two large weights inside their weight-gradient GEMM epilogues"))
+    del step, opt, model, dcsr
+    torch.cuda.empty_cache()
     return out
 
 

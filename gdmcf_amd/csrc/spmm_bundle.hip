@@ -265,7 +265,9 @@ __global__ __launch_bounds__(256) void spmm_stream_kernel(const SpmmStreamPlan p
     const uint32_t ldxb = (uint32_t)ldx * 4u;
     const int w = (blockIdx.x & 7) * pl.waves_per_class + (blockIdx.x >> 3) * 4 + (threadIdx.x >> 6);
     const int sb = __builtin_amdgcn_readfirstlane(pl.wdesc[4 * w]);
-    const int nb = __builtin_amdgcn_readfirstlane(pl.wdesc[4 * w + 1]);
+    // (the packer gives every wave with units at least one batch -- spmm_stream_pack; the clamp keeps the pre-loads below
+    // inside the run even for a hand-made descriptor with none)
+    const int nb = max(__builtin_amdgcn_readfirstlane(pl.wdesc[4 * w + 1]), 1);
     const int u0 = __builtin_amdgcn_readfirstlane(pl.wdesc[4 * w + 2]);
     const int u1 = __builtin_amdgcn_readfirstlane(pl.wdesc[4 * w + 3]);
     if (u0 >= u1) return;

@@ -316,6 +316,9 @@ def spmm_stream_pack(plan, indptr, indices, vals, d=64):
     ucum = np.concatenate([[0], np.cumsum(uent)])
     wtot = ucum[u1] - ucum[u0]
     wbat = -(-wtot // 64)
+    # a wave whose units are all bundles of EMPTY rows has no entries of its own; the kernel still pre-loads the first
+    # batch of its run, so every wave with units owns at least one (weight-0, column-0) batch
+    wbat = np.where((u1 > u0) & (wbat == 0), 1, wbat)
     wbase = (np.cumsum(wbat) - wbat) * 64
     n_ent = int(wbat.sum()) * 64
     wave_of_unit = np.repeat(np.arange(n_w), u1 - u0)  # units are in wave order

@@ -11,8 +11,11 @@ def emulate(A, X, d, sp_):
     cw=sp_["cw"].reshape(-1,2); cc=cw[:,0]; ww=cw[:,1].copy().view(np.float32)
     ud=sp_["ud"].reshape(-1,DW); wd=sp_["wdesc"].reshape(-1,4)
     Y=np.full((n,d),np.nan); partial=np.full((max(sp_["n_slots"],1),d),np.nan); written=np.zeros(n,int)
+    n_batches=len(cw)//64
     for w in range(len(wd)):
         sb,nb,u0,u1=wd[w]; pos=sb*64
+        # the kernel pre-loads batch 0 and batch min(1, nb-1) of the run of every wave that has units: they must exist
+        assert u1<=u0 or (nb>=1 and sb+nb<=n_batches), ("wave with units but no batch", w, sb, nb, u0, u1)
         for u in range(u0,u1):
             hdr=int(ud[u,0]); ng=hdr&0x7FFFFFFF
             acc=np.zeros((G,d))

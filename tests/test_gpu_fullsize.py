@@ -1,0 +1,198 @@
+"""GPU (-m gpu): LightGCN propagation at the graph sizes its kernels are SELECTED for (reference lightGCN.py:180-194), and
+a data-parallel rehearsal at the per-rank shape of BASELINE configs[3].
+
+* `LightGCN.propagate_through_layers` with the auto-selected kernel (no GDMCF_SPMM_GEN override) on the synthetic Yelp
+  graph (88 969 nodes, streamed third-generation schedule: 4 096 waves, 8 XCD column ranges), the Amazon-Book graph
+  (203 771 nodes, first-generation kernels) and the config-5 graph (1.2 M nodes, 4e7 directed nonzeros, d = 64, 3 layers:
+  "HBM-bound SpMM stress", BASELINE configs[4]) against the float64 scipy CSR product of the SAME float32 adjacency;
+  tolerance as tests/test_gpu_parity.py::test_spmm_random_graphs_against_float64 (2e-5 of max|ref|, absolute).
+* the config-5 graph row-sharded over 2 ranks (`shard_rows=True`, gloo, both ranks on the one GPU of the test box):
+  every rank's propagated tables equal the float64 product too, and each other bit for bit.
+* 2 ranks x 50 rows at the Yelp width (I = 34 395, dims=[1000], T = 5: the per-GPU share of a global batch of 400 on 8
+  GPUs is 50 rows) through DataParallelStep: the mean loss of the GLOBAL batch and the replicas' weights against the CPU
+  oracle (loss <= 1e-4 relative: north_star).
+"""
+import functools
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import gdmcf_amd
+from gdmcf_amd import data as D
+from oracle import gdmcf_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+LAYERS, DIM = 3, 64
+
+
+@functools.lru_cache(maxsize=1)
+def _graph(shape):
+    indptr, indices, n_items = D.synth_csr(shape, seed=0)
+    n_users = D.SHAPES[shape]["n_users"]
+    users = np.repeat(np.arange(n_users), np.diff(indptr))
+    return users, indices.astype(np.int64), n_users, n_items
+
+
+def _float64_mean_of_layers(users, items, U, It, E0, L):
+    """mean_l (A~^l E0), l = 0..L, in float64 on the float32 adjacency the product builds (reference :145-178, :184-189)."""
+    import scipy.sparse as sp
+    from gdmcf_amd.lightgcn import normalized_bipartite_csr
+    indptr, indices, vals = normalized_bipartite_csr(users, items, U, It)
+    A = sp.csr_matrix((vals.astype(np.float64), indices, indptr), shape=(U + It, U + It))
+    cur = acc = E0.astype(np.float64)
+    for _ in range(L):
+        cur = A @ cur
+        acc = acc + cur
+    return acc / (L + 1), int(indices.size)
+
+
+@pytest.mark.parametrize("shape,expect_streamed,min_nodes,min_nnz", [
+    ("yelp", True, 88969, 1_900_000),
+    ("amazon-book", False, 203771, 4_300_000),
+    ("stress", False, 1_200_000, 39_000_000),
+])
+def test_propagation_at_the_selected_kernels_graph_size(shape, expect_streamed, min_nodes, min_nnz, monkeypatch):
+    monkeypatch.delenv("GDMCF_SPMM_GEN", raising=False)  # the product's own choice (lightgcn.py: SPMM_SLICE_MB)
+    users, items, U, It = _graph(shape)
+    assert U + It >= min_nodes
+    rng = np.random.default_rng(7)
+    E0 = (rng.standard_normal((U + It, DIM)) * 0.1).astype(np.float32)
+    m = gdmcf_amd.LightGCN({"user_id_idx": users, "item_id_idx": items}, U, It, LAYERS, DIM, device=DEV)
+    assert m._streamed == expect_streamed and not m._bundled, (shape, m._streamed, m._bundled)
+    if expect_streamed:
+        assert m._plan["n_waves"] == 4096
+    with torch.no_grad():
+        m.E0.weight.copy_(torch.from_numpy(E0))
+    m = m.to(DEV)
+    with torch.no_grad():
+        fu, fi, iu, ii = m.propagate_through_layers()
+        fu2, fi2, _, _ = m.propagate_through_layers()
+    got = torch.cat([fu, fi]).cpu().numpy()
+    assert torch.equal(fu, fu2) and torch.equal(fi, fi2)  # fixed schedule, no atomics: bit-identical reruns
+    np.testing.assert_array_equal(torch.cat([iu, ii]).cpu().numpy(), E0)
+    ref, nnz = _float64_mean_of_layers(users, items, U, It, E0, LAYERS)
+    assert nnz >= min_nnz and m.nnz == nnz
+    tol = 2e-5 * max(1.0, float(np.abs(ref).max()))
+    err = float(np.abs(got - ref).max())
+    assert err <= tol, (shape, err, tol)
+    # the layers themselves, not only their mean (a wrong row would be diluted by 1/(L+1) otherwise)
+    with torch.no_grad():
+        _, _, _, _, layers = m.propagate_through_layers(return_layers=True)
+    import scipy.sparse as sp
+    from gdmcf_amd.lightgcn import normalized_bipartite_csr
+    indptr, indices, vals = normalized_bipartite_csr(users, items, U, It)
+    A = sp.csr_matrix((vals.astype(np.float64), indices, indptr), shape=(U + It, U + It))
+    l1 = A @ E0.astype(np.float64)
+    assert float(np.abs(layers[0].cpu().numpy() - l1).max()) <= 2e-5 * max(1.0, float(np.abs(l1).max()))
+
+
+def _shard_worker(rank, port, path, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    z = np.load(path)
+    users, items, E0 = z["users"], z["items"], z["E0"]
+    U, It = int(z["U"]), int(z["It"])
+    m = gdmcf_amd.LightGCN({"user_id_idx": users, "item_id_idx": items}, U, It, LAYERS, DIM, device=DEV, shard_rows=True)
+    with torch.no_grad():
+        m.E0.weight.copy_(torch.from_numpy(E0))
+    m = m.to(DEV)
+    with torch.no_grad():
+        fu, fi, _, _ = m.propagate_through_layers()
+    torch.cuda.synchronize()
+    np.save(os.path.join(out_dir, f"shard{rank}.npy"), torch.cat([fu, fi]).cpu().numpy())
+    dist.destroy_process_group()
+
+
+def test_config5_graph_row_sharded_over_two_ranks(tmp_path, monkeypatch):
+    """config 5's graph (1.2 M nodes) with every rank owning half of the adjacency's rows: a layer = local SpMM over the
+    full table + all-gather of the row blocks.  Both ranks end with the full, identical, correct tables."""
+    monkeypatch.delenv("GDMCF_SPMM_GEN", raising=False)
+    users, items, U, It = _graph("stress")
+    rng = np.random.default_rng(11)
+    E0 = (rng.standard_normal((U + It, DIM)) * 0.1).astype(np.float32)
+    path = str(tmp_path / "graph.npz")
+    np.savez(path, users=users, items=items, E0=E0, U=U, It=It)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_shard_worker, args=(port, path, str(tmp_path)), nprocs=2, join=True)
+    a, b = np.load(tmp_path / "shard0.npy"), np.load(tmp_path / "shard1.npy")
+    np.testing.assert_array_equal(a, b)
+    ref, _ = _float64_mean_of_layers(users, items, U, It, E0, LAYERS)
+    assert float(np.abs(a - ref).max()) <= 2e-5 * max(1.0, float(np.abs(ref).max()))
+
+
+# ---- data-parallel rehearsal at the per-rank shape of BASELINE configs[3] -----------------------------------------------
+B_RANK, I_Y, HID_Y, T_Y, DP_STEPS = 50, 34395, 1000, 5, 2
+
+
+def _dp_inputs(step, world):
+    g = torch.Generator().manual_seed(500 + step)
+    B = B_RANK * world
+    x = (torch.rand(B, I_Y, generator=g) < 0.00075).float()
+    ts = torch.randint(0, T_Y, (B,), generator=g)
+    noise = torch.randn(B, I_Y, generator=g)
+    keep = (torch.rand(B, I_Y, generator=g) < 0.5).float()
+    return x, ts, torch.ones(B, dtype=torch.float64), noise, keep
+
+
+def _dp_worker(rank, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    from gdmcf_amd.parallel import DataParallelStep
+    torch.manual_seed(0)
+    model = gdmcf_amd.DNN([I_Y, HID_Y], [HID_Y, I_Y], 10)
+    torch.manual_seed(0)
+    model.load_state_dict(O.DNN([I_Y, HID_Y], [HID_Y, I_Y], 10).state_dict())  # the oracle's initial weights, literally
+    model = model.to(DEV).train()
+    diff = gdmcf_amd.GaussianDiffusion(gdmcf_amd.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, T_Y, DEV)
+    opt = gdmcf_amd.FusedAdamW(model.parameters(), lr=1e-5, weight_decay=0.0)
+    step = DataParallelStep(diff, model, opt)
+    losses = []
+    lo, hi = rank * B_RANK, (rank + 1) * B_RANK
+    for s in range(DP_STEPS):
+        x, ts, pt, noise, keep = [t[lo:hi].to(DEV) for t in _dp_inputs(s, 2)]
+        losses.append(float(step(x, True, ts=ts, pt=pt, noise=noise, drop_mask=keep)))
+    torch.cuda.synchronize()
+    keys = ["in_layers.0.bias", "out_layers.0.bias", "emb_layer.weight"]
+    sd = model.state_dict()
+    torch.save(dict(losses=losses, small={k: sd[k].cpu() for k in keys}, w2_rows=sd["out_layers.0.weight"][:64].cpu(),
+                    hist=diff.Lt_history.cpu(), cnt=diff.Lt_count.cpu()), os.path.join(out_dir, f"dp{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_of_fifty_rows_match_the_oracle_on_the_global_batch(tmp_path):
+    """BASELINE configs[3] splits a batch of 400 over 8 GPUs: 50 rows per rank.  Two such ranks (global batch 100) against
+    the CPU ORACLE on the global batch: mean loss per step (<= 1e-4 relative), Lt-history bookkeeping, weights after AdamW."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_dp_worker, args=(port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "dp0.pt"), torch.load(tmp_path / "dp1.pt")
+    torch.manual_seed(0)
+    om = O.DNN([I_Y, HID_Y], [HID_Y, I_Y], 10).train()
+    od = O.GaussianDiffusion(O.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, T_Y)
+    oopt = O.make_optimizer(om, 1e-5)
+    ref = []
+    for s in range(DP_STEPS):
+        x, ts, pt, noise, keep = _dp_inputs(s, 2)
+        oloss, _ = O.train_step(od, om, oopt, x, True, ts=ts, pt=pt, noise=noise, drop_mask=keep)
+        ref.append(float(oloss))
+    got = 0.5 * (np.array(r0["losses"]) + np.array(r1["losses"]))  # equal shard sizes: global mean = mean of local means
+    np.testing.assert_allclose(got, ref, rtol=1e-4)
+    osd = om.state_dict()
+    for r in (r0, r1):
+        np.testing.assert_array_equal(r["cnt"].numpy(), od.Lt_count.numpy())
+        np.testing.assert_allclose(r["hist"].numpy(), od.Lt_history.numpy(), rtol=1e-4)
+        for k, v in r["small"].items():
+            assert float((v - osd[k]).abs().max()) < 0.25 * 1e-5 * DP_STEPS, k
+        assert float((r["w2_rows"] - osd["out_layers.0.weight"][:64]).abs().max()) < 0.25 * 1e-5 * DP_STEPS
+    for k in r0["small"]:
+        assert torch.equal(r0["small"][k], r1["small"][k])  # replicas stay bit-identical
+    assert torch.equal(r0["w2_rows"], r1["w2_rows"])

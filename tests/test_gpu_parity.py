@@ -1370,6 +1370,13 @@ def test_bench_emits_the_contract_line():
     sp = d["spmm"]
     assert sp["bound"] == "hbm" and sp["ms_per_layer"] > 0 and abs(sp["frac"] - sp["achieved"] / sp["peak"]) < 1e-3
     assert d["sampling"]["users_per_s"] > 0 and d["ranks_in_group"] == 1
+    # BASELINE configs[2] (Amazon-Book shape, bf16 GEMM inputs) rides in the default line so the driver's record carries it
+    c2 = d["configs2_leg"]
+    assert "error" not in c2, c2
+    assert c2["dtype"] == "bf16" and c2["n_items"] == 94949 and c2["ms_per_step"] > 0 and c2["users_per_s"] > 0
+    dk = c2["dominant_kernel"]
+    assert dk["bound"] in ("hbm", "mfma") and abs(dk["frac"] - dk["achieved"] / dk["peak"]) < 1e-3
+    assert c2["fused_optimizer"]["ms_per_step"] > 0
     # asked for two GPUs on a one-GPU box: no line, non-zero exit
     if __import__("torch").cuda.device_count() < 2:
         r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],

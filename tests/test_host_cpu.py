@@ -435,6 +435,33 @@ def test_spmm_stream_pack_reproduces_the_product(d, n_waves):
     assert len(real) == (A.data != 0).sum()
 
 
+@pytest.mark.parametrize("n,n_nonempty", [(2000, 10), (200, 5)])
+def test_spmm_stream_pack_gives_every_wave_with_units_a_batch(n, n_nonempty):
+    """Graphs of mostly isolated nodes: a wave may own nothing but bundles of EMPTY rows (no entries of its own).  The
+    stream kernel pre-loads batch 0 and batch min(1, nb-1) of the run of every wave that has units (csrc/spmm_bundle.hip:
+    spmm_stream_kernel), so the packer must give such a wave one (weight-0) batch inside the cw array -- with nb == 0 those
+    loads fell before / behind the run (round-2 advisor finding)."""
+    import scipy.sparse as sp
+    from gdmcf_amd.lightgcn import spmm_bundle_plan, spmm_stream_pack
+    rng = np.random.default_rng(n)
+    rows = np.repeat(rng.choice(n, n_nonempty, replace=False), 3)
+    cols = rng.integers(0, n, len(rows))
+    A = sp.csr_matrix((np.ones(len(rows), np.float32), (rows, cols)), shape=(n, n))
+    A.sum_duplicates()
+    A.sort_indices()
+    plan = spmm_bundle_plan(A.indptr, A.indices, d=64, n_cols=n)
+    sp_ = spmm_stream_pack(plan, A.indptr, A.indices, A.data, d=64)
+    wd = sp_["wdesc"].reshape(-1, 4)
+    n_batches = sp_["n_entries"] // 64
+    assert len(sp_["cw"]) == 2 * sp_["n_entries"]
+    has_units = wd[:, 3] > wd[:, 2]
+    assert has_units.sum() > n_nonempty  # the case is real: waves that own only empty rows exist
+    assert (wd[has_units, 1] >= 1).all()
+    assert (wd[has_units, 0] + wd[has_units, 1] <= n_batches).all()
+    cw = sp_["cw"].reshape(-1, 2)
+    assert (cw[:, 0] >= 0).all() and (cw[:, 0] < n).all()
+
+
 def test_bench_gpus_n_starts_n_ranks_or_fails_loudly():
     """`python bench.py --gpus N` (the shape of the command the driver runs) must produce an N-rank line or no line: the
     parent starts N fresh rank processes itself (dry run here: the ranks meet in a gloo group on the CPU, nothing is timed),

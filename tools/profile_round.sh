@@ -5,12 +5,12 @@ T=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/$T
 mkdir -p $O
-B="python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-fused-leg --no-graph-leg --no-f32x3-leg"
+B="python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-fused-leg --no-graph-leg --no-configs2-leg"
 rocprofv3 --kernel-trace --stats -d $O/stats -o f32 --output-format csv -- $B > $O/bench_under_rocprof.json 2> $O/stats.log
 echo stats done
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/fetch -o fetch --output-format csv -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-prof --no-fused-leg --no-graph-leg --no-f32x3-leg > $O/fetch.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/fetch -o fetch --output-format csv -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-prof --no-fused-leg --no-graph-leg --no-configs2-leg > $O/fetch.log 2>&1
 echo fetch done
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/write -o write --output-format csv -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-prof --no-fused-leg --no-graph-leg --no-f32x3-leg > $O/write.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/write -o write --output-format csv -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-prof --no-fused-leg --no-graph-leg --no-configs2-leg > $O/write.log 2>&1
 echo write done
 python3 profiles/summarize.py traffic_by_tag $O/fetch/fetch_counter_collection.csv $O/write/write_counter_collection.csv yelp f32 > $O/hbm_traffic.json
 python3 profiles/summarize.py stats $O/stats/f32_kernel_stats.csv > $O/kernel_stats_summary.json
