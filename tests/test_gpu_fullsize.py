@@ -75,7 +75,7 @@ def test_propagation_at_the_selected_kernels_graph_size(shape, expect_streamed, 
         fu2, fi2, _, _ = m.propagate_through_layers()
     got = torch.cat([fu, fi]).cpu().numpy()
     assert torch.equal(fu, fu2) and torch.equal(fi, fi2)  # fixed schedule, no atomics: bit-identical reruns
-    np.testing.assert_array_equal(torch.cat([iu, ii]).cpu().numpy(), E0)
+    np.testing.assert_array_equal(torch.cat([iu, ii]).detach().cpu().numpy(), E0)
     ref, nnz = _float64_mean_of_layers(users, items, U, It, E0, LAYERS)
     assert nnz >= min_nnz and m.nnz == nnz
     tol = 2e-5 * max(1.0, float(np.abs(ref).max()))
