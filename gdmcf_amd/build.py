@@ -11,10 +11,10 @@ import subprocess
 import sys
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-SOURCES = ["capi.hip", "dp_exchange.hip", "gemm_f32.hip", "gemm_bf16.hip", "gemm_split.hip", "gemm_small.hip", "kernels_misc.hip", "linear.hip", "topk_spmm.hip", "spmm_bundle.hip"]
+SOURCES = ["capi.hip", "dp_exchange.hip", "gemm_f32.hip", "gemm_bf16.hip", "gemm_split.hip", "gemm_small.hip", "gemm_dr.hip", "kernels_misc.hip", "linear.hip", "topk_spmm.hip", "spmm_bundle.hip"]
 HEADERS = ["common.h", "gemm_epilogue.h", os.path.join("..", "..", "include", "gdmcf_hip.h")]
 LIB = os.path.join(CSRC, "libgdmcf_hip.so")
-NO_SPILL = ("gemm_f32.hip", "gemm_bf16.hip", "gemm_split.hip")  # kernels with uncounted asm loads: a spill is a build error
+NO_SPILL = ("gemm_f32.hip", "gemm_bf16.hip", "gemm_split.hip", "gemm_dr.hip")  # kernels with uncounted asm loads: a spill is a build error
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

@@ -156,6 +156,9 @@ int gd_gemm_launch(int layA, int layB, int epi, int shape_class, GdGemm& g, hipS
 int gd_gemm_bf16_launch(int layA, int layB, int epi, int shape_class, GdGemm& g, hipStream_t s);  // g.bf16 != 0
 int gd_gemm_split_launch(int layA, int layB, int epi, int shape_class, GdGemm& g, hipStream_t s);  // g.bf16 == 2 (gemm_split.hip)
 int gd_gemm_small_launch(int layA, int layB, int epi, GdGemm& g, hipStream_t s);  // degenerate shapes (gemm_small.hip)
+// direct-to-register f32 products (gemm_dr.hip): GD_DR_NOT_TAKEN = not a product / shape it handles, fall back to the LDS-tiled kernels
+enum { GD_DR_NOT_TAKEN = 1 };
+int gd_gemm_dr_launch(int layA, int layB, int epi, GdGemm& g, hipStream_t s);
 int gd_gemm_tile_m(int shape_class);
 int gd_gemm_tile_n(int shape_class);
 int gd_gemm_bk(int layA, int layB);

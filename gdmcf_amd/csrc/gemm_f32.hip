@@ -723,6 +723,10 @@ int gd_pick_shape_class(int M, int N) {
 int gd_gemm_launch(int layA, int layB, int epi, int cls, GdGemm& g, hipStream_t s) {
     if (g.bf16 == 2) return gd_gemm_split_launch(layA, layB, epi, cls, g, s);
     if (g.bf16) return gd_gemm_bf16_launch(layA, layB, epi, cls, g, s);
+    {
+        const int rc = gd_gemm_dr_launch(layA, layB, epi, g, s);  // barrier-free register-streaming kernels where they apply
+        if (rc != GD_DR_NOT_TAKEN) return rc;
+    }
     // the branch-free edge loader clamps 16-byte vectors onto valid elements: it needs >= 4 elements along the
     // contiguous axis of every operand (K for K-contiguous operands, rows for row-contiguous ones); anything smaller
     // goes to the element-wise kernel of gemm_small.hip

@@ -13,6 +13,8 @@
 bool g_gd_prof_on = false;
 int gd_gemm_bf16_launch(int, int, int, int, GdGemm&, hipStream_t) { return GDMCF_E_UNSUPPORTED; }  // f32 probe only
 int gd_gemm_small_launch(int, int, int, GdGemm&, hipStream_t) { return GDMCF_E_UNSUPPORTED; }
+int gd_gemm_split_launch(int, int, int, int, GdGemm&, hipStream_t) { return GDMCF_E_UNSUPPORTED; }
+#include "../gdmcf_amd/csrc/gemm_dr.hip"
 void gd_prof_begin(int, double, hipStream_t) {}
 void gd_prof_end(hipStream_t) {}
 void gdmcf_set_error(const char* fmt, ...) {
@@ -95,7 +97,7 @@ int main(int argc, char** argv) {
         cases.push_back({"dW1 cls0  ", GD_LAY_MC, GD_LAY_MC, GD_EPI_STORE, 0, g});
     }
     for (auto& c : cases) {
-        for (int w = 0; w < 3; ++w) {
+        for (int w = 0; w < 150; ++w) {
             GdGemm g = c.g;
             if (gd_gemm_launch(c.la, c.lb, c.epi, c.cls, g, s)) return 1;
         }
