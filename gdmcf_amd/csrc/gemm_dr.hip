@@ -35,6 +35,7 @@ namespace {
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef f32x4 f32x4_dr_u __attribute__((aligned(4)));
 
 __device__ unsigned int g_dr_ticket[32];  // one counter per call site (GdGemm::prof_tag); zero between launches
 
@@ -264,60 +265,353 @@ __global__ __launch_bounds__(512, 2) void dr_tn_kernel(const DrArgs d) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// C[M,N] = A[M,K] * B[N,K]^T, both operands K-contiguous (the forward layers, reference models/DNN.py:79-86, with the fused
+// row-loss / posterior / bias-activation epilogues of gaussian_diffusion.py:335, :451-498).
+// A lane loads 16 bytes = four consecutive k of ONE row: lane (j = lane & 15, q = lane >> 4) reads P[row(j)][k0 + 4q .. +3],
+// so a wave instruction covers 16 rows x 16 k and register component s is the operand of the MFMA that takes
+// k in {k0 + s, k0 + 4 + s, k0 + 8 + s, k0 + 12 + s} (A and B permuted alike) -- four MFMA k-steps per load, the unit of the
+// ring is therefore a CHUNK of 16 k.  Which matrix row a lane reads is free: A blocks take rows m0 + 16 i + j, B loads take
+// rows n0 + 4 j + f (f = 0..3), which makes the accumulators
+//     acc[i][f][t] = C[m0 + 16 i + 4 q + t][n0 + 4 r + f]
+// -- again four consecutive columns per lane.  k past K lies inside the next row (no range check helps): the chunks that
+// reach past K are masked with selects (one or two per tile).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int TMB, int NB, int D, int EPI>
+__global__ __launch_bounds__(512, 2) void dr_nt_kernel(const DrArgs d) {
+    static_assert(EPI == GD_EPI_BIAS_ACT || EPI == GD_EPI_LOSS || EPI == GD_EPI_POST, "forward products");
+    static_assert(NB == 4 || NB == 2, "B loads per chunk: 16 NB output columns, NB consecutive ones per lane");
+    constexpr int LPC = TMB + NB;   // loads per chunk
+    constexpr int R = D + 1;
+    constexpr int NM = 4 * TMB * NB;  // MFMAs per chunk
+    constexpr int SP = NM / (LPC + 1);  // the LPC loads of chunk c + D ride behind MFMA 2, 2 + SP, ...; then the cursor step
+    static_assert(SP >= 2 && SP * LPC + 1 < NM, "loads and cursor step must fall inside the chunk");
+    static_assert(LPC * D <= 63, "vmcnt is a 6-bit counter");
+    const GdGemm& g = d.g;
+    const int lane = threadIdx.x & 63;
+    const int r = lane & 15, q = lane >> 4;
+    const int ntiles = d.tiles_m * d.tiles_n;
+    unsigned int* ctr = &g_dr_ticket[d.ctr];
+    const int n_waves = gridDim.x * 8;
+    int cur = __builtin_amdgcn_readfirstlane(blockIdx.x * 8 + (threadIdx.x >> 6));
+    if (cur >= ntiles) return;
+    if (d.stagger > 0 && __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256)
+        for (int i = 0; i < d.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    const int NCP = d.ksp;  // chunks run per tile (a multiple of R)
+    const i32x4 srdA = dr_srd(g.A, (uint32_t)(((int64_t)(g.M - 1) * g.lda + g.K) * 4));
+    const i32x4 srdB = dr_srd(g.B, (uint32_t)(((int64_t)(g.N - 1) * g.ldb + g.K) * 4));
+
+    uint32_t offA[TMB], offB[NB];
+    uint32_t kc = 0;  // byte offset of the chunk to load next (soffset, the same for both operands)
+    int l_left = NCP;
+    auto set_cursor = [&](int tile) {
+        const bool ok = tile < ntiles;
+        const int tm = tile % d.tiles_m, tn = tile / d.tiles_m;  // the row tiles of one column panel draw consecutive tickets
+#pragma unroll
+        for (int i = 0; i < TMB; ++i) offA[i] = ok ? (uint32_t)((tm * (16 * TMB) + 16 * i + r) * g.lda + 4 * q) * 4u : 0xFFFFFFF0u;
+#pragma unroll
+        for (int f = 0; f < NB; ++f) offB[f] = ok ? (uint32_t)((tn * (16 * NB) + NB * r + f) * g.ldb + 4 * q) * 4u : 0xFFFFFFF0u;
+        kc = 0;
+        l_left = NCP;
+    };
+    set_cursor(cur);
+    f32x4 xa[R][TMB], xb[R][NB];
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+#pragma unroll
+        for (int i = 0; i < TMB; ++i) xa[u][i] = dr_load(srdA, offA[i], kc);
+#pragma unroll
+        for (int f = 0; f < NB; ++f) xb[u][f] = dr_load(srdB, offB[f], kc);
+        kc += 64;
+        --l_left;
+    }
+    const int q1 = (NCP / R / 4) * R, q2 = (NCP / R / 2) * R, q3 = (NCP / R * 3 / 4) * R;
+    const int c_mask = g.K >> 4;  // first chunk that reaches past K (== chunks when K % 16 == 0: then only padded chunks)
+    for (;;) {
+        unsigned int tick = dr_ticket_issue(ctr);
+        int nxt = 0;
+        const int tm = cur % d.tiles_m, tn = cur / d.tiles_m;
+        const int m0 = tm * 16 * TMB, n0 = tn * (16 * NB);
+        f32x4 acc[TMB][NB];
+#pragma unroll
+        for (int i = 0; i < TMB; ++i)
+#pragma unroll
+            for (int f = 0; f < NB; ++f) acc[i][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_s_setprio(0);
+        for (int c0 = 0; c0 < NCP; c0 += R) {
+            if (c0 == q1) __builtin_amdgcn_s_setprio(1);
+            else if (c0 == q2) __builtin_amdgcn_s_setprio(2);
+            else if (c0 == q3) __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+            for (int u = 0; u < R; ++u) {
+                const int v = (u + D) % R;
+                dr_wait<LPC*(D - 1)>();
+#pragma unroll
+                for (int i = 0; i < TMB; ++i) asm volatile("" : "+v"(xa[u][i]));
+#pragma unroll
+                for (int f = 0; f < NB; ++f) asm volatile("" : "+v"(xb[u][f]));
+                if (c0 + u >= c_mask) {  // uniform; the last chunk(s) of a tile only: zero every k >= K
+                    const int kq = (c0 + u) * 16 + 4 * q;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool keep = kq + e < g.K;
+#pragma unroll
+                        for (int i = 0; i < TMB; ++i) xa[u][i][e] = keep ? xa[u][i][e] : 0.f;
+#pragma unroll
+                        for (int f = 0; f < NB; ++f) xb[u][f][e] = keep ? xb[u][f][e] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int n = 0; n < NM; ++n) {
+                    const int e = n / (TMB * NB), i = (n / NB) % TMB, f = n % NB;
+                    acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[u][i][e], xb[u][f][e], acc[i][f], 0, 0, 0);
+                    if (n % SP == 1 && n / SP < LPC) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        const int l = n / SP;
+                        if (l < TMB) xa[v][l] = dr_load(srdA, offA[l], kc);
+                        else xb[v][l - TMB] = dr_load(srdB, offB[l - TMB], kc);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (n == SP * LPC + 1) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        kc += 64;
+                        if (--l_left == 0) {
+                            if (NCP < 2 * D + 2) dr_wait<0>();
+                            asm volatile("" : "+v"(tick));
+                            const int tk = __builtin_amdgcn_readfirstlane(tick);
+                            if (tk == ntiles - 1 && lane == 0) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            nxt = n_waves + tk;
+                            set_cursor(nxt);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- epilogue.  acc[i][f][t] = C[m0 + 16 i + 4 q + t][n0 + NB r + f]: the lane owns NB consecutive columns of 4 TMB rows ----
+        typedef float vecnb __attribute__((ext_vector_type(NB)));
+        typedef vecnb vecnb_u __attribute__((aligned(4)));
+        const int n = n0 + NB * r;
+        const bool full = n + NB - 1 < g.N;
+        float biasv[NB];
+#pragma unroll
+        for (int f = 0; f < NB; ++f) biasv[f] = g.bias ? g.bias[min(n + f, g.N - 1)] : 0.f;
+        const bool has_z = (EPI == GD_EPI_POST) && (g.aux2 != nullptr);
+        const bool has_r = (EPI == GD_EPI_POST) && (g.r2 != nullptr);
+        auto put = [&](float* base, int64_t ld, int m, const float (&val)[NB]) {  // NB consecutive columns of row m (m < M)
+            if (full) {
+                vecnb w;
+#pragma unroll
+                for (int f = 0; f < NB; ++f) w[f] = val[f];
+                *reinterpret_cast<vecnb_u*>(base + (int64_t)m * ld + n) = w;
+            } else {
+                for (int f = 0; f < NB; ++f)
+                    if (n + f < g.N) base[(int64_t)m * ld + n + f] = val[f];
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < TMB; ++i) {
+            float racc[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int m = m0 + 16 * i + 4 * q + t;
+                const int mc = min(m, g.M - 1);
+                const bool mok = m < g.M;
+                float v4[NB];
+#pragma unroll
+                for (int f = 0; f < NB; ++f) v4[f] = acc[i][f][t] + biasv[f];
+                racc[t] = 0.f;
+                if (EPI == GD_EPI_BIAS_ACT) {
+                    if (g.act == 1) {
+#pragma unroll
+                        for (int f = 0; f < NB; ++f) v4[f] = tanhf(v4[f]);
+                    }
+                    if (mok) put(g.C, g.ldc, m, v4);
+                } else if (EPI == GD_EPI_LOSS) {
+                    const float c1 = g.r0 ? g.r0[mc] : 1.f;
+                    float tg[NB];
+                    if (g.aux_bits) {
+                        // {0,1} target rows as bitmaps: the lane's columns are NB bits of one word (n is a multiple of NB)
+                        const uint32_t w = g.aux_bits[(int64_t)mc * g.ldbits + min((int64_t)(n >> 5), g.ldbits - 1)];
+#pragma unroll
+                        for (int f = 0; f < NB; ++f) tg[f] = (float)((w >> ((n & 31) + f)) & 1u);
+                    } else {
+#pragma unroll
+                        for (int f = 0; f < NB; ++f) tg[f] = g.aux[(int64_t)mc * g.ldaux + min(n + f, g.N - 1)];
+                    }
+                    float dd[NB], ss = 0.f;
+#pragma unroll
+                    for (int f = 0; f < NB; ++f) {
+                        dd[f] = c1 * v4[f] - tg[f];
+                        if (mok && n + f < g.N) ss += dd[f] * dd[f];
+                    }
+                    if (mok) {
+                        put(g.C, g.ldc, m, dd);
+                        if (g.out2) put(g.out2, g.ldout2, m, v4);
+                    }
+                    racc[t] = ss;
+                } else {  // GD_EPI_POST
+                    const float c1 = g.r0[mc], c2 = g.r1[mc];
+                    const float p1 = has_r ? g.r2[mc] : 0.f, p2 = has_r ? g.r3[mc] : 0.f;
+                    const float sg = has_z ? g.r4[mc] : 0.f;
+                    float pr[NB], mn[NB];
+#pragma unroll
+                    for (int f = 0; f < NB; ++f) {
+                        const int nf = min(n + f, g.N - 1);
+                        const float xt = g.aux[(int64_t)mc * g.ldaux + nf];
+                        const float zz = has_z ? g.aux2[(int64_t)mc * g.ldaux2 + nf] : 0.f;
+                        pr[f] = has_r ? (p1 * xt - p2 * v4[f]) : v4[f];
+                        mn[f] = c1 * pr[f] + c2 * xt;
+                        if (has_z) mn[f] += sg * zz;
+                    }
+                    if (mok) {
+                        put(g.C, g.ldc, m, mn);
+                        if (g.out2) put(g.out2, g.ldout2, m, pr);
+                    }
+                }
+            }
+            if (EPI == GD_EPI_LOSS) {
+                // per-row sum of squares over the tile's columns: the 16 lanes r of a q-group hold one row
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    float sv = racc[t];
+                    sv += __shfl_xor(sv, 1);
+                    sv += __shfl_xor(sv, 2);
+                    sv += __shfl_xor(sv, 4);
+                    sv += __shfl_xor(sv, 8);
+                    const int m = m0 + 16 * i + 4 * q + t;
+                    if (r == 0 && m < g.M) g.rowpart[(int64_t)m * g.ld_rowpart + tn] = sv;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);  // one block of rows at a time: keeps the epilogue's live registers bounded
+        }
+        if (nxt >= ntiles) break;
+        cur = nxt;
+    }
+    dr_wait<0>();
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+#pragma unroll
+        for (int i = 0; i < TMB; ++i) asm volatile("" ::"v"(xa[u][i]));
+#pragma unroll
+        for (int f = 0; f < NB; ++f) asm volatile("" ::"v"(xb[u][f]));
+    }
+}
+
+// tile = 16 TMB rows x 16 NB columns; D chunks in flight beside the one being multiplied (ring of D + 1 slots)
+template <int TMB, int NB, int D, int EPI>
+void dr_nt_go(const DrArgs& d, int n_cu, hipStream_t s) {
+    hipLaunchKernelGGL((dr_nt_kernel<TMB, NB, D, EPI>), dim3(n_cu), dim3(512), 0, s, d);
+}
+
+int dr_cu_count_fwd();
 template <int D, int EPI>
 void dr_tn_go(const DrArgs& d, hipStream_t s) {
+    hipLaunchKernelGGL((dr_tn_kernel<1, 1, D, EPI>), dim3(dr_cu_count_fwd()), dim3(512), 0, s, d);
+}
+
+}  // namespace
+
+static int dr_cu_count();
+namespace { int dr_cu_count_fwd() { return dr_cu_count(); } }
+static int dr_cu_count() {
     static int n_cu = 0;
     if (n_cu == 0) {
         int dev = 0;
         hipDeviceProp_t prop;
         n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
     }
-    hipLaunchKernelGGL((dr_tn_kernel<1, 1, D, EPI>), dim3(n_cu), dim3(512), 0, s, d);
+    return n_cu;
 }
-
-}  // namespace
 
 // Returns GD_DR_NOT_TAKEN when the product is not one this file handles (the caller falls back to the LDS-tiled kernels).
 int gd_gemm_dr_launch(int layA, int layB, int epi, GdGemm& g, hipStream_t s) {
-    static const bool on = !(getenv("GDMCF_GEMM_DR") && atoi(getenv("GDMCF_GEMM_DR")) == 0);
+    static const int on = getenv("GDMCF_GEMM_DR") ? atoi(getenv("GDMCF_GEMM_DR")) : 1;  // bit 0: weight gradients (default), bit 1: forward
+    // products (opt-in: measured SLOWER than the LDS-tiled kernels -- 0.279 vs 0.270 ms for the Yelp loss product: a K-contiguous
+    // operand costs 16 half-line L1 accesses per load instead of 8 full lines, TCP accesses x3.6, 20 % of the wave cycles waiting)
     if (!on || g.bf16) return GD_DR_NOT_TAKEN;
-    if (!(layA == GD_LAY_MC && layB == GD_LAY_MC && (epi == GD_EPI_STORE || epi == GD_EPI_ADAMW))) return GD_DR_NOT_TAKEN;
     if (g.accumulate || g.splits > 1 || g.C16) return GD_DR_NOT_TAKEN;
-    // 32-bit byte offsets inside every matrix; enough tiles for the persistent waves to be worth it
-    const int64_t lim = (int64_t)1 << 32;
-    if ((int64_t)g.K * g.lda * 4 >= lim || (int64_t)g.K * g.ldb * 4 >= lim || (int64_t)g.M * g.ldc * 4 >= lim) return GD_DR_NOT_TAKEN;
-    if (g.lda < g.M || g.ldb < g.N || g.ldc < g.N || g.K < 1) return GD_DR_NOT_TAKEN;
-    const long tiles = (long)gd_cdiv(g.M, 64) * gd_cdiv(g.N, 64);
-    if (tiles < 512 || g.K < 128) return GD_DR_NOT_TAKEN;  // (short reductions: a tile is all prologue; the LDS-tiled kernels take them)
-    DrArgs d = {};
-    d.g = g;
-    d.tiles_m = gd_cdiv(g.M, 64);
-    d.tiles_n = gd_cdiv(g.N, 64);
-    d.m_fastest = d.tiles_m <= d.tiles_n;  // tiles that share the LARGER operand's panel draw consecutive tickets
-    d.ctr = g.prof_tag & 31;
     static const int stagger = getenv("GDMCF_DR_STAGGER") ? atoi(getenv("GDMCF_DR_STAGGER")) : 3;
+    const int64_t lim = (int64_t)1 << 32;  // 32-bit byte offsets inside every matrix
+    DrArgs d = {};
+    d.ctr = g.prof_tag & 31;
     d.stagger = stagger;
-    const int ks = gd_cdiv(g.K, 4);
-    // ring depth: the one whose size wastes the fewest padded steps per tile
-    int best = 9, waste = 1 << 30;
-    for (int dd : {9, 8, 7}) {
-        const int w = gd_cdiv(ks, dd + 1) * (dd + 1) - ks;
-        if (w < waste) { waste = w; best = dd; }
-    }
-    d.ksp = ks + waste;
-    g.tiles_m = d.tiles_m;
-    g.tiles_n = d.tiles_n;
-    {
-        GdProfScope prof(g.prof_tag, 2.0 * g.M * g.N * g.K, s);
+    if ((on & 1) && layA == GD_LAY_MC && layB == GD_LAY_MC && (epi == GD_EPI_STORE || epi == GD_EPI_ADAMW)) {
+        if ((int64_t)g.K * g.lda * 4 >= lim || (int64_t)g.K * g.ldb * 4 >= lim || (int64_t)g.M * g.ldc * 4 >= lim) return GD_DR_NOT_TAKEN;
+        if (g.lda < g.M || g.ldb < g.N || g.ldc < g.N) return GD_DR_NOT_TAKEN;
+        const long tiles = (long)gd_cdiv(g.M, 64) * gd_cdiv(g.N, 64);
+        if (tiles < 512 || g.K < 128) return GD_DR_NOT_TAKEN;  // (short reductions: a tile is all prologue; the LDS-tiled kernels take them)
+        d.tiles_m = gd_cdiv(g.M, 64);
+        d.tiles_n = gd_cdiv(g.N, 64);
+        d.m_fastest = d.tiles_m <= d.tiles_n;  // tiles that share the LARGER operand's panel draw consecutive tickets
+        const int ks = gd_cdiv(g.K, 4);
+        // ring depth: the one whose size wastes the fewest padded steps per tile
+        int best = 9, waste = 1 << 30;
+        for (int dd : {9, 8, 7}) {
+            const int w = gd_cdiv(ks, dd + 1) * (dd + 1) - ks;
+            if (w < waste) { waste = w; best = dd; }
+        }
+        d.ksp = ks + waste;
+        g.tiles_m = d.tiles_m;
+        g.tiles_n = d.tiles_n;
+        d.g = g;
+        {
+            GdProfScope prof(g.prof_tag, 2.0 * g.M * g.N * g.K, s);
 #define GD_DR_GO(DD)                                                      \
     do {                                                                  \
         if (epi == GD_EPI_STORE) dr_tn_go<DD, GD_EPI_STORE>(d, s);        \
         else dr_tn_go<DD, GD_EPI_ADAMW>(d, s);                            \
     } while (0)
-        if (best == 9) GD_DR_GO(9);
-        else if (best == 8) GD_DR_GO(8);
-        else GD_DR_GO(7);
+            if (best == 9) GD_DR_GO(9);
+            else if (best == 8) GD_DR_GO(8);
+            else GD_DR_GO(7);
 #undef GD_DR_GO
+        }
+        return gd_launch_status("gemm_dr");
     }
-    return gd_launch_status("gemm_dr");
+    if ((on & 2) && layA == GD_LAY_KC && layB == GD_LAY_KC && (epi == GD_EPI_LOSS || epi == GD_EPI_POST)) {
+        if ((int64_t)g.M * g.lda * 4 >= lim || (int64_t)g.N * g.ldb * 4 >= lim) return GD_DR_NOT_TAKEN;
+        if (g.lda < g.K || g.ldb < g.K || g.K < 256) return GD_DR_NOT_TAKEN;
+        // batch-sized M in blocks of 16 rows: 5 blocks (80 rows) when that pads little (400 = 5 x 80), else 4
+        const int tmb = ((long)gd_cdiv(g.M, 80) * 80 * 100 <= (long)gd_cdiv(g.M, 64) * 64 * 103) ? 5 : 4;
+        // 64-column tiles halve the operand traffic per FLOP, 32-column tiles quantise better over 1 024 SIMDs (Yelp loss product:
+        // 2 690 tiles of 80 x 64 = 2.6 per SIMD against 5 375 of 80 x 32)
+        static const int nb_env = getenv("GDMCF_DR_NB") ? atoi(getenv("GDMCF_DR_NB")) : 0;
+        const int n_cu = dr_cu_count();
+        int nb = 4;
+        {
+            const long t4 = (long)gd_cdiv(g.M, 16 * tmb) * gd_cdiv(g.N, 64);
+            const long per = (t4 + 4 * n_cu - 1) / (4 * n_cu);           // rounds of one tile per SIMD
+            if (t4 * 100 < per * 4 * n_cu * 92 && per < 6) nb = 2;       // the last round would be < 92 % full
+        }
+        if (nb_env == 2 || nb_env == 4) nb = nb_env;
+        d.tiles_m = gd_cdiv(g.M, 16 * tmb);
+        d.tiles_n = gd_cdiv(g.N, 16 * nb);
+        if ((long)d.tiles_m * d.tiles_n < 1024) return GD_DR_NOT_TAKEN;
+        if (epi == GD_EPI_LOSS && (g.ld_rowpart < d.tiles_n || g.rowpart == nullptr)) return GD_DR_NOT_TAKEN;
+        if (epi == GD_EPI_LOSS && g.aux_bits && g.ldbits < (g.N + 31) / 32) return GD_DR_NOT_TAKEN;
+        d.m_fastest = 1;
+        const int nc = gd_cdiv(g.K, 16);
+        const int ring = nb == 4 ? 2 : 3;
+        d.ksp = gd_cdiv(nc, ring) * ring;  // a multiple of the ring size
+        g.tiles_m = d.tiles_m;
+        g.tiles_n = d.tiles_n;
+        d.g = g;
+        {
+            GdProfScope prof(g.prof_tag, 2.0 * g.M * g.N * g.K, s);
+#define GD_DR_NT(T, NBV, DV)                                                            \
+    do {                                                                                \
+        if (epi == GD_EPI_LOSS) dr_nt_go<T, NBV, DV, GD_EPI_LOSS>(d, n_cu, s);          \
+        else dr_nt_go<T, NBV, DV, GD_EPI_POST>(d, n_cu, s);                             \
+    } while (0)
+            if (tmb == 5 && nb == 4) GD_DR_NT(5, 4, 1);
+            else if (tmb == 5) GD_DR_NT(5, 2, 2);
+            else if (nb == 4) GD_DR_NT(4, 4, 1);
+            else GD_DR_NT(4, 2, 2);
+#undef GD_DR_NT
+        }
+        return gd_launch_status("gemm_dr");
+    }
+    return GD_DR_NOT_TAKEN;
 }

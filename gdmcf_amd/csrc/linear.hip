@@ -114,7 +114,7 @@ size_t gdmcf_linear_ws_bytes(int M, int N, int K) {
     return need * sizeof(float) + 256;
 }
 
-int gdmcf_loss_tiles(int N) { return gd_cdiv(N, 64); }
+int gdmcf_loss_tiles(int N) { return gd_cdiv(N, 16); }  // partial row sums per output tile: the narrowest tile any kernel uses
 
 int gdmcf_linear_fwd_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias, int act, int M,
                          int N, int K, float* C, int64_t ldc, void* ws, size_t ws_bytes, void* stream) {

@@ -73,6 +73,9 @@ def counters(path):
 import re
 
 TAG_RULES = [
+    (r"^dr_tn_kernel<", "bwd_weight_gemm"),
+    (r"^dr_nt_kernel<.*, 2>$", "loss_fwd_gemm"),
+    (r"^dr_nt_kernel<.*, 3>$", "posterior_gemm"),
     (r"^gemm_f32_spec_kernel<1, 1,", "bwd_weight_gemm"),
     (r"^gemm_f32_kernel<0, 0, .*, 2>$", "loss_fwd_gemm"),
     (r"^gemm_f32_kernel<0, 0, .*, 3>$", "posterior_gemm"),

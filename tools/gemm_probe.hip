@@ -35,7 +35,8 @@ void gdmcf_set_error(const char* fmt, ...) {
     } while (0)
 
 int main(int argc, char** argv) {
-    const int B = 400, I = 34395, H = 1000, E = 10, ldk = 34432, ldi = 34432, ldh = 1024;
+    const int B = 400, I = 34395, H = 1000, E = 10, ldk = 34432, ldi = 34432;
+    const int ldh = getenv("GD_LDH") ? atoi(getenv("GD_LDH")) : 1024;  // leading dimension of the hidden activations
     const int reps = argc > 1 ? atoi(argv[1]) : 20;
     float *xin, *W1, *W2, *h, *diff, *slab, *dW1, *dW2, *tgt, *rowpart;
     CK(hipMalloc(&xin, (size_t)B * ldk * 4));
@@ -47,8 +48,8 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&slab, (size_t)64 * B * 1024 * 4));  // up to 64 splits
     CK(hipMalloc(&dW1, (size_t)H * (I + E) * 4));
     CK(hipMalloc(&dW2, (size_t)I * H * 4));
-    CK(hipMalloc(&rowpart, (size_t)B * 1024 * 4));
-    CK(hipMemset(rowpart, 0, (size_t)B * 1024 * 4));
+    CK(hipMalloc(&rowpart, (size_t)B * 2200 * 4));
+    CK(hipMemset(rowpart, 0, (size_t)B * 2200 * 4));
     std::vector<float> init((size_t)I * H);
     srand(1);
     for (auto& v : init) v = (rand() / (float)RAND_MAX - 0.5f) * 0.02f;
@@ -73,7 +74,7 @@ int main(int argc, char** argv) {
     }
     {   // GEMM2 + loss
         GdGemm g = {}; g.A = h; g.lda = ldh; g.B = W2; g.ldb = H; g.M = B; g.N = I; g.K = H; g.splits = 1; g.m_fastest = 1;
-        g.aux = tgt; g.ldaux = I; g.C = diff; g.ldc = ldi; g.rowpart = rowpart; g.ld_rowpart = 1024;
+        g.aux = tgt; g.ldaux = I; g.C = diff; g.ldc = ldi; g.rowpart = rowpart; g.ld_rowpart = 2200;
         cases.push_back({"gemm2_loss", GD_LAY_KC, GD_LAY_KC, GD_EPI_LOSS, 0, g});
     }
     {   // dh = diff * W2
