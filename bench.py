@@ -105,6 +105,9 @@ def parse():
     ap.add_argument("--no-configs2-leg", action="store_true",
                     help="N = 1: skip the BASELINE configs[2] leg (Amazon-Book shape, bf16 GEMM inputs, B = 400)")
     ap.add_argument("--no-graph-leg", action="store_true", help="N = 1: skip the extra leg that replays the step from a hipGraph")
+    ap.add_argument("--graph-dp", action="store_true",
+                    help="N > 1: also time the data-parallel step (all-reduce exchange) replayed from one hipGraph per rank, RCCL "
+                         "calls captured (default on with --rehearse-dp)")
     ap.add_argument("--bpr", action="store_true", help="also time a LightGCN BPR training step (reported under 'bpr')")
     ap.add_argument("--backbone", default="dnn", choices=["dnn", "onehot", "onehot-emb", "onehot-gcn"],
                     help="dnn: the plain denoiser (BASELINE configs); onehot: GaussianDiffusionDiscrete(CatOneHot=True) + "
@@ -506,11 +509,15 @@ def main():
     # device memory, batch = a fixed id buffer over the resident CSR matrix; bit-identical to the eager step by test).
     # `host_enqueue_ms` is what the host spends per step: one 3 KB id copy + one graph launch. ----
     graph_leg = None
-    if world == 1 and args.backbone == "dnn" and sparse_rows and not args.fuse_optimizer and not args.rehearse_dp \
-            and not args.no_graph_leg:
+    # With --rehearse-dp (one-rank RCCL group) the captured body includes every collective of the data-parallel step; at N > 1
+    # the leg is opt-in (--graph-dp): all ranks capture the same collectives.
+    graph_dp = (args.rehearse_dp and world == 1) or (world > 1 and args.graph_dp)
+    if (world == 1 or graph_dp) and args.backbone == "dnn" and sparse_rows and not args.fuse_optimizer \
+            and (not args.rehearse_dp or graph_dp) and not args.no_graph_leg:
         from gdmcf_amd.graph import GraphedTrainStep
         try:
-            with GraphedTrainStep(diffusion, model, opt, dcsr, B, warmup=3) as gstep:
+            step.flush()
+            with GraphedTrainStep(diffusion, model, opt, dcsr, B, warmup=3, force_exchange=args.rehearse_dp) as gstep:
                 for i in range(max(5, args.warmup // 4)):
                     gstep(row_ids[i % n_pool])
                 sync()
@@ -520,7 +527,13 @@ def main():
                 hg = time.perf_counter() - t1
                 sync()
                 eg = time.perf_counter() - t1
-            graph_leg = dict(ms_per_step=round(1e3 * eg / args.steps, 4), users_per_s=round(B * args.steps / eg, 1),
+                captured, cap_err = isinstance(gstep.graph, torch.cuda.CUDAGraph), gstep.capture_error
+            if dist.is_initialized():
+                tg = torch.tensor([eg, hg], dtype=torch.float64, device=dev)
+                dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+                eg, hg = float(tg[0]), float(tg[1])
+            graph_leg = dict(captured=captured, capture_error=cap_err, exchange=bool(gstep.step.exchange),
+                             ms_per_step=round(1e3 * eg / args.steps, 4), users_per_s=round(world * B * args.steps / eg, 1),
                              host_enqueue_ms=round(1e3 * hg / args.steps, 4), eager_host_enqueue_ms=round(1e3 * host_el / args.steps, 4),
                              steps=args.steps, final_loss=float(loss_g),
                              what="the training step replayed from one hipGraph (gdmcf_amd.graph.GraphedTrainStep)")

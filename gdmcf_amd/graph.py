@@ -11,8 +11,13 @@ in device memory:
     step state (include/gdmcf_hip.h: gdmcf_graph_state_*), advanced by one tick kernel at the head of the graph; the
     corrections come from a host-computed table, so the updates are bit-identical to the eager path;
   * the Lt-history (already on the device), gradients (persistent buffers: DenoiserEngine.static_grads), the loss.
-Single GPU, plain DNN denoiser, in-kernel Philox randomness, x0 target (what bench.py times); other configurations use
-DataParallelStep.  The first `warmup` calls run eagerly (same kernels, same device state: they are ordinary training steps),
+Plain DNN denoiser, in-kernel Philox randomness, x0 target (what bench.py times); other configurations use DataParallelStep.
+Data parallel (world > 1, backend "nccl" = RCCL; or `force_exchange=True` in a one-rank group, the rehearsal of that path on a
+one-GPU box): the captured body is DataParallelStep's -- the gradient all-reduces and the small float64 exchange are RCCL
+calls on torch's collective stream, forked from and joined to the capturing stream by events, so they become nodes of the
+same graph and the host enqueues ONE launch per step on every rank (the all-reduce exchange; the sharded optimiser defers
+its all-gathers into the NEXT step and stays eager).  If the capture is refused (an RCCL build that cannot be captured), the
+step keeps running eagerly in the same process -- `capture_error` says why -- never a re-exec.  The first `warmup` calls run eagerly (same kernels, same device state: they are ordinary training steps),
 the next call captures and replays.  `close()` (or leaving the `with` block) writes the device counters back into the
 host-side counters (optimizer step counts, Philox offsets) so that eager steps, checkpoints and resumes continue seamlessly.
 """
@@ -28,9 +33,13 @@ from .parallel import DataParallelStep
 
 
 class GraphedTrainStep:
-    def __init__(self, diffusion, model, optimizer, csr, batch_size, reweight=True, warmup=3, table_steps=8192):
-        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
-            raise NotImplementedError("GraphedTrainStep is single-GPU (the gradient exchange is host-driven)")
+    def __init__(self, diffusion, model, optimizer, csr, batch_size, reweight=True, warmup=3, table_steps=8192, group=None,
+                 force_exchange=False):
+        dist = torch.distributed
+        multi = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force_exchange)
+        if multi and dist.get_backend(group) != "nccl":
+            raise NotImplementedError("GraphedTrainStep with a gradient exchange needs the nccl (RCCL) backend: host-staged "
+                                      "collectives cannot be captured")
         if not isinstance(model, DNN) or model.norm or diffusion.mean_type != ModelMeanType.START_X:
             raise NotImplementedError("GraphedTrainStep: plain DNN denoiser without F.normalize, x0 target")
         if getattr(diffusion, "CatOneHot", False) or diffusion.rng != "philox" or diffusion.noise_scale == 0.0:
@@ -47,9 +56,12 @@ class GraphedTrainStep:
         assert self.batch.row_ids.data_ptr() == self.ids.data_ptr()
         self.eng = model.engine
         self.eng.static_grads = True
-        self.step = DataParallelStep(diffusion, model, optimizer)
+        # (constructed BEFORE the AdamW table is uploaded: it sets optimizer.grad_scale = 1 / world)
+        self.step = DataParallelStep(diffusion, model, optimizer, group=group, force_exchange=bool(force_exchange) and multi)
         self.warmup, self.calls, self.graph, self.loss = int(warmup), 0, None, None
+        self.capture_error = None
         self.table_steps = int(table_steps)
+        self._state = None
         self._upload_state()
 
     # -- device step state ---------------------------------------------------------------------------------------------
@@ -63,6 +75,7 @@ class GraphedTrainStep:
         lib, dev = self.lib, self.ids.device
         prep, ts, step = counters if counters is not None else self._host_counters()
         g = self.optimizer.param_groups[0]
+        self._hyper = self._hyper_now()
         hb, sb = lib.gdmcf_adam_hyper_bytes(), lib.gdmcf_graph_state_bytes()
         host_tab = (ctypes.c_ubyte * (hb * self.table_steps))()
         _lib.check(lib.gdmcf_adam_hyper_fill(host_tab, self.table_steps, g["lr"], g["betas"][0], g["betas"][1], g["eps"],
@@ -77,6 +90,11 @@ class GraphedTrainStep:
             self._state.copy_(new)  # same address: the captured graph keeps pointing at it
         self._table_end = step + self.table_steps  # last optimiser step the table covers
         self._dev_step = step                      # host mirror of the device's optimiser step count
+
+    def _hyper_now(self):
+        g = self.optimizer.param_groups[0]
+        return (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
+                float(self.optimizer.grad_scale))
 
     def _read_state(self):
         torch.cuda.synchronize()
@@ -96,21 +114,33 @@ class GraphedTrainStep:
             raise ValueError("GraphedTrainStep: every batch must have the captured batch size")
         self.ids.copy_(row_ids, non_blocking=True)
         self.calls += 1
-        if self.graph is None:
+        # the AdamW scalars of the coming steps sit in a device table computed from the optimizer's hyper-parameters: a changed
+        # learning rate (scheduler, manual edit) or an exhausted table means a new table -- same address, the graph stays valid
+        if self._hyper_now() != self._hyper or self._dev_step + 1 > self._table_end:
+            self._upload_state(self._read_state())
+        if self.graph is None or self.graph is False:
             self.lib.gdmcf_graph_state_bind(self._state.data_ptr())
             try:
-                if self.calls <= self.warmup:
+                if self.calls <= self.warmup or self.graph is False:
                     self._dev_step += 1
                     return self._body().clone()
                 self.lib.gdmcf_prof_enable(0)  # event records cannot be captured
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    self.loss = self._body()
-                self.graph = g
+                try:
+                    # RCCL's watchdog thread polls the events of earlier (eager) collectives: under the default "global"
+                    # capture mode such a query from ANOTHER thread is an error that kills the process; thread-local mode
+                    # only polices the capturing thread.  Nothing of the eager steps may still be in flight either way.
+                    torch.cuda.synchronize()
+                    with torch.cuda.graph(g, capture_error_mode="thread_local" if self.step.exchange else "global"):
+                        self.loss = self._body()
+                    self.graph = g
+                except Exception as exc:  # e.g. a collective library that refuses stream capture: stay eager, same process
+                    self.graph, self.capture_error = False, f"{type(exc).__name__}: {exc}"[:300]
+                    torch.cuda.synchronize()
+                    self._dev_step += 1
+                    return self._body().clone()
             finally:
                 self.lib.gdmcf_graph_state_bind(None)
-        elif self._dev_step + 1 > self._table_end:
-            self._upload_state(self._read_state())  # refill the table of AdamW scalars (every `table_steps` steps)
         self.graph.replay()
         self._dev_step += 1
         return self.loss.clone()
@@ -123,7 +153,8 @@ class GraphedTrainStep:
             return
         prep, ts, step = self._read_state()
         self.eng.offset = prep
-        self.diffusion._ts_calls = ts
+        if self.reweight:  # (the sampler's Philox position only moves when importance sampling draws timesteps)
+            self.diffusion._ts_calls = ts
         for st in self.optimizer.state.values():
             if "step" in st:
                 st["step"] = step

@@ -74,3 +74,73 @@ def test_graph_step_rejects_what_it_cannot_capture():
         GraphedTrainStep(eps, model, opt, dcsr, 32)
     with pytest.raises(NotImplementedError):
         GraphedTrainStep(diff, model, torch.optim.AdamW(model.parameters()), dcsr, 32)
+
+
+def _dp_graph_worker(rank, port, out_dir):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    from gdmcf_amd.graph import GraphedTrainStep
+    from gdmcf_amd.parallel import DataParallelStep
+    B, n_graph = 64, 12
+    batches = [torch.from_numpy(np.random.default_rng(300 + k).permutation(500)[:B].astype(np.int64)) for k in range(n_graph)]
+    dcsr, model, diff, opt = _setup("f32")
+    step = DataParallelStep(diff, model, opt, force_exchange=True)
+    assert step.exchange
+    eager_losses = [step(dcsr.batch(b.to(DEV)), True).clone() for b in batches]
+    step.flush()
+    eager = _state(model, diff, opt)
+    dcsr, model, diff, opt = _setup("f32")
+    losses = []
+    with GraphedTrainStep(diff, model, opt, dcsr, B, warmup=3, force_exchange=True) as gstep:
+        assert gstep.step.exchange
+        for b in batches:
+            losses.append(gstep(b))
+        captured, err = isinstance(gstep.graph, torch.cuda.CUDAGraph), gstep.capture_error
+    same = all(torch.equal(a, b) for a, b in zip(eager_losses, losses)) and \
+        all(torch.equal(a, b) for a, b in zip(eager, _state(model, diff, opt)))
+    torch.save(dict(captured=captured, err=err, same=same), os.path.join(out_dir, "dpgraph.pt"))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_step_replayed_from_a_graph_in_a_one_rank_rccl_group(tmp_path):
+    """The data-parallel body (gradient all-reduces + the small float64 exchange through RCCL, history replay on the gathered
+    batch, AdamW with 1/world folded in) captured into ONE hipGraph: a group of one rank with force_exchange=True runs every
+    collective (a one-rank SUM is the identity), so 3 eager + 9 replayed steps must equal 12 eager data-parallel steps bit for
+    bit -- and the capture itself must succeed on this RCCL build."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_dp_graph_worker, args=(port, str(tmp_path)), nprocs=1, join=True)
+    res = torch.load(tmp_path / "dpgraph.pt")
+    assert res["captured"], res["err"]
+    assert res["same"]
+
+
+def test_graph_step_follows_a_changed_learning_rate():
+    """The AdamW scalars of the coming steps live in a device table: a learning-rate change between replays (scheduler) must
+    reach the replayed update (round-2 advisor finding: it was silently ignored until the next table refill)."""
+    from gdmcf_amd.graph import GraphedTrainStep
+    from gdmcf_amd.parallel import DataParallelStep
+    B, n = 64, 10
+    batches = [torch.from_numpy(np.random.default_rng(400 + k).permutation(500)[:B].astype(np.int64)) for k in range(n)]
+    dcsr, model, diff, opt = _setup("f32")
+    step = DataParallelStep(diff, model, opt)
+    for k, b in enumerate(batches):
+        if k == 6:
+            opt.param_groups[0]["lr"] = 3e-4
+        step(dcsr.batch(b.to(DEV)), True)
+    eager = _state(model, diff, opt)
+    dcsr, model, diff, opt = _setup("f32")
+    with GraphedTrainStep(diff, model, opt, dcsr, B, warmup=3) as gstep:
+        for k, b in enumerate(batches):
+            if k == 6:
+                opt.param_groups[0]["lr"] = 3e-4
+            gstep(b)
+        assert isinstance(gstep.graph, torch.cuda.CUDAGraph)
+    for a, b in zip(eager, _state(model, diff, opt)):
+        assert torch.equal(a, b)
