@@ -7,6 +7,7 @@ The .so is kept in-tree (git-ignored) so it travels to the GPU box with the sour
 import concurrent.futures
 import hashlib
 import os
+import re
 import subprocess
 import sys
 
@@ -32,6 +33,65 @@ def _digest():
             h.update(fh.read())
     h.update(" ".join(FLAGS).encode())
     return h.hexdigest()
+
+
+# ---- ISA lint for the register-streaming kernels (gemm_dr.hip: dr_tn_kernel) -----------------------------------------------
+# Their operand ring lives in registers that asm buffer loads write long after the asm statement: hipcc believes the value is
+# there at once.  That is only safe while NO compiler-generated instruction reads or writes such a register other than the
+# MFMAs that consume it as an A / B operand -- a v_mov (PHI copy, e.g. after loop unswitching), a temporary placed in a slot
+# the compiler considers dead, an accumulator rotated through it, or a spill would move stale or half-landed data (seen:
+# single accumulator registers wrong in lanes 12-15 of each row of 16).  The lint makes that invariant a build error.
+_REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+
+
+def _regs(text):
+    out = set()
+    for m in _REG.finditer(text):
+        if m.group(1) is not None:
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def lint_ring_registers(asm_text, kernel_prefix="dr_tn_kernel"):
+    """Returns a list of violations (strings) over every function of `asm_text` whose name contains `kernel_prefix`."""
+    bad, seen = [], 0
+    for m in re.finditer(r"^(\S*%s\S*):[^\n]*\n(.*?)\n\s*s_endpgm" % kernel_prefix, asm_text, flags=re.S | re.M):
+        name, body = m.group(1), m.group(2)
+        seen += 1
+        lines = [ln.split(";")[0].strip() for ln in body.splitlines()]
+        lines = [ln for ln in lines if ln and not ln.endswith(":") and not ln.startswith(".")]
+        ring = set()
+        for ln in lines:
+            if ln.startswith("buffer_load_dwordx4"):
+                ring |= _regs(ln.split(",")[0])
+        if not ring:
+            bad.append(f"{name}: no asm ring loads found (lint out of date?)")
+            continue
+        # loads can be in flight from the first ring load to the final drain (the last s_waitcnt vmcnt(0) of the function):
+        # before and after, the same registers are ordinary temporaries
+        first = next(i for i, ln in enumerate(lines) if ln.startswith("buffer_load_dwordx4"))
+        drains = [i for i, ln in enumerate(lines) if ln.startswith("s_waitcnt") and "vmcnt(0)" in ln]
+        last = drains[-1] if drains and drains[-1] > first else len(lines)
+        for ln in lines[first:last]:
+            mnem, _, ops = ln.partition(" ")
+            parts = [o.strip() for o in ops.split(",")]
+            if mnem.startswith("buffer_load_dwordx4"):
+                if _regs(",".join(parts[1:])) & ring:
+                    bad.append(f"{name}: ring register used as an address: {ln}")
+            elif mnem.startswith("v_mfma"):
+                # accumulators rotated through ring registers: the two pools are no longer separate, nothing below can be checked
+                if (_regs(parts[0]) | _regs(parts[3] if len(parts) > 3 else "")) & ring:
+                    bad.append(f"{name}: MFMA accumulator inside the operand ring: {ln}")
+            elif mnem.startswith(("v_mov", "v_pk_mov", "v_accvgpr", "scratch_", "v_swap")):
+                # a copy / spill of a ring register moves data that may not have landed.  (Other VALU instructions that use a
+                # slot as a temporary between its last MFMA and its next load are legitimate and not flagged.)
+                if _regs(ops) & ring:
+                    bad.append(f"{name}: copy or spill of a ring register: {ln}")
+    if not seen:
+        bad.append(f"no function named *{kernel_prefix}* in the assembly (lint out of date?)")
+    return bad
 
 
 def build(force=False, verbose=True):
@@ -66,6 +126,16 @@ def build(force=False, verbose=True):
             err = err if ("warning:" in err or "error:" in err) else ""  # the remarks (and their source excerpts) are not news
         if verbose and err.strip():
             print(err, file=sys.stderr)
+        if src == "gemm_dr.hip":
+            asm = os.path.join(CSRC, "gemm_dr.lint.s")
+            r2 = subprocess.run([hipcc] + FLAGS + ["-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", asm],
+                                capture_output=True, text=True)
+            if r2.returncode != 0:
+                raise RuntimeError(f"hipcc -S failed for {src}:\n{r2.stderr}")
+            bad = [b for b in lint_ring_registers(open(asm).read()) if "ELi5EEEv" not in b.split(":")[0]]  # (EPI 5 = fused AdamW: not dispatched)
+            os.remove(asm)
+            if bad:
+                raise RuntimeError("gemm_dr.hip: operand-ring invariant violated (see lint_ring_registers):\n  " + "\n  ".join(bad[:12]))
         return obj
 
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:

@@ -583,7 +583,10 @@ int gd_gemm_dr_launch(int layA, int layB, int epi, GdGemm& g, hipStream_t s) {
     DrArgs d = {};
     d.ctr = g.prof_tag & 31;
     d.stagger = stagger;
-    if ((on & 1) && layA == GD_LAY_MC && layB == GD_LAY_MC && (epi == GD_EPI_STORE || epi == GD_EPI_ADAMW)) {
+    // (the fused-AdamW epilogue is compiled but not dispatched: with it hipcc rotates accumulators through ring registers and
+    // copies ring values -- build.py:lint_ring_registers -- i.e. it may move operands that have not landed yet; GDMCF_GEMM_DR=5
+    // forces it for experiments)
+    if ((on & 1) && layA == GD_LAY_MC && layB == GD_LAY_MC && (epi == GD_EPI_STORE || (epi == GD_EPI_ADAMW && (on & 4)))) {
         if ((int64_t)g.K * g.lda * 4 >= lim || (int64_t)g.K * g.ldb * 4 >= lim || (int64_t)g.M * g.ldc * 4 >= lim) return GD_DR_NOT_TAKEN;
         if (g.lda < g.M || g.ldb < g.N || g.ldc < g.N) return GD_DR_NOT_TAKEN;
         const long tiles = (long)gd_cdiv(g.M, 64) * gd_cdiv(g.N, 64);

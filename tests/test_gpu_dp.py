@@ -166,12 +166,12 @@ def test_row_sharded_lightgcn_equals_single_process(tmp_path):
     assert r0["rows"][:2] == (0, 252) and r1["rows"][:2] == (252, 504)
 
 
-def _shard_worker(rank, port, out_dir):
+def _shard_worker(rank, port, out_dir, world=WORLD, I2=3001):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
     import gdmcf_amd
     from gdmcf_amd.parallel import DataParallelStep
-    dev, I2, H2, B2 = "cuda:0", 3001, 128, 32  # 3001 rows: one leftover row that every rank updates
+    dev, H2, B2 = "cuda:0", 128, 32  # 3001 rows / 2 ranks: one leftover row that every rank updates (3003 / 4: three)
 
     def run(shard):
         torch.manual_seed(5)
@@ -184,10 +184,10 @@ def _shard_worker(rank, port, out_dir):
             if shard == "toggle":  # bench.py's warm-up autotune: sharded, all-reduce, sharded, all-reduce
                 assert step.set_shard_optimizer(s % 2 == 0) == (s % 2 == 0)
             g = torch.Generator().manual_seed(50 + s)
-            x = (torch.rand(2 * B2, I2, generator=g) < 0.03).float()[rank * B2:(rank + 1) * B2].to(dev)
-            ts = torch.randint(0, T, (2 * B2,), generator=g)[rank * B2:(rank + 1) * B2].to(dev)
-            noise = torch.randn(2 * B2, I2, generator=g)[rank * B2:(rank + 1) * B2].to(dev)
-            keep = (torch.rand(2 * B2, I2, generator=g) < 0.5).float()[rank * B2:(rank + 1) * B2].to(dev)
+            x = (torch.rand(world * B2, I2, generator=g) < 0.03).float()[rank * B2:(rank + 1) * B2].to(dev)
+            ts = torch.randint(0, T, (world * B2,), generator=g)[rank * B2:(rank + 1) * B2].to(dev)
+            noise = torch.randn(world * B2, I2, generator=g)[rank * B2:(rank + 1) * B2].to(dev)
+            keep = (torch.rand(world * B2, I2, generator=g) < 0.5).float()[rank * B2:(rank + 1) * B2].to(dev)
             losses.append(float(step(x, True, ts=ts, pt=torch.ones(B2, device=dev), noise=noise, drop_mask=keep)))
         step.gather_optimizer_state()
         torch.cuda.synchronize()
@@ -202,7 +202,13 @@ def _shard_worker(rank, port, out_dir):
             and torch.equal(o0.state[a]["exp_avg_sq"], o1.state[b]["exp_avg_sq"]) and o0.state[a]["step"] == o1.state[b]["step"]
         ok = ok and torch.equal(a, c) and torch.equal(o0.state[a]["exp_avg"], o2.state[c]["exp_avg"]) \
             and torch.equal(o0.state[a]["exp_avg_sq"], o2.state[c]["exp_avg_sq"])
-    torch.save(dict(ok=bool(ok), params=[p.detach().cpu() for p in m1.parameters()]), os.path.join(out_dir, f"s{rank}.pt"))
+    # beyond two ranks a ring all-reduce adds an element's contributions in an order that depends on where the element sits in
+    # the buffer, and the sharded path reduces differently cut buffers: equal up to fp32 summation order, not bit for bit
+    close = st1.shard_optimizer and bool(np.allclose(l0, l1, rtol=1e-6) and np.allclose(l0, l2, rtol=1e-6))
+    for a, b, c in zip(m0.parameters(), m1.parameters(), m2.parameters()):
+        for x, y in ((a, b), (a, c), (o0.state[a]["exp_avg"], o1.state[b]["exp_avg"]), (o0.state[a]["exp_avg_sq"], o1.state[b]["exp_avg_sq"])):
+            close = close and bool(torch.allclose(x, y, rtol=2e-4, atol=1e-6 * float(x.abs().max()) + 1e-12))
+    torch.save(dict(ok=bool(ok), close=bool(close), params=[p.detach().cpu() for p in m1.parameters()]), os.path.join(out_dir, f"s{rank}.pt"))
     dist.destroy_process_group()
 
 
@@ -218,6 +224,20 @@ def test_sharded_optimizer_equals_all_reduce_path(tmp_path):
     assert r0["ok"] and r1["ok"]
     for a, b in zip(r0["params"], r1["params"]):
         assert torch.equal(a, b)
+
+
+def test_sharded_optimizer_world4_with_leftover_rows(tmp_path):
+    """The same through FOUR ranks (gloo, all on the one GPU of the test box) and a weight of 3003 rows: 750 rows per rank
+    + 3 leftover rows that every rank updates from the all-reduced tail -- `R mod world != 0` beyond world 2."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_shard_worker, args=(port, str(tmp_path), 4, 3003), nprocs=4, join=True)
+    rs = [torch.load(tmp_path / f"s{r}.pt") for r in range(4)]
+    assert all(r["close"] for r in rs)  # (bit-identical only for two ranks: see _shard_worker)
+    for r in rs[1:]:
+        for a, b in zip(rs[0]["params"], r["params"]):
+            assert torch.equal(a, b)
 
 
 def _rccl_worker(rank, port, out_dir):

@@ -196,3 +196,35 @@ def test_two_ranks_of_fifty_rows_match_the_oracle_on_the_global_batch(tmp_path):
     for k in r0["small"]:
         assert torch.equal(r0["small"][k], r1["small"][k])  # replicas stay bit-identical
     assert torch.equal(r0["w2_rows"], r1["w2_rows"])
+
+
+@pytest.mark.parametrize("B,N,K", [(400, 34395, 1000), (400, 1000, 34405), (400, 94949, 1000), (400, 1000, 94959), (256, 5000, 777),
+                                   (130, 4100, 515)])
+def test_weight_gradient_product_every_element_against_float64(B, N, K):
+    """gdmcf_linear_bwd_weight_f32 (dW = dZ^T A, db = sum_m rs_m dZ_m; reference main.py:350) through the C ABI at the shapes
+    the register-streaming kernel serves (csrc/gemm_dr.hip: operands travel in registers that hand-counted waits guard), EVERY
+    element against a float64 product, three launches each: a compiler-inserted copy of such a register -- seen during
+    development -- shows up as a handful of elements off by O(1) among tens of millions, which sampled checks miss.
+    Also: bit-identical from launch to launch (dynamic tile queue, fixed arithmetic)."""
+    from gdmcf_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device="cpu").manual_seed(B + N + K)
+    ldz, lda = (N + 63) // 64 * 64, (K + 63) // 64 * 64
+    dZ = torch.randn(B, ldz, generator=g).to(DEV)
+    A = torch.randn(B, lda, generator=g).to(DEV)
+    rs = (torch.rand(B, generator=g) + 0.5).to(DEV)
+    ref = dZ[:, :N].double().t() @ A[:, :K].double()
+    scale = float(ref.abs().max())
+    outs = []
+    for use_db, use_rs in [(0, 0), (1, 0), (1, 1)]:
+        dW = torch.full((N, K), float("nan"), device=DEV)
+        db = torch.full((N,), float("nan"), device=DEV)
+        _lib.check(lib.gdmcf_linear_bwd_weight_f32(dZ.data_ptr(), ldz, A.data_ptr(), lda, rs.data_ptr() if use_rs else None, B, N, K,
+                                                   dW.data_ptr(), K, db.data_ptr() if use_db else None, 0, _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        assert float((dW.double() - ref).abs().max()) <= 2e-6 * scale * max(1.0, (B / 400) ** 0.5), (use_db, use_rs)
+        if use_db:
+            dref = (dZ[:, :N].double() * (rs.double()[:, None] if use_rs else 1.0)).sum(0)
+            assert float((db.double() - dref).abs().max()) <= 2e-6 * float(dref.abs().max()), (use_db, use_rs)
+        outs.append(dW)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])

@@ -477,6 +477,12 @@ def test_bench_gpus_n_starts_n_ranks_or_fails_loudly():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["ranks_in_group"] == 2 and line["dry_run"] is True
+    # the driver's largest case: eight ranks of one node (dry run: they only have to find each other and report as eight)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["ranks_in_group"] == 8 and line["dry_run"] is True
     # launched as ONE rank but asked for two GPUs: refuse (before anything touches a GPU)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="1", RANK="0"),
                        capture_output=True, text=True, timeout=300)

@@ -133,3 +133,42 @@ def test_row_collectives_world2(tmp_path):
     assert torch.equal(q0["full"], want) and torch.equal(q1["full"], want)
     want_t = torch.cat([torch.zeros(4, 2), torch.ones(3, 2)])
     assert torch.equal(q0["table"], want_t) and torch.equal(q1["table"], want_t)
+
+
+def _shard4_worker(rank, port, out_dir):
+    """What DataParallelStep._sink / _finish_exchange do to ONE large weight gradient under shard_optimizer=True, with the
+    product's collectives, on a weight whose row count is NOT a multiple of the world size (world 4, 11 rows: blocks of
+    2 rows per rank + 3 leftover rows that every rank updates from an all-reduced gradient).  The update rule is a stand-in
+    (w -= lr * g / world; the AdamW kernel needs the GPU): what is under test is the row arithmetic and the exchange."""
+    world = 4
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    R, C, lr = 11, 5, 0.1
+    w = torch.arange(R * C, dtype=torch.float32).reshape(R, C) / 7.0          # identical replicas
+    g = torch.Generator().manual_seed(40 + rank)
+    grad = torch.randn(R, C, generator=g)                                      # this rank's local gradient
+    n_eq = R // world * world
+    shard, h = parallel.reduce_scatter_rows(grad[:n_eq].contiguous())
+    tail = grad[n_eq:].clone()
+    parallel._all_reduce(tail, None)
+    if h is not None:
+        h.wait()
+    nr = n_eq // world
+    w[rank * nr:(rank + 1) * nr] -= lr * shard / world                         # own block
+    w[n_eq:] -= lr * tail / world                                              # leftover rows: every rank, same values
+    h = parallel.all_gather_rows_inplace(w[:n_eq])
+    if h is not None:
+        h.wait()
+    torch.save(dict(grad=grad, w=w), os.path.join(out_dir, f"w4_{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_sharded_update_world4_with_leftover_rows(tmp_path):
+    port = _free_port()
+    mp.spawn(_shard4_worker, args=(port, str(tmp_path)), nprocs=4, join=True)
+    rs = [torch.load(tmp_path / f"w4_{r}.pt") for r in range(4)]
+    total = sum(r["grad"] for r in rs)
+    want = torch.arange(11 * 5, dtype=torch.float32).reshape(11, 5) / 7.0 - 0.1 * total / 4
+    for r in rs:
+        np.testing.assert_allclose(r["w"].numpy(), want.numpy(), rtol=1e-6, atol=1e-6)
+        assert torch.equal(r["w"], rs[0]["w"])  # replicas bit-identical
