@@ -41,7 +41,7 @@ PEAK_HBM_GBPS = 8000.0
 TAGS = {1: "linear_fwd_gemm", 2: "loss_fwd_gemm", 3: "posterior_gemm", 4: "bwd_input_gemm", 5: "bwd_weight_gemm",
         6: "adamw", 7: "prep_input", 8: "spmm_csr", 9: "topk", 10: "onehot_noise"}
 GEMM_TAGS = (1, 2, 3, 4, 5)
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")
 
 
 def measured_traffic(kernel_tag, workload, gemm_dtype="f32"):
@@ -572,7 +572,7 @@ def main():
                         traffic=traffic, traffic_source=traffic_note, kernel=k0["kernel"], avg_ms=k0["avg_ms"],
                         launches_per_step=k0["launches"] // max(n_profiled, 1), profiled_steps=n_profiled,
                         traffic_unit="HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE passes of this "
-                                     "command (profiles/r02_hbm_traffic.json)",
+                                     "command (profiles/r03_hbm_traffic.json)",
                         algorithmic_unit=("2*M*N*K FLOP per launch" if k0["bound"] == "mfma" else
                                           "compulsory bytes per launch (operands and results once; AdamW 28 B/param)"))
 
@@ -756,9 +756,18 @@ def bench_spmm(gdmcf_amd, lib, workload, dev, layers=3, d=64, iters=20, world=1)
     gbps = alg / (ms * 1e-3) / 1e9
     sched = "streamed (one launch + combine)" if getattr(m, "_streamed", False) else \
         "bundled" if getattr(m, "_bundled", False) else "virtual rows (short / long / combine launches)"
+    # second fraction: what the kernel has to move is one d*4-byte row PER NONZERO; the chip's rate for random
+    # rows of that size depends on the table size (tools/gather_probe.hip, profiles/r02_spmm_gather_probe*.txt)
+    table_mb = N * d * 4 / 1e6
+    gather_peak = float(np.interp(table_mb, [4.0, 16.8, 33.0, 268.0], [32.0, 10.0, 8.5, 7.3]))
+    gathered = nnz * d * 4 / (ms * 1e-3) / 1e12
     return dict(ms_per_layer=round(ms, 4), ms_per_propagation=round(wall_ms, 4), row_shards=world, nnz=nnz, nodes=N, d=d,
                 schedule=sched, algorithmic_MB=round(alg / 1e6, 2), gathered_MB=round(nnz * d * 4 / 1e6, 1),
-                gathered_TBps=round(nnz * d * 4 / (ms * 1e-3) / 1e12, 2),
+                gathered_TBps=round(gathered, 2),
+                gather_roofline=dict(table_MB=round(table_mb, 1), achieved=round(gathered, 2), peak=round(gather_peak, 2),
+                                     unit="TB/s of gathered rows", frac=round(gathered / gather_peak, 3),
+                                     peak_source="random 256-byte row gathers from a table of this size, measured "
+                                                 "(tools/gather_probe.hip)"),
                 achieved=round(gbps, 1), peak=PEAK_HBM_GBPS, unit="GB/s", frac=round(gbps / PEAK_HBM_GBPS, 4), bound="hbm")
 
 
