@@ -254,6 +254,13 @@ def launch_ranks(args):
     import socket
     import subprocess
     n = args.gpus
+    # a profiler's preloaded library has initialised the GPU in THIS process before main() ran: starting the ranks from here
+    # would be an exec from a GPU-initialised process (forbidden on this pool).  Profile one rank started directly instead.
+    preload = " ".join(os.environ.get(k, "") for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "ROCPROFILER_LIBRARY_PATH"))
+    if any(tag in preload.lower() for tag in ("rocprof", "roctracer", "rocprofiler")) and not os.environ.get("GDMCF_BENCH_DRY_RUN"):
+        raise SystemExit("bench.py --gpus N under a profiler: the parent would have to start ranks from a GPU-initialised "
+                         "process.  Profile a single rank (rocprofv3 ... -- python bench.py) or launch the ranks with "
+                         "torch.distributed.run and profile inside them.")
     have = torch.cuda.device_count()  # counting devices does not initialise the GPU on this image
     if have < n and not os.environ.get("GDMCF_BENCH_DRY_RUN"):
         raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible; refusing to report an N-GPU line from fewer ranks")

@@ -15,6 +15,7 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 SOURCES = ["capi.hip", "dp_exchange.hip", "gemm_f32.hip", "gemm_bf16.hip", "gemm_split.hip", "gemm_small.hip", "gemm_dr.hip", "kernels_misc.hip", "linear.hip", "topk_spmm.hip", "spmm_bundle.hip"]
 HEADERS = ["common.h", "gemm_epilogue.h", os.path.join("..", "..", "include", "gdmcf_hip.h")]
 LIB = os.path.join(CSRC, "libgdmcf_hip.so")
+ASM_LINT = ("gemm_dr.hip", "gemm_split.hip")  # disassembled and run through lint_vmcnt at every build
 NO_SPILL = ("gemm_f32.hip", "gemm_bf16.hip", "gemm_split.hip", "gemm_dr.hip")  # kernels with uncounted asm loads: a spill is a build error
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
@@ -47,6 +48,19 @@ _REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
 def _regs(text):
     out = set()
     for m in _REG.finditer(text):
+        if m.group(1) is not None:
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+_SREG = re.compile(r"\bs(\d+)\b|\bs\[(\d+):(\d+)\]")
+
+
+def _sregs(text):
+    out = set()
+    for m in _SREG.finditer(text):
         if m.group(1) is not None:
             out.add(int(m.group(1)))
         else:
@@ -94,6 +108,128 @@ def lint_ring_registers(asm_text, kernel_prefix="dr_tn_kernel"):
     return bad
 
 
+_COPY = ("v_mov", "v_pk_mov", "v_accvgpr", "scratch_", "v_swap")
+_VMEM = ("buffer_", "global_", "flat_", "scratch_")
+
+
+def lint_vmcnt(asm_text, only=None):
+    """Checks the hand-counted waits AND the no-copy invariant of every kernel that issues INLINE-ASM vector loads, by abstract
+    interpretation over the kernel's control-flow graph.  State: for each register written by an asm load that may still be
+    in flight, its RANK = how many vector-memory instructions have been issued since (vmcnt retires in order, so
+    `s_waitcnt vmcnt(N)` lands every register of rank >= N; merge at joins = the lower rank).  Any instruction that reads,
+    copies, spills or overwrites a register while it is pending is a violation: a consumer placed before its counted wait, a
+    v_mov / v_accvgpr / scratch copy hipcc inserted (PHI copies after loop unswitching, spills), an accumulator rotated over a
+    slot that has not landed.  Path-insensitive: kernels whose waits are selected by the same predicate as their loads
+    (gemm_f32.hip, gemm_bf16.hip: `if (more) load(); ... if (more) wait(N) else wait(0)`) raise false alarms and are not run
+    through it; gemm_dr.hip (all kernels) and gemm_split.hip verify cleanly and are checked at every build."""
+    bad, nk = [], 0
+    for m in re.finditer(r"^(_Z\S+):[^\n]*\n(.*?)\n\s*s_endpgm", asm_text, flags=re.S | re.M):
+        name, body = m.group(1), m.group(2)
+        if only and only not in name:
+            continue
+        ins, in_asm = [], False
+        for ln in body.splitlines():
+            t = ln.strip()
+            if t.startswith(";;#ASMSTART"):
+                in_asm = True
+                continue
+            if t.startswith(";;#ASMEND"):
+                in_asm = False
+                continue
+            c = t.split(";")[0].strip()
+            if not c or (c.startswith(".") and not c.endswith(":")):
+                continue
+            ins.append((c, in_asm))
+        if not any(a and "load_dword" in c.split()[0] for c, a in ins):
+            continue
+        nk += 1
+        leaders, labels = {0}, {}
+        for k, (c, a) in enumerate(ins):
+            if c.endswith(":"):
+                labels[c[:-1]] = k
+                leaders.add(k)
+            elif c.startswith(("s_cbranch", "s_branch")):
+                leaders.add(k + 1)
+        starts = sorted(x for x in leaders if x < len(ins))
+        blocks = [(st, starts[i + 1] if i + 1 < len(starts) else len(ins)) for i, st in enumerate(starts)]
+        blk_of = {st: i for i, (st, en) in enumerate(blocks)}
+        succ = []
+        for bi, (st, en) in enumerate(blocks):
+            mn, _, ops = ins[en - 1][0].partition(" ")
+            nxt = []
+            if mn.startswith(("s_cbranch", "s_branch")) and labels.get(ops.strip()) is not None:
+                nxt.append(blk_of[labels[ops.strip()]])
+            if not mn.startswith("s_branch") and bi + 1 < len(blocks):
+                nxt.append(bi + 1)
+            succ.append(nxt)
+        found = {}
+
+        def transfer(bi, st_in, report):
+            st = dict(st_in)
+            fresh = {}  # SGPRs written by a VALU instruction (v_readlane of a spilled SGPR, v_readfirstlane, v_cmp) -> wait states left
+            for k in range(*blocks[bi]):
+                ln, a = ins[k]
+                if ln.endswith(":"):
+                    continue
+                mnem, _, ops = ln.partition(" ")
+                parts = [o.strip() for o in ops.split(",")]
+                # gfx9 / CDNA data hazard the compiler cannot see through inline asm: an SGPR written by a VALU instruction must
+                # not be read by a vector-memory instruction (descriptor, scalar offset) for 5 wait states -- hipcc pads its own
+                # instructions with s_nop, an asm load right behind a v_readlane of its soffset reads the OLD value (seen: the
+                # hybrid kernel's fill loads with SGPR spills, DESIGN 4.1c)
+                if a and mnem.startswith(_VMEM):
+                    hot = _sregs(ops) & fresh.keys()
+                    if hot and report:
+                        found.setdefault(f"s{min(hot)} written by a VALU instruction < 5 wait states before this asm load reads it: {ln}", k)
+                step = int(ops) + 1 if mnem == "s_nop" and ops.strip().isdigit() else 1
+                fresh = {r: w - step for r, w in fresh.items() if w - step > 0}
+                if mnem.startswith("v_") and parts and re.fullmatch(r"s\d+|s\[\d+:\d+\]", parts[0]):
+                    for r in _sregs(parts[0]):
+                        fresh[r] = 5
+                if mnem == "s_waitcnt":
+                    mm = re.search(r"vmcnt\((\d+)\)", ops)
+                    if mm:
+                        st = {r: rk for r, rk in st.items() if rk < int(mm.group(1))}
+                    continue
+                asm_load = a and "load_dword" in mnem
+                touched = _regs(",".join(parts[1:]) if asm_load else ops) & st.keys()
+                if touched and report:
+                    what = "used as an address" if asm_load else ("copied / spilled" if mnem.startswith(_COPY) else "used")
+                    found.setdefault(f"register v{min(touched)} {what} before a counted wait covers its load: {ln}", k)
+                if mnem.startswith(_VMEM):
+                    st = {r: min(rk + 1, 64) for r, rk in st.items()}
+                    if asm_load:
+                        for r in _regs(parts[0]):
+                            st[r] = 0
+            return st
+
+        state = [None] * len(blocks)
+        state[0] = {}
+        work = [0]
+        while work:
+            bi = work.pop()
+            out = transfer(bi, state[bi], False)
+            for sj in succ[bi]:
+                if state[sj] is None:
+                    state[sj] = dict(out)
+                    work.append(sj)
+                else:
+                    changed = False
+                    for r, rk in out.items():
+                        if state[sj].get(r, 65) > rk:
+                            state[sj][r] = rk
+                            changed = True
+                    if changed:
+                        work.append(sj)
+        for bi in range(len(blocks)):
+            if state[bi] is not None:
+                transfer(bi, state[bi], True)
+        bad += [f"{name}: {msg}" for msg, k in sorted(found.items(), key=lambda kv: kv[1])]
+    if not nk:
+        bad.append("no kernel with inline-asm loads in the assembly (lint out of date?)")
+    return bad
+
+
 def build(force=False, verbose=True):
     stamp = os.path.join(CSRC, ".build_stamp")
     dig = _digest()
@@ -126,16 +262,20 @@ def build(force=False, verbose=True):
             err = err if ("warning:" in err or "error:" in err) else ""  # the remarks (and their source excerpts) are not news
         if verbose and err.strip():
             print(err, file=sys.stderr)
-        if src == "gemm_dr.hip":
-            asm = os.path.join(CSRC, "gemm_dr.lint.s")
+        if src in ASM_LINT:
+            asm = os.path.join(CSRC, src.replace(".hip", ".lint.s"))
             r2 = subprocess.run([hipcc] + FLAGS + ["-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", asm],
                                 capture_output=True, text=True)
             if r2.returncode != 0:
                 raise RuntimeError(f"hipcc -S failed for {src}:\n{r2.stderr}")
-            bad = [b for b in lint_ring_registers(open(asm).read()) if "ELi5EEEv" not in b.split(":")[0]]  # (EPI 5 = fused AdamW: not dispatched)
+            text = open(asm).read()
             os.remove(asm)
+            bad = lint_vmcnt(text)
+            if src == "gemm_dr.hip":  # (EPI 5 = fused AdamW: not dispatched)
+                bad += [b for b in lint_ring_registers(text) if "ELi5EEEv" not in b.split(":")[0]]
             if bad:
-                raise RuntimeError("gemm_dr.hip: operand-ring invariant violated (see lint_ring_registers):\n  " + "\n  ".join(bad[:12]))
+                raise RuntimeError(f"{src}: in-flight operand registers touched (see lint_vmcnt / lint_ring_registers):\n  "
+                                   + "\n  ".join(bad[:12]))
         return obj
 
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:

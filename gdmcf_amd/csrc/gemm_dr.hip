@@ -545,6 +545,330 @@ __global__ __launch_bounds__(512, 2) void dr_nt_kernel(const DrArgs d) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// C[M,N] = A[M,K] * B[N,K]^T for a SMALL A and a LARGE B (the output layer with the fused row loss, reference
+// models/DNN.py:79-86 + gaussian_diffusion.py:335: A = hidden activations [batch, hidden], B = the [items, hidden] weight).
+// What dr_nt_kernel showed: a K-contiguous operand must not be fetched straight into the MFMA layout (16 quarter lines per
+// load).  Here
+//   * A comes PRE-TRANSPOSED, At[K, M] (a 1.6 MB copy made by dr_transpose_kernel right before the launch), and is streamed
+//     into registers exactly like dr_tn_kernel's operands: one dwordx4 load = rows m0 .. m0+63 of four k, plus one dword
+//     load for rows m0+64 .. m0+79 -- an 80-row tile (batch 400 = 5 x 80);
+//   * B is fetched in full 128-byte lines (8 lanes per row, 8 rows per load: "piece" u = rows 8u .. 8u+7 of a 32-k chunk),
+//     written to a wave-PRIVATE LDS image (swizzled like gemm_f32.hip's K-contiguous image: conflict-free) and read back as
+//     MFMA fragments with ds_read_b128.  Only the wave's own LDS queue orders the write and the read: no barrier, the eight
+//     waves of a workgroup stay independent (2 x 8 KB per wave, 128 KB per workgroup).
+// A fragment register component s of lane group q is k = 16 h + 4 q + s of its chunk half h, so A's lane group q loads k-row
+// 4 q + s at step s: voffset carries 4 q rows, the scalar offset walks s = 0..3 and then jumps to the next half.
+// One ring for everything, 8 steps (= one chunk) long: the loads of step sigma + 7 (A) and of piece u of chunk c + 2 (B) are
+// issued between the MFMAs of step sigma = (c, u); the piece that has landed by then ((c+1, u+1), issued 7 steps earlier) is
+// written to LDS at the start of the step; fragments are read at steps 3 (second half) and 7 (next chunk's first half).
+//     acc[e][b][t] = C[m0 + 16 q + 4 t + e][n0 + 16 b + r]   (e < 4),      acc[4][b][t] = C[m0 + 64 + 4 q + t][n0 + 16 b + r].
+// The ring is drained at the end of a tile (no operand load is in flight during the epilogue: nothing for hipcc to move);
+// the SIMD partner owns the matrix pipe meanwhile.
+// MEASURED (tools/gemm_probe, Yelp shape): correct and bit-identical to the LDS-tiled kernel, 0.262 ms against
+// 0.2705 ms -- not the 0.22 ms hoped for, so it stays OPT-IN (GDMCF_GEMM_DR bit 3).  Why: (i) 2 690 tiles on 1 024 SIMDs are
+// 2.63 tiles per SIMD: a third of the SIMDs run three tiles, the rest wait (the LDS-tiled kernel has the same 2.63 rounds);
+// (ii) with the loop's loads parked outside the matrices (no memory traffic at all) the kernel is just as slow: the loop is
+// bound by instruction issue -- a buffer_load blocks the SIMD's issue for ~50 cycles, 3 of them per 20 MFMAs (640 cycles) --
+// and a second wave per SIMD does not fill those gaps (one wave per SIMD: 0.199 ms for 2 tiles each, two: 0.200 ms).
+// ---------------------------------------------------------------------------------------------------------------------
+// Fill loads of dr_hl_kernel: with its ~100 live scalars hipcc spills SGPRs into VGPR lanes and reloads a scalar offset with
+// v_readlane right in front of the load that uses it.  An SGPR written by a VALU instruction must not be read by a
+// vector-memory instruction for 5 wait states; hipcc pads its OWN instructions, it cannot see into an asm statement -- the
+// load then uses the register's previous value (found the hard way: pieces of the first two chunks fetched from the
+// previous load's offset).  The guarded forms wait inside the statement; build.py:lint_vmcnt rejects any unguarded case.
+__device__ __forceinline__ f32x4 dr_load_g(i32x4 srd, uint32_t voff, uint32_t soff) {
+    f32x4 v;
+    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(v) : "v"(voff), "s"(srd), "s"(soff) : "memory");
+    return v;
+}
+__device__ __forceinline__ float dr_load1_g(i32x4 srd, uint32_t voff, uint32_t soff) {
+    float v;
+    asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, %3 offen" : "=v"(v) : "v"(voff), "s"(srd), "s"(soff) : "memory");
+    return v;
+}
+
+
+__global__ __launch_bounds__(256) void dr_transpose_kernel(const float* __restrict__ A, int64_t lda, int M, int K,
+                                                           float* __restrict__ At, int ldt) {
+    __shared__ float t[32][33];
+    const int k0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+    const int x = threadIdx.x & 31, y = threadIdx.x >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + y + 8 * i, k = k0 + x;
+        t[y + 8 * i][x] = (m < M && k < K) ? A[(int64_t)m * lda + k] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = k0 + y + 8 * i, m = m0 + x;
+        if (k < K && m < M) At[(int64_t)k * ldt + m] = t[x][y + 8 * i];
+    }
+}
+
+// Loop loads of dr_hl_kernel as READ-WRITE operands: a slot then is live all the time, so hipcc cannot hand its registers to an
+// accumulator between the ds_write that empties it and the load that refills it.  With "=v" outputs it did exactly that --
+// every MFMA of the loop wrote its result into a different register quadruple than it read (v_mfma v[112:115], .., v[60:63]):
+// legal, and measured no slower, but it mixes the accumulators into the ring and costs 22 registers (227 -> 205).
+__device__ __forceinline__ void dr_load_rw(f32x4& v, i32x4 srd, uint32_t voff, uint32_t soff) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(v) : "v"(voff), "s"(srd), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void dr_load1_rw(float& v, i32x4 srd, uint32_t voff, uint32_t soff) {
+    asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "+v"(v) : "v"(voff), "s"(srd), "s"(soff) : "memory");
+}
+// probe ablations (tools/gemm_probe.hip): park the loop's A / B loads outside their matrices (they return 0 without a fetch)
+#ifdef HL_NOA
+#define HL_KA(x) (0x80000000u)
+#else
+#define HL_KA(x) (x)
+#endif
+#ifdef HL_NOB
+#define HL_KB(x) (0x80000000u)
+#else
+#define HL_KB(x) (x)
+#endif
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void dr_hl_kernel(const DrArgs d) {
+    static_assert(EPI == GD_EPI_LOSS, "output layer with the fused row loss");
+    constexpr int LPS = 3;  // loads per step: A dwordx4, A dword, B dwordx4
+    constexpr int D = 7;    // steps in flight beside the one being multiplied; ring = 8 steps = one 32-k chunk
+    static_assert(LPS * D <= 63, "vmcnt is a 6-bit counter");
+    const GdGemm& g = d.g;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    extern __shared__ __attribute__((aligned(16))) float dr_lds[];
+    float* const lds = dr_lds + wave * 4096;  // 2 buffers x 64 rows x 32 k
+    // float offsets inside a buffer.  Write: piece u = rows 8u + (lane >> 3), 16-byte slot (lane & 7) ^ ((row >> 1) & 7); the
+    // swizzle term is (lane >> 4) for even u and 4 + (lane >> 4) for odd u.  Read: row 16 b + r, slot (4 h + q) ^ ((r >> 1) & 7).
+    const int w_ev = (lane >> 3) * 32 + (((lane & 7) ^ (lane >> 4)) << 2), w_od = w_ev ^ 16;
+    const int r_h0 = r * 32 + ((q ^ ((r >> 1) & 7)) << 2), r_h1 = r_h0 ^ 16;
+
+    // ---- tiles and tickets: as in dr_tn_kernel (panel = the 80-row tiles of one 64-column slice of B) ----
+    const int n_waves = gridDim.x * (blockDim.x >> 6);
+    const int minor = d.tiles_m, panels = d.tiles_n;
+    int xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    int qx = xcc & 7, visited = 0;
+    auto q_tiles = [&](int x) { return ((panels - x + 7) >> 3) * minor; };
+    auto tile_of = [&](int x, int t) { return ((t / minor) * 8 + x) * minor + t % minor; };
+    auto draw_blocking = [&]() {
+        for (;;) {
+            if (visited == 8) return -1;
+            unsigned int* c = &g_dr_ticket[d.ctr][qx][0];
+            unsigned int tk = dr_ticket_issue(c);
+            dr_wait<0>();
+            asm volatile("" : "+v"(tk));
+            const int t = __builtin_amdgcn_readfirstlane(tk);
+            const int n = q_tiles(qx);
+            if (t == n + n_waves - 1 && lane == 0) __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t < n) return tile_of(qx, t);
+            qx = (qx + 1) & 7;
+            ++visited;
+        }
+    };
+    if (d.stagger > 0 && __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256)  // (second wave of each SIMD; none in a 256-thread launch)
+        for (int i = 0; i < d.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    int cur = draw_blocking();
+    if (cur < 0) return;
+    const int NCH = d.ksp;  // chunks per tile (even)
+    const i32x4 srdA = dr_srd(g.A, (uint32_t)(((int64_t)(g.K - 1) * g.lda + g.M) * 4));  // At[K, M]
+    const i32x4 srdB = dr_srd(g.B, (uint32_t)(((int64_t)(g.N - 1) * g.ldb + g.K) * 4));
+    const uint32_t sa1 = 4u * (uint32_t)g.lda, sa13 = 13u * sa1;
+    const uint32_t ub8 = 32u * (uint32_t)g.ldb;  // 8 rows of B
+    const int q1 = (NCH / 8) * 2, q2 = (NCH / 4) * 2, q3 = (NCH * 3 / 8) * 2;
+
+    for (;;) {
+        unsigned int* tctr = &g_dr_ticket[d.ctr][qx][0];
+        const bool drew = visited < 8;
+        unsigned int tick = drew ? dr_ticket_issue(tctr) : 0u;
+        const int tm = cur % d.tiles_m, tn = cur / d.tiles_m;
+        const int m0 = tm * 80, n0 = tn * 64;
+        const uint32_t oA4 = (uint32_t)(4 * q * g.lda + m0 + 4 * r) * 4u;
+        const uint32_t oA1 = (uint32_t)(4 * q * g.lda + m0 + 64 + r) * 4u;
+        const uint32_t oB = (uint32_t)(((int64_t)(n0 + (lane >> 3)) * g.ldb + 4 * (lane & 7)) * 4);
+        uint32_t ka = 0;    // A: scalar offset of the next step to issue
+        f32x4 ra4[8], G[8], FB[2][4];
+        float ra1[8];
+        f32x4 acc[5][4];
+#pragma unroll
+        for (int e = 0; e < 5; ++e)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[e][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_s_setprio(0);
+        // ---- fill: chunk 0 of B through LDS buffer 0; then, in the order the steady state would have issued them, piece 0 of
+        // chunk 1, and for u = 1..7 the A loads of step u - 1 and piece u of chunk 1 ----
+#pragma unroll
+        for (int u = 0; u < 8; ++u) G[u] = dr_load_g(srdB, oB, (uint32_t)u * ub8);
+        dr_wait<0>();
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            asm volatile("" : "+v"(G[u]));
+            *reinterpret_cast<f32x4*>(lds + u * 256 + ((u & 1) ? w_od : w_ev)) = G[u];
+        }
+        G[0] = dr_load_g(srdB, oB, 128u);
+#pragma unroll
+        for (int u = 1; u < 8; ++u) {
+            ra4[u - 1] = dr_load_g(srdA, oA4, ka);
+            ra1[u - 1] = dr_load1_g(srdA, oA1, ka);
+            ka += ((u - 1) & 3) == 3 ? sa13 : sa1;
+            G[u] = dr_load_g(srdB, oB, 128u + (uint32_t)u * ub8);
+        }
+        dr_wait<21>();
+        asm volatile("" : "=v"(ra4[7]));  // (slot 7 is first loaded by step 0: a defined value for its read-write operand)
+        asm volatile("" : "=v"(ra1[7]));
+        asm volatile("" : "+v"(G[0]));
+        *reinterpret_cast<f32x4*>(lds + 2048 + w_ev) = G[0];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) FB[0][b] = *reinterpret_cast<const f32x4*>(lds + b * 512 + r_h0);
+        uint32_t kb = 256u;  // B: byte offset of chunk c + 2 inside a row
+
+        for (int c0 = 0; c0 < NCH; c0 += 2) {
+            if (c0 == q1) __builtin_amdgcn_s_setprio(1);
+            else if (c0 == q2) __builtin_amdgcn_s_setprio(2);
+            else if (c0 == q3) __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+            for (int uu = 0; uu < 16; ++uu) {
+                const int p = uu >> 3, u = uu & 7, h = u >> 2, sx = u & 3;
+                const int v = (u + 7) & 7;  // ring slot (= position inside its chunk) of step sigma + 7
+                const int w = (u + 1) & 7;  // piece written to LDS in this step: (c+1, u+1), or (c+2, 0) at u = 7
+                // chunks past the end of the tile are never multiplied: park their B loads outside the matrix (returns 0, no fetch)
+                const uint32_t kbs = (c0 + p + 2 < NCH) ? kb : 0x80000000u;
+                dr_wait<LPS * (D - 1)>();
+                asm volatile("" : "+v"(ra4[u]));
+                asm volatile("" : "+v"(ra1[u]));
+                asm volatile("" : "+v"(G[w]));
+                *reinterpret_cast<f32x4*>(lds + ((u < 7) ? (1 - p) : p) * 2048 + w * 256 + ((w & 1) ? w_od : w_ev)) = G[w];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 20; ++i) {
+                    const int e = i >> 2, b = i & 3;
+                    const float av = e < 4 ? ra4[u][e] : ra1[u];
+                    acc[e][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, FB[h][b][sx], acc[e][b], 0, 0, 0);
+                    if (i == 1) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        dr_load_rw(ra4[v], srdA, oA4, HL_KA(ka));
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else if (i == 5) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        dr_load1_rw(ra1[v], srdA, oA1, HL_KA(ka));
+                        ka += (v & 3) == 3 ? sa13 : sa1;
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else if (i == 9) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        dr_load_rw(G[u], srdB, oB, HL_KB(kbs + (uint32_t)u * ub8));
+                        if (u == 7) kb += 128u;
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else if (i == 13 && u == 3) {
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int bb = 0; bb < 4; ++bb) FB[1][bb] = *reinterpret_cast<const f32x4*>(lds + p * 2048 + bb * 512 + r_h1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else if (i == 13 && u == 7) {
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int bb = 0; bb < 4; ++bb) FB[0][bb] = *reinterpret_cast<const f32x4*>(lds + (1 - p) * 2048 + bb * 512 + r_h0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- drain: whatever is still in flight belongs to steps past the tile; its registers stay untouched until it landed ----
+        dr_wait<0>();
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            asm volatile("" ::"v"(ra4[u]));
+            asm volatile("" ::"v"(ra1[u]));
+            asm volatile("" ::"v"(G[u]));
+        }
+        // the next tile (the ticket was issued before the fill: long landed)
+        int nxt = -1;
+        if (drew) {
+            asm volatile("" : "+v"(tick));
+            const int tk = __builtin_amdgcn_readfirstlane(tick);
+            const int nq = q_tiles(qx);
+            if (tk == nq + n_waves - 1 && lane == 0) __hip_atomic_store(tctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tk < nq) {
+                nxt = tile_of(qx, tk);
+            } else {
+                qx = (qx + 1) & 7;
+                ++visited;
+                nxt = -2;  // draw after the epilogue (a few times per wave, at the end of the launch)
+            }
+        }
+        // ---- epilogue (gaussian_diffusion.py:335): d = alpha * (acc + bias) - target, stored; per-row sum of d^2 over the tile ----
+        {
+            int ncl[4];
+            bool nok[4];
+            float biasv[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int n = n0 + 16 * b + r;
+                nok[b] = n < g.N;
+                ncl[b] = min(n, g.N - 1);
+                biasv[b] = g.bias ? g.bias[ncl[b]] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 5; ++e) {
+                float tg[4][4], c1v[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int m = e < 4 ? m0 + 16 * q + 4 * t + e : m0 + 64 + 4 * q + t;
+                    const int mc = min(m, g.M - 1);
+                    c1v[t] = g.r0 ? g.r0[mc] : 1.f;
+                    if (g.aux_bits) {
+                        // {0,1} target rows as bitmaps: the tile's 64 columns are two words of the row (n0 is a multiple of 64)
+                        uint32_t wv[2];
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj)
+                            wv[jj] = g.aux_bits[(int64_t)mc * g.ldbits + min((int64_t)((n0 >> 5) + jj), g.ldbits - 1)];
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) tg[t][b] = (float)((wv[b >> 1] >> (16 * (b & 1) + r)) & 1u);
+                    } else {
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) tg[t][b] = g.aux[(int64_t)mc * g.ldaux + ncl[b]];
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int m = e < 4 ? m0 + 16 * q + 4 * t + e : m0 + 64 + 4 * q + t;
+                    const bool mok = m < g.M;
+                    float ss = 0.f;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        const float vv = acc[e][b][t] + biasv[b];
+                        const float dd = c1v[t] * vv - tg[t][b];
+                        if (mok && nok[b]) {
+                            if (g.out2) g.out2[(int64_t)m * g.ldout2 + ncl[b]] = vv;
+                            g.C[(int64_t)m * g.ldc + ncl[b]] = dd;
+                            ss += dd * dd;
+                        }
+                    }
+                    ss += __shfl_xor(ss, 1);
+                    ss += __shfl_xor(ss, 2);
+                    ss += __shfl_xor(ss, 4);
+                    ss += __shfl_xor(ss, 8);
+                    if (r == 0 && mok) g.rowpart[(int64_t)m * g.ld_rowpart + tn] = ss;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (nxt == -2) nxt = draw_blocking();
+        if (nxt < 0) break;
+        cur = nxt;
+    }
+}
+
+void dr_hl_go(const DrArgs& d, int n_cu, hipStream_t s) {
+    // GDMCF_HL_WAVES=4: one wave per SIMD (256 threads; 96 KB of LDS requested so that only one workgroup fits a CU)
+    static const int waves = getenv("GDMCF_HL_WAVES") ? atoi(getenv("GDMCF_HL_WAVES")) : 8;
+    if (waves == 4) hipLaunchKernelGGL((dr_hl_kernel<GD_EPI_LOSS>), dim3(n_cu), dim3(256), 96 * 1024, s, d);
+    else hipLaunchKernelGGL((dr_hl_kernel<GD_EPI_LOSS>), dim3(n_cu), dim3(512), 128 * 1024, s, d);
+}
+
 // tile = 16 TMB rows x 16 NB columns; D chunks in flight beside the one being multiplied (ring of D + 1 slots)
 template <int TMB, int NB, int D, int EPI>
 void dr_nt_go(const DrArgs& d, int n_cu, hipStream_t s) {
@@ -572,8 +896,10 @@ static int dr_cu_count() {
 }
 
 // Returns GD_DR_NOT_TAKEN when the product is not one this file handles (the caller falls back to the LDS-tiled kernels).
+int g_gd_dr_force = -1;  // tools/gemm_probe.hip: overrides GDMCF_GEMM_DR per call when >= 0
 int gd_gemm_dr_launch(int layA, int layB, int epi, GdGemm& g, hipStream_t s) {
-    static const int on = getenv("GDMCF_GEMM_DR") ? atoi(getenv("GDMCF_GEMM_DR")) : 1;  // bit 0: weight gradients (default), bit 1: forward
+    static const int on_env = getenv("GDMCF_GEMM_DR") ? atoi(getenv("GDMCF_GEMM_DR")) : 1;
+    const int on = g_gd_dr_force >= 0 ? g_gd_dr_force : on_env;  // bit 0: weight gradients (default), bit 1: forward
     // products (opt-in: measured SLOWER than the LDS-tiled kernels -- 0.279 vs 0.270 ms for the Yelp loss product: a K-contiguous
     // operand costs 16 half-line L1 accesses per load instead of 8 full lines, TCP accesses x3.6, 20 % of the wave cycles waiting)
     if (!on || g.bf16) return GD_DR_NOT_TAKEN;
@@ -616,6 +942,46 @@ int gd_gemm_dr_launch(int layA, int layB, int epi, GdGemm& g, hipStream_t s) {
             else if (best == 8) GD_DR_GO(8);
             else GD_DR_GO(7);
 #undef GD_DR_GO
+        }
+        return gd_launch_status("gemm_dr");
+    }
+    // bit 3: the output layer with the fused row loss on the hybrid kernel (A pre-transposed into the tail of the row-sum scratch)
+    if ((on & 8) && layA == GD_LAY_KC && layB == GD_LAY_KC && epi == GD_EPI_LOSS) {
+        if ((int64_t)g.N * g.ldb * 4 >= ((int64_t)1 << 31) || (int64_t)g.K * g.M * 4 >= lim) return GD_DR_NOT_TAKEN;
+        if (g.lda < g.K || g.ldb < g.K || g.K < 256 || g.M < 64) return GD_DR_NOT_TAKEN;
+        if (g.ldb != g.K && (g.K & 31)) return GD_DR_NOT_TAKEN;  // a chunk that reaches past K reads the next row: it must hold weights, not padding
+        if ((long)gd_cdiv(g.M, 80) * 80 * 100 > (long)g.M * 112) return GD_DR_NOT_TAKEN;  // 80-row tiles: at most 12 % padding
+        const int tiles_m = gd_cdiv(g.M, 80), tiles_n = gd_cdiv(g.N, 64);
+        if ((long)tiles_m * tiles_n < 1024) return GD_DR_NOT_TAKEN;
+        if (g.aux_bits && g.ldbits < (g.N + 31) / 32) return GD_DR_NOT_TAKEN;
+        // scratch: the caller's row-sum buffer holds M x gdmcf_loss_tiles(N) floats; this kernel needs M x tiles_n of them
+        const int64_t used = ((int64_t)g.M * tiles_n + 3) & ~(int64_t)3;
+        if (g.rowpart == nullptr || used + (int64_t)g.K * g.M > (int64_t)g.M * g.ld_rowpart) return GD_DR_NOT_TAKEN;
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dr_hl_kernel<GD_EPI_LOSS>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            if (e != hipSuccess) {
+                gdmcf_set_error("hipFuncSetAttribute(dr_hl_kernel, LDS=128 KB): %s", hipGetErrorString(e));
+                return GDMCF_E_HIP;
+            }
+            attr_set = true;
+        }
+        float* at = g.rowpart + used;
+        d.tiles_m = tiles_m;
+        d.tiles_n = tiles_n;
+        d.m_fastest = 1;
+        d.ksp = (gd_cdiv(g.K, 32) + 1) & ~1;  // chunks of 32 k, an even number of them
+        g.tiles_m = tiles_m;
+        g.tiles_n = tiles_n;
+        g.ld_rowpart = tiles_n;
+        d.g = g;
+        d.g.A = at;
+        d.g.lda = g.M;
+        {
+            GdProfScope prof(g.prof_tag, 2.0 * g.M * g.N * g.K, s);
+            hipLaunchKernelGGL(dr_transpose_kernel, dim3(gd_cdiv(g.K, 32), gd_cdiv(g.M, 32)), dim3(256), 0, s, g.A, g.lda, g.M, g.K, at, g.M);
+            dr_hl_go(d, dr_cu_count(), s);
         }
         return gd_launch_status("gemm_dr");
     }

@@ -427,6 +427,13 @@ class GaussianDiffusionDiscrete(GaussianDiffusion):
             # per-step coefficient vectors [T, B] of the fused posterior epilogue (reference :451-471, :495-498), once
             tabs = {k: self._t32[k][: self.steps, None].expand(self.steps, B).contiguous() for k in ("c1", "c2", "r1", "r2", "sigma")} \
                 if self.noise_scale != 0.0 else None
+            # models of this package fuse the posterior into their output GEMM (`posterior=` of their forward); anything
+            # else with the reference's call signature takes the element-wise path below
+            import inspect
+            try:
+                fused_posterior = "posterior" in inspect.signature(getattr(model, "forward", model)).parameters
+            except (TypeError, ValueError):
+                fused_posterior = False
             for n, i in enumerate(list(range(self.steps))[::-1]):
                 t = torch.full((B,), i, dtype=torch.int64, device=dev)
                 kw = dict(index=index) if self.indexIn else {}
@@ -448,10 +455,27 @@ class GaussianDiffusionDiscrete(GaussianDiffusion):
                     z = step_noise[n] if step_noise is not None else torch.randn_like(x_t)
                     po.update(sigma=tabs["sigma"][i], z=z.float().contiguous())
                 x_in = x_t if (x_t.dtype == torch.float32 and x_t.is_contiguous()) else x_t.float().contiguous()
-                x_next, pred = model(x_in, t, x_tU, posterior=po, **kw)
+                noisy = sampling_noise and i != 0
+                if fused_posterior:
+                    if capture is not None and noisy:
+                        # parity consumers get the real posterior mean: ask the epilogue for the mean alone and add the
+                        # noise here (a capture run is a test run; the product path below adds it inside the epilogue)
+                        po_mean = {k: v for k, v in po.items() if k not in ("sigma", "z")}
+                        mean, pred = model(x_in, t, x_tU, posterior=po_mean, **kw)
+                        x_next = torch.addcmul(mean, po["sigma"][:, None], po["z"])
+                    else:
+                        x_next, pred = model(x_in, t, x_tU, posterior=po, **kw)
+                        mean = x_next
+                else:
+                    # any callable with the reference's signature model(x, t, x_tU[, index, graph]) (:745-760): the same
+                    # arithmetic as the fused epilogue, as element-wise passes over the model output
+                    out = model(x_in, t, x_tU, **kw).float()
+                    pred = po["r1"][:, None] * x_in - po["r2"][:, None] * out if eps_mode else out
+                    mean = po["c1"][:, None] * pred + po["c2"][:, None] * x_in
+                    x_next = torch.addcmul(mean, po["sigma"][:, None], po["z"]) if noisy else mean
                 if capture is not None:
                     capture.setdefault("pred_xstart", []).append(pred)
-                    capture.setdefault("mean", []).append(x_next if not (sampling_noise and i != 0) else None)
+                    capture.setdefault("mean", []).append(mean)
                 x_t = x_next
             del keep
             self.last_graph = graph

@@ -228,3 +228,63 @@ def test_weight_gradient_product_every_element_against_float64(B, N, K):
             assert float((db.double() - dref).abs().max()) <= 2e-6 * float(dref.abs().max()), (use_db, use_rs)
         outs.append(dW)
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+_HL_SCRIPT = r'''
+import sys, torch
+sys.path.insert(0, {root!r})
+from gdmcf_amd import _lib
+lib = _lib.load()
+dev = "cuda:0"
+for (B, N, K, bits) in [(400, 34395, 1000, 0), (400, 34395, 1000, 1), (400, 94949, 1000, 1), (240, 40000, 520, 0)]:
+    g = torch.Generator(device="cpu").manual_seed(B + N + K + bits)
+    h = torch.randn(B, K, generator=g).to(dev)
+    W = (torch.randn(N, K, generator=g) * 0.05).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    alpha = (torch.rand(B, generator=g) + 0.5).to(dev)
+    tgt = (torch.rand(B, N, generator=g) < 0.02).float().to(dev)
+    ldd = (N + 31) // 32 * 32
+    diff = torch.full((B, ldd), float("nan"), device=dev)
+    nt = lib.gdmcf_loss_tiles(N)
+    rowpart = torch.zeros(B * nt, device=dev)
+    rowsum = torch.zeros(B, device=dev)
+    if bits:
+        words = (N + 31) // 32
+        pad = torch.zeros(B, words * 32, device=dev)
+        pad[:, :N] = tgt
+        wts = (2 ** torch.arange(32, device=dev, dtype=torch.float64))
+        packed = (pad.view(B, words, 32).double() * wts).sum(-1).to(torch.int64)
+        packed = torch.where(packed >= 2 ** 31, packed - 2 ** 32, packed).to(torch.int32).contiguous()
+        _lib.check(lib.gdmcf_linear_loss_fwd_bits_f32(h.data_ptr(), K, W.data_ptr(), K, bias.data_ptr(), packed.data_ptr(), words,
+                                                      alpha.data_ptr(), B, N, K, None, 0, diff.data_ptr(), ldd, rowpart.data_ptr(),
+                                                      rowsum.data_ptr(), _lib.stream_ptr()))
+    else:
+        _lib.check(lib.gdmcf_linear_loss_fwd_f32(h.data_ptr(), K, W.data_ptr(), K, bias.data_ptr(), tgt.data_ptr(), N,
+                                                 alpha.data_ptr(), B, N, K, None, 0, diff.data_ptr(), ldd, rowpart.data_ptr(),
+                                                 rowsum.data_ptr(), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    ref = alpha.double()[:, None] * (h.double() @ W.double().t() + bias.double()) - tgt.double()
+    err = float((diff[:, :N].double() - ref).abs().max())
+    rs = float(((rowsum.double() - (ref * ref).sum(1)).abs() / (ref * ref).sum(1)).max())
+    print("case", B, N, K, bits, "max err", err, "row sums", rs)
+    used = (B * ((N + 63) // 64) + 3) // 4 * 4  # the hybrid kernel keeps its transposed copy of h behind the row partials:
+    assert torch.equal(rowpart[used:used + K * B].view(K, B), h.t()), "the hybrid kernel did not run"  # proof that it ran
+    assert err <= 2e-5 * float(ref.abs().max()), err
+    assert rs <= 2e-6, rs
+print("HL-OK")
+'''
+
+
+def test_output_layer_loss_product_on_the_opt_in_hybrid_kernel(tmp_path):
+    """csrc/gemm_dr.hip dr_hl_kernel (GDMCF_GEMM_DR bit 3: small operand pre-transposed and register-streamed, large operand
+    through wave-private LDS; DESIGN 4.1c) through the C ABI of the fused loss layer (gaussian_diffusion.py:335): every element
+    of alpha * (h W^T + b) - target and the row sums of its square against float64, float and bitmap targets, Yelp and
+    Amazon-Book widths and a ragged shape.  The switch is read once per process, so the check runs in ONE child process."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "hl_check.py"
+    script.write_text(_HL_SCRIPT.format(root=root))
+    env = dict(os.environ, GDMCF_GEMM_DR="9")
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "HL-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])

@@ -86,6 +86,23 @@ def test_onehot_p_sample_matches_reference(case):
         diff.p_sample(model, x, T + 1, False)
     with pytest.raises(TypeError):  # the one-hot path needs the one-hot backbone
         diff.p_sample(gdmcf_amd.DNN([meta["I"], 8], [8, meta["I"]], 10).to(DEV), x, 0, False)
+    # a backbone whose forward keeps the reference's signature model(x, t, x_tU) (no `posterior=`): the reverse loop applies
+    # the posterior element-wise instead of inside the output GEMM -- same results; `capture` holds the real means
+    plain = type("PlainForward", (type(model),), {"forward": lambda self, a, t, u: type(model).forward(self, a, t, u)})
+    model.__class__ = plain
+    cap = {}
+    pn2 = diff.p_sample(model, x, 2, True, noise0=cu(torch.from_numpy(fx["noise_noisy0"])),
+                        sampled0=cu(torch.from_numpy(fx["sampled_noisy0"])),
+                        step_noise=cu(torch.from_numpy(fx["noise_noisy_steps"])), capture=cap)
+    assert H.relerr(pn2.cpu().numpy(), fx["pred_noisy"]) < 2e-5
+    assert len(cap["mean"]) == 2 and all(m is not None and torch.isfinite(m).all() for m in cap["mean"])
+    model.__class__ = plain.__mro__[1]
+    cap = {}
+    pn3 = diff.p_sample(model, x, 2, True, noise0=cu(torch.from_numpy(fx["noise_noisy0"])),
+                        sampled0=cu(torch.from_numpy(fx["sampled_noisy0"])),
+                        step_noise=cu(torch.from_numpy(fx["noise_noisy_steps"])), capture=cap)
+    assert H.relerr(pn3.cpu().numpy(), fx["pred_noisy"]) < 2e-5
+    assert all(m is not None for m in cap["mean"]) and H.relerr(cap["mean"][-1].cpu().numpy(), pn3.cpu().numpy()) < 1e-6
 
 
 def test_onehot_noise_kernel_statistics_and_determinism():

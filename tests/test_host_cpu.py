@@ -545,3 +545,33 @@ def test_onehot_embedding_backbone_surface_matches_reference_init_and_names():
     for k in ref:
         assert torch.equal(sd[k], ref[k]), k
     assert m.embedding_item.weight.shape == (I, 3 * dims[-1]) and m.embedding_user.weight.shape == (meta["U"], dims[-1])
+
+
+def _fake_kernel(body):
+    return "_Z4fakev:                                ; @fake\n" + body + "\n\ts_endpgm\n"
+
+
+def test_build_lint_finds_registers_touched_before_their_counted_wait():
+    """gdmcf_amd/build.py: the kernels with hand-counted `s_waitcnt vmcnt(N)` behind inline-asm loads are disassembled at build
+    time; a consumer placed before its wait, a compiler copy of a register whose load is still in flight, or an address that
+    uses one are build errors (the failure mode behind DESIGN 4.1b's corrupted accumulator lanes)."""
+    from gdmcf_amd.build import lint_vmcnt, lint_ring_registers
+    load = lambda d, a: f"\t;;#ASMSTART\n\tbuffer_load_dwordx4 v[{d}:{d + 3}], v{a}, s[0:3], s4 offen\n\t;;#ASMEND\n"
+    ok = _fake_kernel(load(10, 1) + load(14, 1) + "\t;;#ASMSTART\n\ts_waitcnt vmcnt(1)\n\t;;#ASMEND\n"
+                      "\tv_mfma_f32_16x16x4_f32 v[20:23], v10, v2, v[20:23]\n" + load(10, 1) +
+                      "\t;;#ASMSTART\n\ts_waitcnt vmcnt(1)\n\t;;#ASMEND\n\tv_mfma_f32_16x16x4_f32 v[20:23], v14, v2, v[20:23]\n"
+                      "\ts_waitcnt vmcnt(0)\n\tv_mov_b32_e32 v30, v10")
+    assert lint_vmcnt(ok) == []
+    early = ok.replace("vmcnt(1)\n\t;;#ASMEND\n\tv_mfma_f32_16x16x4_f32 v[20:23], v10", "vmcnt(2)\n\t;;#ASMEND\n\tv_mfma_f32_16x16x4_f32 v[20:23], v10")
+    assert any("v10 used" in b for b in lint_vmcnt(early))
+    copy = ok.replace("\ts_waitcnt vmcnt(0)\n", "")
+    assert any("copied" in b for b in lint_vmcnt(copy))
+    addr = _fake_kernel(load(10, 1) + load(14, 11))
+    assert any("address" in b for b in lint_vmcnt(addr))
+    # a loop: the load issued at the bottom of the body is consumed at its top -- behind the wait: clean; without it: flagged
+    loop = _fake_kernel(load(10, 1) + ".LBB0_1:\n\t;;#ASMSTART\n\ts_waitcnt vmcnt(0)\n\t;;#ASMEND\n"
+                        "\tv_mfma_f32_16x16x4_f32 v[20:23], v10, v2, v[20:23]\n" + load(10, 1) + "\ts_cbranch_scc1 .LBB0_1\n\ts_waitcnt vmcnt(0)")
+    assert lint_vmcnt(loop) == []
+    assert lint_vmcnt(loop.replace(".LBB0_1:\n\t;;#ASMSTART\n\ts_waitcnt vmcnt(0)", ".LBB0_1:\n\t;;#ASMSTART\n\ts_nop 0"))
+    assert lint_vmcnt("nothing here")  # no kernel with asm loads: the lint says so instead of passing silently
+    assert lint_ring_registers("nothing here")
