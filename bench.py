@@ -712,8 +712,20 @@ def bench_configs2(gdmcf_amd, lib, dev, steps, warmup, B=400, hid=1000, T=5, pro
     el, kernels, loss = timed(steps, True)
     klist = kernel_table(kernels, "bf16", B, hid, I, steps, len(range(0, steps, prof_every)), el)
     opt.fuse_into_backward(model)
-    elf, _, lossf = timed(steps, False)
+    elf, kf, lossf = timed(steps, True)
     opt.fuse_into_backward(model, min_numel=1 << 62)
+    # the fused step's dominant kernel is the weight-gradient product WITH the optimiser stream in its epilogue: HBM-bound,
+    # 26 B per parameter (W, exp_avg, exp_avg_sq read and written, the bf16 shadow written) + the bf16 operands once
+    fused_dom = None
+    kw = kf.get(5)
+    if kw:
+        avg = kw["ms"] / kw["n"]
+        byt = 26.0 * I * hid + 2.0 * B * (I + hid)
+        fused_dom = dict(kernel="bwd_weight_gemm + AdamW epilogue", bound="hbm", avg_ms=round(avg, 4), launches_per_step=2,
+                         achieved=round(byt / (avg * 1e-3) / 1e9, 1), peak=PEAK_HBM_GBPS, unit="GB/s",
+                         frac=round(byt / (avg * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
+                         share_of_step=round(2 * avg / (1e3 * elf / steps), 4),
+                         algorithmic_unit="26 B per parameter of the [I, hid] weight + its bf16 operands once, per launch")
     k0 = klist[0] if klist else None
     out = dict(what="BASELINE configs[2]: Amazon-Book-shape synthetic rows, batch=400, dims=[1000], T=5, bf16 denoiser GEMM inputs on "
                     "the bf16 MFMA (f32 accumulate, f32 master weights and AdamW state), 1 GPU",
@@ -725,7 +737,10 @@ def bench_configs2(gdmcf_amd, lib, dev, steps, warmup, B=400, hid=1000, T=5, pro
                    algorithmic_unit="AdamW: 30 B/param (28 + the bf16 shadow of the two large weights); products: operands "
                                     "(bf16 shadows) and results once"),
                fused_optimizer=dict(ms_per_step=round(1e3 * elf / steps, 4), users_per_s=round(B * steps / elf, 1), final_loss=lossf,
-                                    what="AdamW of the two large weights inside their weight-gradient GEMM epilogues"))
+                                    dominant_kernel=fused_dom,
+                                    what="the same step with FusedAdamW.fuse_into_backward(model): AdamW of the two large weights "
+                                         "inside their weight-gradient GEMM epilogues (no gradient round trip through HBM) -- the "
+                                         "recommended optimiser path of this configuration"))
     del step, opt, model, dcsr
     torch.cuda.empty_cache()
     return out

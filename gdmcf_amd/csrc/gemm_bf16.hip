@@ -369,7 +369,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_bf16_kernel(co
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int kbeg = split * g.kchunk;
     const int kend = min(g.K, kbeg + g.kchunk);
-    const int nt = (kend - kbeg + BK - 1) / BK;
+    const int nt = (g.dbg & 1) ? 0 : (kend - kbeg + BK - 1) / BK;  // (dbg: timing ablations, GDMCF_BF16_DBG; 0 in production)
 
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -482,6 +482,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, 2) void gemm_bf16_kernel(co
             __syncthreads();
         }
     }
+    if (g.dbg & 2) return;
     if constexpr (EPI == GD_EPI_ADAMW || (EPI == GD_EPI_STORE && S16))
         gemm_epilogue_rows<BM, BN, TM, TN, WAVES_M, WAVES_N, EPI, 64 * (BM + BN), NT>(acc, g, m0, n0, wn0, r, q, wave, tid,
                                                                                      smem);
@@ -540,6 +541,9 @@ int launch_class(int cls, GdGemm& g, hipStream_t s) {
 }  // namespace
 
 int gd_gemm_bf16_launch(int layA, int layB, int epi, int cls, GdGemm& g, hipStream_t s) {
+    // timing ablations of the weight-gradient products (tools/bf16_fused_sweep.sh): bit 0 skips the k loop, bit 1 the epilogue
+    static const int dbg = getenv("GDMCF_BF16_DBG") ? atoi(getenv("GDMCF_BF16_DBG")) : 0;
+    if (dbg && layA == GD_LAY_MC && layB == GD_LAY_MC) g.dbg = dbg;
     if (g.kchunk > 0 && g.kchunk % BK != 0) {
         gdmcf_set_error("gemm_bf16: kchunk %d is not a multiple of %d", g.kchunk, BK);
         return GDMCF_E_ARG;

@@ -42,9 +42,13 @@ int pick_class(int M, int N, bool fused, int prec) {
 // weight-gradient products ([N_out x K_in] outputs, reduction over the batch): bf16 takes the 208x256 class when
 // both dimensions are large and the last round of workgroups is mostly full (measured 0.397 -> 0.374 ms on the
 // Amazon-Book shape; the kernel is bound by getting the f32 operands through L1, not by MFMA).
-int pick_class_dw(int M, int N, int prec) {
+int pick_class_dw(int M, int N, int prec, bool fused_adamw = false) {
     static const int forced = getenv("GDMCF_BF16_DW_CLASS") ? atoi(getenv("GDMCF_BF16_DW_CLASS")) : -1;  // tuning knob
     if (prec == GDMCF_GEMM_BF16 && forced >= 0) return forced;
+    // AdamW in the epilogue: the kernel is its optimiser stream (26 B per parameter) plus a short, latency-bound k loop that
+    // nothing overlaps when one 208x256 workgroup owns the CU: three 80x128 workgroups per CU run one's k loop under the
+    // others' streams (Amazon-Book shape, tools/bf16_fused_ablate.sh: 0.61 -> 0.55 ms per weight; 128x128: 0.59)
+    if (prec == GDMCF_GEMM_BF16 && fused_adamw && M >= 160 && N >= 256) return 0;
     if (prec == GDMCF_GEMM_BF16 && M >= 416 && N >= 512) {
         const long tiles = (long)gd_cdiv(M, 208) * gd_cdiv(N, 256);
         const long rounds = (tiles + 255) / 256;
@@ -269,7 +273,7 @@ int gdmcf_linear_bwd_weight_adamw_f32(const float* dZ, int64_t lddz, const float
     GD_CHECK_SHAPE(M > 0 && N > 0 && K > 0 && lddz >= N && lda >= K && ldw >= K, "linear_bwd_weight_adamw: bad shape");
     GD_CHECK_ARG(W && exp_avg && exp_avg_sq && step >= 1, "linear_bwd_weight_adamw: optimizer state missing");
     hipStream_t s = (hipStream_t)stream;
-    const int cls = pick_class_dw(N, K, t_gemm_prec);
+    const int cls = pick_class_dw(N, K, t_gemm_prec, true);
     GdGemm g = {};
     g.bf16 = t_gemm_prec;  // 0 f32, 1 bf16, 2 three-term split
     g.A = dZ; g.lda = lddz; g.B = A; g.ldb = lda; g.M = N; g.N = K; g.K = M; g.splits = 1;

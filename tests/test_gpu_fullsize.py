@@ -252,8 +252,7 @@ for (B, N, K, bits) in [(400, 34395, 1000, 0), (400, 34395, 1000, 1), (400, 9494
         words = (N + 31) // 32
         pad = torch.zeros(B, words * 32, device=dev)
         pad[:, :N] = tgt
-        wts = (2 ** torch.arange(32, device=dev, dtype=torch.float64))
-        packed = (pad.view(B, words, 32).double() * wts).sum(-1).to(torch.int64)
+        packed = (pad.view(B, words, 32).to(torch.int64) << torch.arange(32, device=dev)).sum(-1)  # bit n & 31 of word n >> 5
         packed = torch.where(packed >= 2 ** 31, packed - 2 ** 32, packed).to(torch.int32).contiguous()
         _lib.check(lib.gdmcf_linear_loss_fwd_bits_f32(h.data_ptr(), K, W.data_ptr(), K, bias.data_ptr(), packed.data_ptr(), words,
                                                       alpha.data_ptr(), B, N, K, None, 0, diff.data_ptr(), ldd, rowpart.data_ptr(),
