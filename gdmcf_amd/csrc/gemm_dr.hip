@@ -909,10 +909,13 @@ int gd_gemm_dr_launch(int layA, int layB, int epi, GdGemm& g, hipStream_t s) {
     DrArgs d = {};
     d.ctr = g.prof_tag & 31;
     d.stagger = stagger;
-    // (the fused-AdamW epilogue is compiled but not dispatched: with it hipcc rotates accumulators through ring registers and
-    // copies ring values -- build.py:lint_ring_registers -- i.e. it may move operands that have not landed yet; GDMCF_GEMM_DR=5
-    // forces it for experiments)
-    if ((on & 1) && layA == GD_LAY_MC && layB == GD_LAY_MC && (epi == GD_EPI_STORE || (epi == GD_EPI_ADAMW && (on & 4)))) {
+    // (the fused-AdamW epilogue: hipcc rotates accumulators through ring slots there, which the first, set-based lint
+    // (build.py:lint_ring_registers) cannot tell from a copy of in-flight data; the per-register analysis that replaced it for
+    // this variant (lint_vmcnt: no instruction touches a register whose load the counted waits do not cover) verifies it clean,
+    // and tests/test_gpu_fullsize.py checks every element of W / exp_avg / exp_avg_sq at the full shapes.  GDMCF_GEMM_DR bit 2
+    // clear (e.g. =1 with bit 2 masked by GDMCF_DR_NO_FUSED=1) sends the fused products back to the LDS-tiled kernel.)
+    static const int no_fused = getenv("GDMCF_DR_NO_FUSED") ? atoi(getenv("GDMCF_DR_NO_FUSED")) : 0;
+    if ((on & 1) && layA == GD_LAY_MC && layB == GD_LAY_MC && (epi == GD_EPI_STORE || (epi == GD_EPI_ADAMW && !no_fused))) {
         if ((int64_t)g.K * g.lda * 4 >= lim || (int64_t)g.K * g.ldb * 4 >= lim || (int64_t)g.M * g.ldc * 4 >= lim) return GD_DR_NOT_TAKEN;
         if (g.lda < g.M || g.ldb < g.N || g.ldc < g.N) return GD_DR_NOT_TAKEN;
         const long tiles = (long)gd_cdiv(g.M, 64) * gd_cdiv(g.N, 64);

@@ -3,6 +3,7 @@
 // per-row loss tail with the Lt-history FIFO, and the fused multi-tensor AdamW.
 #include <math.h>
 
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "common.h"
@@ -1266,18 +1267,29 @@ int gdmcf_scale_f32(const float* acc, int64_t n, float scale, float* out, void* 
 
 }  // extern "C"
 
+// The C ABI carries the hyper-parameters as float; torch.optim.AdamW forms its scalars from the Python doubles the user wrote
+// (1 - 0.999 = 0.001, whereas 1 - (double)0.999f = 0.00099998713: 1.3e-5 off in every exp_avg_sq increment).  The double the
+// user meant is the shortest decimal that rounds to the float we were given (7 significant digits identify a float).
+static double gd_decimal(float x) {
+    char buf[32];
+    snprintf(buf, sizeof buf, "%.7g", (double)x);
+    const double d = strtod(buf, nullptr);
+    return (float)d == x ? d : (double)x;
+}
+
 GdAdamHyper gd_adam_hyper(float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale) {
     // scalars formed in double exactly as torch/optim/adamw.py does, then narrowed to f32
     GdAdamHyper h;
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    h.decay = (float)(1.0 - (double)lr * (double)weight_decay);
-    h.one_m_b1 = (float)(1.0 - (double)beta1);
+    const double lr_d = gd_decimal(lr), b1 = gd_decimal(beta1), b2 = gd_decimal(beta2), wd = gd_decimal(weight_decay);
+    const double bc1 = 1.0 - pow(b1, (double)step);
+    const double bc2 = 1.0 - pow(b2, (double)step);
+    h.decay = (float)(1.0 - lr_d * wd);
+    h.one_m_b1 = (float)(1.0 - b1);
     h.beta2 = beta2;
-    h.one_m_b2 = (float)(1.0 - (double)beta2);
+    h.one_m_b2 = (float)(1.0 - b2);
     h.bc2_sqrt = (float)sqrt(bc2);
     h.eps = eps;
-    h.neg_step = (float)(-((double)lr / bc1));
+    h.neg_step = (float)(-(lr_d / bc1));
     h.grad_scale = grad_scale;
     return h;
 }

@@ -287,3 +287,38 @@ def test_output_layer_loss_product_on_the_opt_in_hybrid_kernel(tmp_path):
     env = dict(os.environ, GDMCF_GEMM_DR="9")
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "HL-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+@pytest.mark.parametrize("B,N,K", [(400, 34395, 1000), (400, 1000, 34405), (400, 94949, 1000), (130, 4100, 515)])
+def test_fused_adamw_weight_gradient_every_element_against_float64(B, N, K):
+    """gdmcf_linear_bwd_weight_adamw_f32 (dW = dZ^T A never leaves the accumulators; W, exp_avg, exp_avg_sq updated in the
+    epilogue with torch.optim.AdamW's single-tensor math; reference main.py:350-351) at the shapes the register-streaming
+    kernel serves: EVERY element of the three tensors against the float64 update of the float64 product, and bit-identical
+    when repeated from the same state."""
+    from gdmcf_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device="cpu").manual_seed(7 * B + N + K)
+    ldz, lda = (N + 63) // 64 * 64, (K + 63) // 64 * 64
+    dZ = (torch.randn(B, ldz, generator=g) * 0.1).to(DEV)
+    A = torch.randn(B, lda, generator=g).to(DEV)
+    W0 = (torch.randn(N, K, generator=g) * 0.05).to(DEV)
+    m0 = (torch.randn(N, K, generator=g) * 0.01).to(DEV)
+    v0 = (torch.rand(N, K, generator=g) * 1e-3).to(DEV)
+    lr, b1, b2, eps, wd, step, gs = 1e-3, 0.9, 0.999, 1e-8, 0.01, 3, 0.5
+    gref = (dZ[:, :N].double().t() @ A[:, :K].double()) * gs
+    p = W0.double() * (1 - lr * wd)
+    m = m0.double() + (gref - m0.double()) * (1 - b1)
+    v = v0.double() * b2 + (1 - b2) * gref * gref
+    p = p - (lr / (1 - b1 ** step)) * m / (v.sqrt() / (1 - b2 ** step) ** 0.5 + eps)
+    outs = []
+    for _ in range(2):
+        W, me, ve = W0.clone(), m0.clone(), v0.clone()
+        _lib.check(lib.gdmcf_linear_bwd_weight_adamw_f32(dZ.data_ptr(), ldz, A.data_ptr(), lda, None, B, N, K, W.data_ptr(), K,
+                                                         me.data_ptr(), ve.data_ptr(), None, lr, b1, b2, eps, wd, step, gs,
+                                                         _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        assert float((me.double() - m).abs().max()) <= 4e-6 * float(m.abs().max())
+        assert float((ve.double() - v).abs().max()) <= 4e-6 * float(v.abs().max())
+        assert float((W.double() - p).abs().max()) <= 4e-6 * float(p.abs().max()) + 2e-5 * lr
+        outs.append((W, me, ve))
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
