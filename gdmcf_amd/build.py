@@ -230,6 +230,41 @@ def lint_vmcnt(asm_text, only=None):
     return bad
 
 
+def lint_store_data(asm_text):
+    """gfx9 / CDNA: a vector-memory store of more than 64 bits reads its data registers after it has issued; a VALU write of one
+    of them needs wait states in between (2 on gfx940+).  LLVM's hazard recognizer pads this only when the store's scalar offset
+    is NOT a register -- `buffer_store_dwordx4 v[146:149], v0, s[36:39], s10 offen` followed directly by `v_mov_b32 v146, ..` is
+    what it emitted for the register-streaming kernel's epilogue, and on gfx950 lanes 12-15 of every 16-lane row of v146 then
+    went to memory with the NEXT row's values in timing-dependent launches (the signature that had been blamed on
+    copies of in-flight operand registers).  Any store of 3 or 4 dwords whose data registers are written within the next two
+    instructions is reported, whoever emitted it."""
+    bad = []
+    for m in re.finditer(r"^(_Z\S+):[^\n]*\n(.*?)\n\s*s_endpgm", asm_text, flags=re.S | re.M):
+        name, body = m.group(1), m.group(2)
+        lines = [ln.split(";")[0].strip() for ln in body.splitlines()]
+        lines = [ln for ln in lines if ln and not ln.startswith(".") and not ln.endswith(":")]
+        for k, ln in enumerate(lines):
+            mnem, _, ops = ln.partition(" ")
+            if not re.match(r"(buffer|global|flat|scratch)_store_dwordx[34]$", mnem):
+                continue
+            parts = [o.strip() for o in ops.split(",")]
+            data = _regs(parts[1] if mnem.startswith(("global", "flat", "scratch")) else parts[0])
+            left = 2
+            for nxt in lines[k + 1:k + 8]:
+                nm, _, nops = nxt.partition(" ")
+                if nm == "s_nop":
+                    left -= int(nops.strip() or 0) + 1
+                else:
+                    nparts = [o.strip() for o in nops.split(",")]
+                    if nm.startswith("v_") and nparts and _regs(nparts[0]) & data and left > 0:
+                        bad.append(f"{name}: data register of `{ln}` rewritten {2 - left} wait state(s) later by `{nxt}`")
+                        break
+                    left -= 1
+                if left <= 0:
+                    break
+    return bad
+
+
 def build(force=False, verbose=True):
     stamp = os.path.join(CSRC, ".build_stamp")
     dig = _digest()
@@ -270,8 +305,8 @@ def build(force=False, verbose=True):
                 raise RuntimeError(f"hipcc -S failed for {src}:\n{r2.stderr}")
             text = open(asm).read()
             os.remove(asm)
-            bad = lint_vmcnt(text)
-            if src == "gemm_dr.hip":  # (EPI 5 = fused AdamW: not dispatched)
+            bad = lint_vmcnt(text) + lint_store_data(text)
+            if src == "gemm_dr.hip":  # (EPI 5 = fused AdamW: accumulators rotate through the ring there, see lint_vmcnt)
                 bad += [b for b in lint_ring_registers(text) if "ELi5EEEv" not in b.split(":")[0]]
             if bad:
                 raise RuntimeError(f"{src}: in-flight operand registers touched (see lint_vmcnt / lint_ring_registers):\n  "

@@ -104,6 +104,16 @@ struct GdStepState {
 };
 extern thread_local const GdStepState* t_gd_step_state;  // bound by gdmcf_graph_state_bind; NULL = by-value arguments
 
+// The scaled activation copy last written by gdmcf_rowscale_f32 on this thread: out[m, K] holds rowscale[m] (ldo > K), which lets
+// the weight-gradient product that consumes it next deliver the bias gradient as its column K (no second pass over dZ).
+struct GdBiasCol {
+    const float* out;
+    const float* rowscale;
+    int M, K;
+    void* stream;
+};
+extern thread_local GdBiasCol t_gd_bias_col;
+
 struct GdGemm {
     const float* A;
     int64_t lda;
@@ -130,7 +140,9 @@ struct GdGemm {
     const float* r2;  // POST: r1 (eps) or NULL
     const float* r3;  // POST: r2 (eps)
     const float* r4;  // POST: sigma
-    float* out2;  // LOSS: raw model output;  POST: pred_xstart
+    float* out2;  // LOSS: raw model output;  POST: pred_xstart;  STORE / ADAMW on the register-streaming kernel: bias gradient
+                  // [M] taken from column N of the product (operand B carries one more column); cleared by the kernel's launcher
+                  // when it has taken the request
     int64_t ldout2;
     float* rowpart;
     int ld_rowpart;

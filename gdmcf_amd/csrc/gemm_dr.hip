@@ -130,7 +130,9 @@ __global__ __launch_bounds__(512, 2) void dr_tn_kernel(const DrArgs d) {
     const i32x4 srdA = dr_srd(g.A, (uint32_t)(((int64_t)(g.K - 1) * g.lda + g.M) * 4));
     const i32x4 srdB = dr_srd(g.B, (uint32_t)(((int64_t)(g.K - 1) * g.ldb + g.N) * 4));
     const uint32_t sa = 16u * (uint32_t)g.lda, sb = 16u * (uint32_t)g.ldb;
-    const uint32_t c_bytes = (uint32_t)(((int64_t)(g.M - 1) * g.ldc + g.N) * 4);
+    // (with a bias column the product has one more column than C: the descriptor ends with C's own last element, or the first
+    // lane of the row tile past M would pass the range check by that one element)
+    const uint32_t c_bytes = (uint32_t)(((int64_t)(g.M - 1) * g.ldc + (g.out2 ? g.N - 1 : g.N)) * 4);
     const __amdgpu_buffer_rsrc_t srdC = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, (int)c_bytes, 0x00020000);
 
     // ---- load cursor: the tile whose operands are being fetched ----
@@ -241,7 +243,7 @@ __global__ __launch_bounds__(512, 2) void dr_tn_kernel(const DrArgs d) {
         for (int b = 0; b < TB; ++b) {
             const int n = n0 + 64 * b + 4 * r;
             const uint32_t vo = (uint32_t)(16 * q * g.ldc + n) * 4u;
-            if (n + 3 < g.N) {
+            if (n + 3 < (g.out2 ? g.N - 1 : g.N)) {  // (a bias column, the last one, never goes out with a 16-byte group)
 #pragma unroll
                 for (int a = 0; a < TA; ++a)
 #pragma unroll
@@ -249,15 +251,21 @@ __global__ __launch_bounds__(512, 2) void dr_tn_kernel(const DrArgs d) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             f32x4 gv = {acc[a][e][b][0][t], acc[a][e][b][1][t], acc[a][e][b][2][t], acc[a][e][b][3][t]};
+                            // The row offset travels in the VGPR offset, the scalar offset field stays 0.  With an SGPR there hipcc
+                            // emits `buffer_store_dwordx4 v[146:149], v0, s[36:39], s10 offen` and refills v146..149 for the next row
+                            // in the very next instruction: LLVM's hazard recognizer holds that a store of more than 64 bits needs no
+                            // wait state before its data registers are rewritten when soffset is a register -- on gfx950 it does:
+                            // lanes 12-15 of every 16-lane row of the FIRST data register went out with the next row's values, in
+                            // timing-dependent launches.  With soffset = 0 the recognizer inserts the s_nop itself.
                             const uint32_t so = (uint32_t)(m0 + 64 * a + 4 * t + e) * (uint32_t)g.ldc * 4u;
                             if (EPI == GD_EPI_STORE) {
-                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, gv), srdC, vo, so, 0);
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, gv), srdC, vo + so, 0, 0);
                             } else {
                                 const __amdgpu_buffer_rsrc_t srdM = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.aux), 0, (int)c_bytes, 0x00020000);
                                 const __amdgpu_buffer_rsrc_t srdV = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.aux2), 0, (int)c_bytes, 0x00020000);
-                                f32x4 pv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdC, vo, so, 0));
-                                f32x4 mv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdM, vo, so, 0));
-                                f32x4 vv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdV, vo, so, 0));
+                                f32x4 pv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdC, vo + so, 0, 0));
+                                f32x4 mv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdM, vo + so, 0, 0));
+                                f32x4 vv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdV, vo + so, 0, 0));
 #pragma unroll
                                 for (int k = 0; k < 4; ++k) {
                                     float pk = pv[k], mk = mv[k], vk = vv[k];
@@ -266,9 +274,9 @@ __global__ __launch_bounds__(512, 2) void dr_tn_kernel(const DrArgs d) {
                                     mv[k] = mk;
                                     vv[k] = vk;
                                 }
-                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pv), srdC, vo, so, 0);
-                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, mv), srdM, vo, so, 0);
-                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vv), srdV, vo, so, 0);
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pv), srdC, vo + so, 0, 0);
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, mv), srdM, vo + so, 0, 0);
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vv), srdV, vo + so, 0, 0);
                             }
                         }
             } else if (n < g.N) {  // the lane's four columns straddle N (last column tile only)
@@ -283,6 +291,10 @@ __global__ __launch_bounds__(512, 2) void dr_tn_kernel(const DrArgs d) {
                                 if (n + k >= g.N) continue;
                                 const int64_t o = (int64_t)m * g.ldc + n + k;
                                 const float gk = acc[a][e][b][k][t];
+                                if (g.out2 && n + k == g.N - 1) {  // the bias column (operand B's extra column): its own vector
+                                    g.out2[m] = gk;
+                                    continue;
+                                }
                                 if (EPI == GD_EPI_STORE) {
                                     g.C[o] = gk;
                                 } else {
@@ -920,6 +932,12 @@ int gd_gemm_dr_launch(int layA, int layB, int epi, GdGemm& g, hipStream_t s) {
         if (g.lda < g.M || g.ldb < g.N || g.ldc < g.N) return GD_DR_NOT_TAKEN;
         const long tiles = (long)gd_cdiv(g.M, 64) * gd_cdiv(g.N, 64);
         if (tiles < 512 || g.K < 128) return GD_DR_NOT_TAKEN;  // (short reductions: a tile is all prologue; the LDS-tiled kernels take them)
+        // bias gradient requested as one more column of the product (linear.hip: operand B carries the row scale in column N): the
+        // kernel multiplies N + 1 columns -- the extra one needs its lane's 4-column group to straddle the end, i.e. N % 4 == 0 or
+        // any N (the straddle path stores element-wise) -- and writes it to out2 instead of C
+        float* const bias_db = (g.ldb > g.N) ? g.out2 : nullptr;
+        const int n_user = g.N;
+        if (bias_db) g.N = n_user + 1;
         d.tiles_m = gd_cdiv(g.M, 64);
         d.tiles_n = gd_cdiv(g.N, 64);
         d.m_fastest = d.tiles_m <= d.tiles_n;  // tiles that share the LARGER operand's panel draw consecutive tickets
@@ -934,8 +952,9 @@ int gd_gemm_dr_launch(int layA, int layB, int epi, GdGemm& g, hipStream_t s) {
         g.tiles_m = d.tiles_m;
         g.tiles_n = d.tiles_n;
         d.g = g;
+        d.g.out2 = bias_db;
         {
-            GdProfScope prof(g.prof_tag, 2.0 * g.M * g.N * g.K, s);
+            GdProfScope prof(g.prof_tag, 2.0 * g.M * n_user * g.K, s);
 #define GD_DR_GO(DD)                                                      \
     do {                                                                  \
         if (epi == GD_EPI_STORE) dr_tn_go<DD, GD_EPI_STORE>(d, s);        \
@@ -946,6 +965,8 @@ int gd_gemm_dr_launch(int layA, int layB, int epi, GdGemm& g, hipStream_t s) {
             else GD_DR_GO(7);
 #undef GD_DR_GO
         }
+        g.N = n_user;
+        if (bias_db) g.out2 = nullptr;  // taken: the caller skips its column-sum pass
         return gd_launch_status("gemm_dr");
     }
     // bit 3: the output layer with the fused row loss on the hybrid kernel (A pre-transposed into the tail of the row-sum scratch)

@@ -568,9 +568,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 __global__ __launch_bounds__(256) void rowscale_kernel(const float* __restrict__ A, int64_t lda,
                                                        const float* __restrict__ rs, int M, int K,
                                                        float* __restrict__ out, int64_t ldo,
-                                                       unsigned short* __restrict__ out16, int64_t ldo16) {
+                                                       unsigned short* __restrict__ out16, int64_t ldo16, int bias_col) {
     typedef f32x4 f32x4_u4 __attribute__((aligned(4)));
     const int m = blockIdx.y, k = (blockIdx.x * 256 + threadIdx.x) * 4;
+    // column K of the scaled copy = the row scale itself: as one more column of the weight-gradient product's second operand it
+    // makes the bias gradient sum_m rs[m] dZ[m, n] column K of that product (gdmcf_linear_bwd_weight_f32)
+    if (bias_col && blockIdx.x == 0 && threadIdx.x == 0) out[(int64_t)m * ldo + K] = rs[m];
     if (k >= K) return;
     const float r = rs[m];
     const float* a = A + (int64_t)m * lda + k;
@@ -1139,8 +1142,10 @@ int gdmcf_rowscale_f32(const float* A, int64_t lda, const float* rowscale, int M
     GdShadow sh;
     const bool has16 = gd_shadow_lookup(out, &sh) && sh.rows == M && sh.cols == K;
     (void)n;
+    const int bias_col = ldo > K;  // room for one more column: out[m, K] = rowscale[m] (see the kernel)
     hipLaunchKernelGGL(rowscale_kernel, dim3(gd_cdiv(K, 1024), M), dim3(256), 0, (hipStream_t)stream, A, lda,
-                       rowscale, M, K, out, ldo, has16 ? (unsigned short*)sh.p16 : nullptr, has16 ? sh.ld16 : 0);
+                       rowscale, M, K, out, ldo, has16 ? (unsigned short*)sh.p16 : nullptr, has16 ? sh.ld16 : 0, bias_col);
+    t_gd_bias_col = bias_col ? GdBiasCol{out, rowscale, M, K, stream} : GdBiasCol{};
     return gd_launch_status("rowscale");
 }
 
@@ -1296,6 +1301,7 @@ GdAdamHyper gd_adam_hyper(float lr, float beta1, float beta2, float eps, float w
 
 // ---- graph step state ---------------------------------------------------------------------------------------------------
 thread_local const GdStepState* t_gd_step_state = nullptr;
+thread_local GdBiasCol t_gd_bias_col = {};
 
 __global__ void graph_state_tick_kernel(GdStepState* st) {
     st->prep_offset += 1;

@@ -213,7 +213,11 @@ int gdmcf_linear_bwd_input_f32(const float* dZ, int64_t lddz, const float* W, in
                                size_t ws_bytes, void* stream);
 /* dW[N,K] = dZ[M,N]^T @ A[M,K]  (weight grad; accumulate != 0 adds into dW)
  * db[N]   = sum_m rowscale[m]*dZ[m,n]   (db NULL -> skipped).  When rowscale != NULL the
- * caller passes A already multiplied by rowscale (see gdmcf_rowscale_f32).                 */
+ * caller passes A already multiplied by rowscale (see gdmcf_rowscale_f32).  When A is the
+ * copy the calling thread's LAST gdmcf_rowscale_f32 call wrote with the same rowscale on the
+ * same stream and lda > K, column K of that copy holds rowscale[m] and db comes out of the
+ * product as its column K (no second pass over dZ); any other A takes a column-sum pass --
+ * same result within float32 rounding.  The caller must not overwrite A[:, K] in between.  */
 int gdmcf_linear_bwd_weight_f32(const float* dZ, int64_t lddz, const float* A, int64_t lda,
                                 const float* rowscale, int M, int N, int K, float* dW,
                                 int64_t lddw, float* db, int accumulate, void* stream);
@@ -227,6 +231,8 @@ int gdmcf_linear_bwd_weight_adamw_f32(const float* dZ, int64_t lddz, const float
                                       float* exp_avg, float* exp_avg_sq, float* db, float lr, float beta1,
                                       float beta2, float eps, float weight_decay, int step,
                                       float grad_scale, void* stream);
+/* out[m, k] = rowscale[m] * A[m, k], k < K (the scaled activation copy of the weight-gradient product: (rs . dZ)^T A ==
+ * dZ^T (rs . A)); with ldo > K also out[m, K] = rowscale[m] (see gdmcf_linear_bwd_weight_f32).                         */
 int gdmcf_rowscale_f32(const float* A, int64_t lda, const float* rowscale, int M, int K, float* out,
                        int64_t ldo, void* stream);
 /* ---- pieces of the indexIn backbone DNNOneHotEmbedding (models/DNN.py:510-682) ----------------

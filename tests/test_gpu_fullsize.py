@@ -330,3 +330,40 @@ def test_fused_adamw_weight_gradient_every_element_against_float64(B, N, K):
         assert float((W.double() - p).abs().max()) <= 4e-6 * float(p.abs().max()) + 2e-5 * lr
         outs.append((W, me, ve))
     assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+
+
+@pytest.mark.parametrize("B,N,K", [(400, 34395, 1000), (400, 94949, 1000), (256, 5000, 777), (130, 4100, 515)])
+def test_bias_gradient_as_a_column_of_the_weight_gradient_product(B, N, K):
+    """gdmcf_rowscale_f32 writes the row scale into column K of its scaled copy (ldo > K); gdmcf_linear_bwd_weight_f32 on that copy
+    then takes db[n] = sum_m rs[m] dZ[m, n] (reference: the bias gradient of main.py:350's backward) out of the product as its
+    column K instead of reading dZ a second time.  Every element of dW and db against float64; the same call on a copy without
+    the spare column (ldo == K) goes through the column-sum pass and must agree; twenty repetitions bit for bit (the variant of
+    the kernel that first carried this column is the one that exposed the store-data hazard of DESIGN 4.1b)."""
+    from gdmcf_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device="cpu").manual_seed(3 * B + N + K)
+    ldz = (N + 63) // 64 * 64
+    dZ = torch.randn(B, ldz, generator=g).to(DEV)
+    h = torch.randn(B, K, generator=g).to(DEV)
+    rs = (torch.rand(B, generator=g) + 0.5).to(DEV)
+    ref = dZ[:, :N].double().t() @ (h.double() * rs.double()[:, None])
+    dref = (dZ[:, :N].double() * rs.double()[:, None]).sum(0)
+    res = []
+    for ldo in (K + 24, K):
+        hs = torch.zeros(B, ldo, device=DEV)
+        _lib.check(lib.gdmcf_rowscale_f32(h.data_ptr(), K, rs.data_ptr(), B, K, hs.data_ptr(), ldo, _lib.stream_ptr()))
+        for rep in range(21 if ldo > K else 1):
+            dW = torch.full((N, K), float("nan"), device=DEV)
+            db = torch.full((N,), float("nan"), device=DEV)
+            _lib.check(lib.gdmcf_linear_bwd_weight_f32(dZ.data_ptr(), ldz, hs.data_ptr(), ldo, rs.data_ptr(), B, N, K, dW.data_ptr(), K,
+                                                       db.data_ptr(), 0, _lib.stream_ptr()))
+            torch.cuda.synchronize()
+            if rep == 0:
+                if ldo > K:
+                    assert torch.equal(hs[:, K], rs)
+                assert float((dW.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max()) * max(1.0, (B / 400) ** 0.5), ldo
+                assert float((db.double() - dref).abs().max()) <= 2e-6 * float(dref.abs().max()) * max(1.0, (B / 400) ** 0.5), ldo
+                res.append((dW, db))
+            else:
+                assert torch.equal(dW, res[-1][0]) and torch.equal(db, res[-1][1]), rep
+    assert torch.equal(res[0][0], res[1][0])  # the product itself does not change with the extra column

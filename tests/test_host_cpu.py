@@ -575,3 +575,17 @@ def test_build_lint_finds_registers_touched_before_their_counted_wait():
     assert lint_vmcnt(loop.replace(".LBB0_1:\n\t;;#ASMSTART\n\ts_waitcnt vmcnt(0)", ".LBB0_1:\n\t;;#ASMSTART\n\ts_nop 0"))
     assert lint_vmcnt("nothing here")  # no kernel with asm loads: the lint says so instead of passing silently
     assert lint_ring_registers("nothing here")
+
+
+def test_build_lint_finds_store_data_rewritten_too_early():
+    """gdmcf_amd/build.py:lint_store_data -- a 16-byte vector-memory store whose data register is rewritten by the next
+    instruction (what hipcc emitted for `buffer_store_dwordx4 .., sN offen`: it pads this hazard only for immediate scalar offsets)."""
+    from gdmcf_amd.build import lint_store_data
+    bad = _fake_kernel("\tbuffer_store_dwordx4 v[146:149], v0, s[36:39], s10 offen\n\tv_mov_b32_e32 v146, v114\n\tv_mov_b32_e32 v147, v110")
+    assert len(lint_store_data(bad)) == 1 and "v146" in lint_store_data(bad)[0]
+    ok = _fake_kernel("\tbuffer_store_dwordx4 v[148:151], v1, s[36:39], 0 offen\n\tv_mov_b32_e32 v146, v126\n\tv_mov_b32_e32 v147, v122\n"
+                      "\tv_mov_b32_e32 v148, v118")
+    assert lint_store_data(ok) == []
+    nop = _fake_kernel("\tglobal_store_dwordx4 v[0:1], v[4:7], off\n\ts_nop 1\n\tv_mov_b32_e32 v4, v9")
+    assert lint_store_data(nop) == []
+    assert len(lint_store_data(_fake_kernel("\tglobal_store_dwordx4 v[0:1], v[4:7], off\n\ts_nop 0\n\tv_mov_b32_e32 v5, v9"))) == 1
