@@ -15,7 +15,8 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 SOURCES = ["capi.hip", "dp_exchange.hip", "gemm_f32.hip", "gemm_bf16.hip", "gemm_split.hip", "gemm_small.hip", "gemm_dr.hip", "kernels_misc.hip", "linear.hip", "topk_spmm.hip", "spmm_bundle.hip"]
 HEADERS = ["common.h", "gemm_epilogue.h", os.path.join("..", "..", "include", "gdmcf_hip.h")]
 LIB = os.path.join(CSRC, "libgdmcf_hip.so")
-ASM_LINT = ("gemm_dr.hip", "gemm_split.hip")  # disassembled and run through lint_vmcnt at every build
+ASM_LINT = ("gemm_dr.hip", "gemm_split.hip")  # disassembled and run through lint_vmcnt + lint_store_data at every build
+STORE_LINT = ("gemm_f32.hip", "gemm_bf16.hip")  # disassembled for lint_store_data only
 NO_SPILL = ("gemm_f32.hip", "gemm_bf16.hip", "gemm_split.hip", "gemm_dr.hip")  # kernels with uncounted asm loads: a spill is a build error
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
@@ -297,6 +298,16 @@ def build(force=False, verbose=True):
             err = err if ("warning:" in err or "error:" in err) else ""  # the remarks (and their source excerpts) are not news
         if verbose and err.strip():
             print(err, file=sys.stderr)
+        if src in STORE_LINT:  # (their waits are path-dependent, see lint_vmcnt: only the store-data hazard is checked here)
+            asm = os.path.join(CSRC, src.replace(".hip", ".lint.s"))
+            r2 = subprocess.run([hipcc] + FLAGS + ["-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", asm],
+                                capture_output=True, text=True)
+            if r2.returncode != 0:
+                raise RuntimeError(f"hipcc -S failed for {src}:\n{r2.stderr}")
+            bad = lint_store_data(open(asm).read())
+            os.remove(asm)
+            if bad:
+                raise RuntimeError(f"{src}: store data registers rewritten too early (lint_store_data):\n  " + "\n  ".join(bad[:12]))
         if src in ASM_LINT:
             asm = os.path.join(CSRC, src.replace(".hip", ".lint.s"))
             r2 = subprocess.run([hipcc] + FLAGS + ["-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", asm],
