@@ -273,6 +273,7 @@ int gdmcf_linear_bwd_weight_f32(const float* dZ, int64_t lddz, const float* A, i
     attach_shadows(g, GD_LAY_MC, GD_LAY_MC);
     g.out2 = bias_col_request(A, lda, rowscale, M, K, db, stream);
     const bool asked = g.out2 != nullptr;
+    t_gd_bias_col = GdBiasCol{};  // one use per gdmcf_rowscale_f32 call: a later product has to be preceded by its own
     int rc = gd_gemm_launch(GD_LAY_MC, GD_LAY_MC, GD_EPI_STORE, cls, g, s);
     if (rc) return rc;
     if (asked && g.out2 == nullptr) return GDMCF_OK;  // db came out of the product
@@ -298,6 +299,7 @@ int gdmcf_linear_bwd_weight_adamw_f32(const float* dZ, int64_t lddz, const float
     attach_shadows(g, GD_LAY_MC, GD_LAY_MC);
     g.out2 = bias_col_request(A, lda, rowscale, M, K, db, stream);
     const bool asked = g.out2 != nullptr;
+    t_gd_bias_col = GdBiasCol{};
     int rc = gd_gemm_launch(GD_LAY_MC, GD_LAY_MC, GD_EPI_ADAMW, cls, g, s);
     if (rc) return rc;
     if (asked && g.out2 == nullptr) return GDMCF_OK;  // db came out of the product

@@ -217,7 +217,8 @@ int gdmcf_linear_bwd_input_f32(const float* dZ, int64_t lddz, const float* W, in
  * copy the calling thread's LAST gdmcf_rowscale_f32 call wrote with the same rowscale on the
  * same stream and lda > K, column K of that copy holds rowscale[m] and db comes out of the
  * product as its column K (no second pass over dZ); any other A takes a column-sum pass --
- * same result within float32 rounding.  The caller must not overwrite A[:, K] in between.  */
+ * same result within float32 rounding.  The caller must not overwrite A[:, K] in between;
+ * the record of the copy is consumed by the first gdmcf_linear_bwd_weight_* call after it.   */
 int gdmcf_linear_bwd_weight_f32(const float* dZ, int64_t lddz, const float* A, int64_t lda,
                                 const float* rowscale, int M, int N, int K, float* dW,
                                 int64_t lddw, float* db, int accumulate, void* stream);
