@@ -68,7 +68,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="yelp", choices=["yelp", "amazon-book", "stress"])
+    ap.add_argument("--workload", default="yelp", choices=["yelp", "amazon-book", "stress", "tiny"])
     ap.add_argument("--T", type=int, default=5, help="diffusion steps")
     ap.add_argument("--batch", type=int, default=400)
     ap.add_argument("--global-batch", type=int, default=0,
@@ -82,6 +82,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-1thread", action="store_true", help="skip the one-thread CPU step (tens of seconds)")
+    ap.add_argument("--preheat-seconds", type=float, default=1.0,
+                    help="untimed: run dense products on scratch buffers for this long before the warm-up steps so that the timed "
+                         "region does not start on a cold clock (0 = off; reported as clock_preheat)")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--prof-every", type=int, default=4,
                     help="bracket the tagged launches of every Nth timed step with HIP events (an event pair keeps the next "
@@ -250,7 +253,7 @@ def physical_cores():
 def launch_ranks(args):
     """`python bench.py --gpus N` without a launcher: this parent -- which never touches the GPU -- starts N fresh child
     processes (one rank per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set), relays rank 0's JSON line and fails
-    loudly when a rank fails or fewer than N GPUs are visible."""
+    loudly when a rank fails -- e.g. because fewer than N GPUs are visible to it."""
     import socket
     import subprocess
     n = args.gpus
@@ -261,9 +264,8 @@ def launch_ranks(args):
         raise SystemExit("bench.py --gpus N under a profiler: the parent would have to start ranks from a GPU-initialised "
                          "process.  Profile a single rank (rocprofv3 ... -- python bench.py) or launch the ranks with "
                          "torch.distributed.run and profile inside them.")
-    have = torch.cuda.device_count()  # counting devices does not initialise the GPU on this image
-    if have < n and not os.environ.get("GDMCF_BENCH_DRY_RUN"):
-        raise SystemExit(f"bench.py --gpus {n}: only {have} GPU(s) visible; refusing to report an N-GPU line from fewer ranks")
+    # (the parent does not even COUNT devices: torch.cuda.device_count() can fall back to hipGetDeviceCount, i.e. initialise the
+    # GPU in the process that is about to start the ranks; every rank checks the count itself and exits non-zero)
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
@@ -307,6 +309,16 @@ def main():
                               "ranks_in_group": int(one.item())}))
         dist.destroy_process_group()
         return
+    # GDMCF_BENCH_SHARE_GPU=1 (tests only: the rehearsal of the N > 1 launcher and step on a one-GPU box): the ranks share the
+    # visible devices (rank r -> device r % count) and meet in a gloo group, collectives staged through the host; the line says
+    # so (`rehearsal`).  Without it a rank that does not find a GPU of its own refuses to run.
+    share = os.environ.get("GDMCF_BENCH_SHARE_GPU") == "1"
+    have = torch.cuda.device_count()
+    if have < (1 if share else max(world, 1)):
+        raise SystemExit(f"bench.py --gpus {args.gpus}: rank {rank} sees {have} GPU(s) visible; refusing to report an "
+                         f"N-GPU line from fewer GPUs than ranks")
+    if share:
+        local = local % have
     if world > 1 or args.rehearse_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -316,7 +328,10 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        if share and world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
 
@@ -389,6 +404,28 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- clock pre-heat (untimed, not a training step): after an idle period the chip runs its first tens of milliseconds
+    # at 2.1-2.2 GHz instead of 2.38 GHz (in-kernel s_memtime / s_memrealtime stamps); a timed region of 20 steps
+    # = 32 ms behind 5 warm-up steps = 8 ms would measure the ramp, which no training run longer than a blink sees.  A fixed
+    # TIME of dense products on scratch operands brings the clock up; the model, the optimiser and the random streams are
+    # not touched (the W warm-up steps that follow are the only steps before the timed ones).  Reported as `clock_preheat`.
+    preheat = None
+    if args.preheat_seconds > 0:
+        pa = torch.randn(400, 4096, device=dev)
+        pw = torch.randn(4096, 4096, device=dev)
+        pc = torch.empty(400, 4096, device=dev)
+        pws = torch.empty(max(int(lib.gdmcf_linear_ws_bytes(400, 4096, 4096)), 256), dtype=torch.uint8, device=dev)
+        t_ph, n_ph = time.perf_counter(), 0
+        while time.perf_counter() - t_ph < args.preheat_seconds:
+            for _ in range(16):
+                _lib.check(lib.gdmcf_linear_fwd_f32(pa.data_ptr(), 4096, pw.data_ptr(), 4096, None, 0, 400, 4096, 4096,
+                                                    pc.data_ptr(), 4096, pws.data_ptr(), pws.numel(), _lib.stream_ptr()))
+            torch.cuda.synchronize()
+            n_ph += 16
+        preheat = dict(seconds=round(time.perf_counter() - t_ph, 3), launches=n_ph,
+                       what="untimed dense products on scratch buffers before the warm-up steps (clock ramp after idle); "
+                            "no training step, no model / optimiser / RNG state touched")
+        del pa, pw, pc, pws
     loss = None
     for i in range(args.warmup):
         loss = step(rows_of(i % n_pool), True, **step_kw[i % n_pool])
@@ -620,7 +657,9 @@ def main():
                        "n_items": I, "global_batch": world * B, "parallelism": f"dp{world}",
                        "batch_rows": "device CSR rows (CsrBatch)" if sparse_rows else "dense rows densified from the device CSR"},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": klist, "final_loss": final_loss,
-            "host_enqueue_ms_per_step": round(1e3 * host_el / args.steps, 4),
+            "host_enqueue_ms_per_step": round(1e3 * host_el / args.steps, 4), "clock_preheat": preheat,
+            "rehearsal": ("ranks share the visible GPU(s), gloo group with host-staged collectives (GDMCF_BENCH_SHARE_GPU=1): "
+                          "launcher / step rehearsal, not a measurement") if (share and world > 1) else None,
             "replicas_in_sync": in_sync, "dp_autotune": dp_autotune, "strong_scaling": strong_leg, "fused_optimizer_leg": fused_leg, "graph_leg": graph_leg, "f32x3_leg": x3_leg,
             "configs2_leg": configs2_leg,
             "ranks_in_group": dist.get_world_size() if dist.is_initialized() else 1,

@@ -47,8 +47,8 @@ _SIGNATURES = {
                                                c_int, c_int, P, c_int64, P, c_int64, P]),
     "gdmcf_linear_bwd_input_f32": (c_int, [P, c_int64, P, c_int64, P, P, c_int64, c_int, c_int, c_int, c_int, P,
                                            c_int64, P, c_size_t, P]),
-    "gdmcf_linear_bwd_weight_f32": (c_int, [P, c_int64, P, c_int64, P, c_int, c_int, c_int, P, c_int64, P, c_int, P]),
-    "gdmcf_linear_bwd_weight_adamw_f32": (c_int, [P, c_int64, P, c_int64, P, c_int, c_int, c_int, P, c_int64, P, P, P, c_float,
+    "gdmcf_linear_bwd_weight_f32": (c_int, [P, c_int64, P, c_int64, P, c_int, c_int, c_int, c_int, P, c_int64, P, c_int, P]),
+    "gdmcf_linear_bwd_weight_adamw_f32": (c_int, [P, c_int64, P, c_int64, P, c_int, c_int, c_int, c_int, P, c_int64, P, P, P, c_float,
                                                   c_float, c_float, c_float, c_float, c_int, c_float, P]),
     "gdmcf_rowscale_f32": (c_int, [P, c_int64, P, c_int, c_int, P, c_int64, P]),
     "gdmcf_emb_bwd_f32": (c_int, [P, c_int64, P, c_int64, c_int, c_int, P, c_int, c_int, P, P, P, P]),

@@ -104,16 +104,6 @@ struct GdStepState {
 };
 extern thread_local const GdStepState* t_gd_step_state;  // bound by gdmcf_graph_state_bind; NULL = by-value arguments
 
-// The scaled activation copy last written by gdmcf_rowscale_f32 on this thread: out[m, K] holds rowscale[m] (ldo > K), which lets
-// the weight-gradient product that consumes it next deliver the bias gradient as its column K (no second pass over dZ).
-struct GdBiasCol {
-    const float* out;
-    const float* rowscale;
-    int M, K;
-    void* stream;
-};
-extern thread_local GdBiasCol t_gd_bias_col;
-
 struct GdGemm {
     const float* A;
     int64_t lda;

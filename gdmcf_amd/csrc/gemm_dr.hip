@@ -37,7 +37,8 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef f32x4 f32x4_dr_u __attribute__((aligned(4)));
 
-// ticket counters: per call site (GdGemm::prof_tag) one queue per XCD, each on a 128-byte line of its own; zero between launches
+// ticket counters: one SET per launch in flight (dr_ticket_slot below), one queue per XCD inside a set, each on a 128-byte line of
+// its own; a queue's last draw resets it, so every set is zero again when its launch has drained
 __device__ unsigned int g_dr_ticket[32][8][32];
 
 __device__ __forceinline__ i32x4 dr_srd(const void* p, uint32_t bytes) {
@@ -72,7 +73,7 @@ struct DrArgs {
     GdGemm g;
     int tiles_m, tiles_n, m_fastest;
     int ksp;      // k-steps run per tile (a multiple of the ring size; steps past K load zeros)
-    int ctr;      // index into g_dr_ticket
+    int ctr;      // index into g_dr_ticket (dr_ticket_slot: a set of its own for every launch that may be in flight)
     int stagger;  // waves 4-7 of a workgroup start this many x 3.4 us later
 };
 
@@ -907,6 +908,28 @@ static int dr_cu_count() {
     return n_cu;
 }
 
+// Ticket-counter set of one launch.  Two launches that overlap in time -- the two weight gradients of a step on two streams
+// (GDMCF_GEMM_SIDE=1), two host threads, a replayed graph beside an eager step -- must not draw from the same counters, or each
+// computes only a subset of its tiles.  The set therefore belongs to the LAUNCH, not to the call site: eager launches rotate
+// through sets 0..15, launches recorded during a stream capture through 16..31 (a graph node keeps its set for every replay, so
+// it must never meet an eager launch's).  Limits that follow: at most 16 eager launches of these kernels in flight at once, and
+// at most 16 captured ones among all graphs that replay concurrently -- stream order and graph order serialise far below that.
+#include <atomic>
+static std::atomic<unsigned> g_dr_seq_eager{0}, g_dr_seq_graph{0};
+static int dr_ticket_slot(hipStream_t s) {
+    // GDMCF_DR_TICKET_SLOT=n pins every launch to set n: the behaviour before round 4, kept as the negative control of
+    // tests/test_gpu_reentrancy.py (overlapping launches then share their queues and lose tiles)
+    static const int pinned = getenv("GDMCF_DR_TICKET_SLOT") ? atoi(getenv("GDMCF_DR_TICKET_SLOT")) : -1;
+    if (pinned >= 0) return pinned & 31;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) {
+        (void)hipGetLastError();  // (the legacy stream while another stream captures: not a capture of this launch)
+        st = hipStreamCaptureStatusNone;
+    }
+    if (st == hipStreamCaptureStatusActive) return 16 + (int)(g_dr_seq_graph.fetch_add(1, std::memory_order_relaxed) & 15u);
+    return (int)(g_dr_seq_eager.fetch_add(1, std::memory_order_relaxed) & 15u);
+}
+
 // Returns GD_DR_NOT_TAKEN when the product is not one this file handles (the caller falls back to the LDS-tiled kernels).
 int g_gd_dr_force = -1;  // tools/gemm_probe.hip: overrides GDMCF_GEMM_DR per call when >= 0
 int gd_gemm_dr_launch(int layA, int layB, int epi, GdGemm& g, hipStream_t s) {
@@ -919,7 +942,7 @@ int gd_gemm_dr_launch(int layA, int layB, int epi, GdGemm& g, hipStream_t s) {
     static const int stagger = getenv("GDMCF_DR_STAGGER") ? atoi(getenv("GDMCF_DR_STAGGER")) : 3;
     const int64_t lim = (int64_t)1 << 32;  // 32-bit byte offsets inside every matrix
     DrArgs d = {};
-    d.ctr = g.prof_tag & 31;
+    d.ctr = -1;  // drawn per launch, once the product is known to be taken (dr_ticket_slot)
     d.stagger = stagger;
     // (the fused-AdamW epilogue: hipcc rotates accumulators through ring slots there, which the first, set-based lint
     // (build.py:lint_ring_registers) cannot tell from a copy of in-flight data; the per-register analysis that replaced it for
@@ -952,6 +975,7 @@ int gd_gemm_dr_launch(int layA, int layB, int epi, GdGemm& g, hipStream_t s) {
         g.tiles_m = d.tiles_m;
         g.tiles_n = d.tiles_n;
         d.g = g;
+        d.ctr = dr_ticket_slot(s);
         d.g.out2 = bias_db;
         {
             GdProfScope prof(g.prof_tag, 2.0 * g.M * n_user * g.K, s);
@@ -1000,6 +1024,7 @@ int gd_gemm_dr_launch(int layA, int layB, int epi, GdGemm& g, hipStream_t s) {
         g.tiles_n = tiles_n;
         g.ld_rowpart = tiles_n;
         d.g = g;
+        d.ctr = dr_ticket_slot(s);
         d.g.A = at;
         d.g.lda = g.M;
         {
@@ -1037,6 +1062,7 @@ int gd_gemm_dr_launch(int layA, int layB, int epi, GdGemm& g, hipStream_t s) {
         g.tiles_m = d.tiles_m;
         g.tiles_n = d.tiles_n;
         d.g = g;
+        d.ctr = dr_ticket_slot(s);
         {
             GdProfScope prof(g.prof_tag, 2.0 * g.M * g.N * g.K, s);
 #define GD_DR_NT(T, NBV, DV)                                                            \

@@ -1145,7 +1145,6 @@ int gdmcf_rowscale_f32(const float* A, int64_t lda, const float* rowscale, int M
     const int bias_col = ldo > K;  // room for one more column: out[m, K] = rowscale[m] (see the kernel)
     hipLaunchKernelGGL(rowscale_kernel, dim3(gd_cdiv(K, 1024), M), dim3(256), 0, (hipStream_t)stream, A, lda,
                        rowscale, M, K, out, ldo, has16 ? (unsigned short*)sh.p16 : nullptr, has16 ? sh.ld16 : 0, bias_col);
-    t_gd_bias_col = bias_col ? GdBiasCol{out, rowscale, M, K, stream} : GdBiasCol{};
     return gd_launch_status("rowscale");
 }
 
@@ -1301,7 +1300,6 @@ GdAdamHyper gd_adam_hyper(float lr, float beta1, float beta2, float eps, float w
 
 // ---- graph step state ---------------------------------------------------------------------------------------------------
 thread_local const GdStepState* t_gd_step_state = nullptr;
-thread_local GdBiasCol t_gd_bias_col = {};
 
 __global__ void graph_state_tick_kernel(GdStepState* st) {
     st->prep_offset += 1;

@@ -93,17 +93,15 @@ int pick_splits(int M, int N, int K, int cls, int prec) {
 
 inline int64_t round4(int64_t x) { return (x + 3) & ~(int64_t)3; }
 
-// The bias gradient db[n] = sum_m rowscale[m] dZ[m, n] as column K of the weight-gradient product: possible when the activation
-// operand A is the copy gdmcf_rowscale_f32 has just written with the SAME row scale on the same stream (its column K then holds
-// rowscale[m]).  Returns db when the request can be made, else NULL; a launcher that takes the request clears GdGemm::out2.
-float* bias_col_request(const float* A, int64_t lda, const float* rowscale, int M, int K, float* db, void* stream) {
+// The bias gradient db[n] = sum_m rowscale[m] dZ[m, n] as column K of the weight-gradient product: possible when the caller
+// states (a_scale_col) that column K of the activation operand A holds rowscale[m] -- gdmcf_rowscale_f32 writes it there when its
+// output has room (ldo > K).  Nothing is remembered between calls.  Returns db when the request can be made, else NULL; a
+// launcher that takes the request clears GdGemm::out2.
+float* bias_col_request(int a_scale_col, int64_t lda, const float* rowscale, int K, float* db) {
     static const int on = getenv("GDMCF_BIAS_COL") ? atoi(getenv("GDMCF_BIAS_COL")) : 1;
-    const GdBiasCol& b = t_gd_bias_col;
-    if (!on || db == nullptr || rowscale == nullptr || t_gemm_prec != GDMCF_GEMM_F32) return nullptr;
-    if (b.out != A || b.rowscale != rowscale || b.M != M || b.K != K || b.stream != stream || lda <= K) return nullptr;
+    if (!on || !a_scale_col || db == nullptr || rowscale == nullptr || t_gemm_prec != GDMCF_GEMM_F32 || lda <= K) return nullptr;
     return db;
 }
-
 
 }  // namespace
 
@@ -259,7 +257,7 @@ int gdmcf_linear_bwd_input_f32(const float* dZ, int64_t lddz, const float* W, in
 }
 
 int gdmcf_linear_bwd_weight_f32(const float* dZ, int64_t lddz, const float* A, int64_t lda, const float* rowscale,
-                                int M, int N, int K, float* dW, int64_t lddw, float* db, int accumulate,
+                                int a_scale_col, int M, int N, int K, float* dW, int64_t lddw, float* db, int accumulate,
                                 void* stream) {
     GD_CHECK_SHAPE(M > 0 && N > 0 && K > 0 && lddz >= N && lda >= K && lddw >= K, "linear_bwd_weight: bad shape");
     hipStream_t s = (hipStream_t)stream;
@@ -271,9 +269,8 @@ int gdmcf_linear_bwd_weight_f32(const float* dZ, int64_t lddz, const float* A, i
     g.m_fastest = gd_cdiv(N, gd_gemm_tile_m(cls)) <= gd_cdiv(K, gd_gemm_tile_n(cls));
     g.C = dW; g.ldc = lddw; g.accumulate = accumulate; g.prof_tag = 5;
     attach_shadows(g, GD_LAY_MC, GD_LAY_MC);
-    g.out2 = bias_col_request(A, lda, rowscale, M, K, db, stream);
+    g.out2 = bias_col_request(a_scale_col, lda, rowscale, K, db);
     const bool asked = g.out2 != nullptr;
-    t_gd_bias_col = GdBiasCol{};  // one use per gdmcf_rowscale_f32 call: a later product has to be preceded by its own
     int rc = gd_gemm_launch(GD_LAY_MC, GD_LAY_MC, GD_EPI_STORE, cls, g, s);
     if (rc) return rc;
     if (asked && g.out2 == nullptr) return GDMCF_OK;  // db came out of the product
@@ -282,7 +279,7 @@ int gdmcf_linear_bwd_weight_f32(const float* dZ, int64_t lddz, const float* A, i
 }
 
 int gdmcf_linear_bwd_weight_adamw_f32(const float* dZ, int64_t lddz, const float* A, int64_t lda, const float* rowscale,
-                                      int M, int N, int K, float* W, int64_t ldw, float* exp_avg, float* exp_avg_sq,
+                                      int a_scale_col, int M, int N, int K, float* W, int64_t ldw, float* exp_avg, float* exp_avg_sq,
                                       float* db, float lr, float beta1, float beta2, float eps, float weight_decay,
                                       int step, float grad_scale, void* stream) {
     GD_CHECK_SHAPE(M > 0 && N > 0 && K > 0 && lddz >= N && lda >= K && ldw >= K, "linear_bwd_weight_adamw: bad shape");
@@ -297,9 +294,8 @@ int gdmcf_linear_bwd_weight_adamw_f32(const float* dZ, int64_t lddz, const float
     g.adam = gd_adam_hyper(lr, beta1, beta2, eps, weight_decay, step, grad_scale);
     attach_result_shadow(g);  // the bf16 kernels' row epilogue also refreshes W's bf16 shadow
     attach_shadows(g, GD_LAY_MC, GD_LAY_MC);
-    g.out2 = bias_col_request(A, lda, rowscale, M, K, db, stream);
+    g.out2 = bias_col_request(a_scale_col, lda, rowscale, K, db);
     const bool asked = g.out2 != nullptr;
-    t_gd_bias_col = GdBiasCol{};
     int rc = gd_gemm_launch(GD_LAY_MC, GD_LAY_MC, GD_EPI_ADAMW, cls, g, s);
     if (rc) return rc;
     if (asked && g.out2 == nullptr) return GDMCF_OK;  // db came out of the product

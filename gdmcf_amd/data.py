@@ -11,6 +11,7 @@ SHAPES = {
     "yelp": dict(n_users=54574, n_items=34395, nnz=981915),
     "amazon-book": dict(n_users=108822, n_items=94949, nnz=2202379),
     "stress": dict(n_users=1000000, n_items=200000, nnz=20000000),
+    "tiny": dict(n_users=6000, n_items=3001, nnz=90000),  # launcher / data-parallel rehearsals in tests (ragged width)
 }
 
 

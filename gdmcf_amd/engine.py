@@ -427,15 +427,17 @@ class DenoiserEngine:
         def weight_grad(li, w, bias, A_prev, lda_prev, N, K):
             db = self._grad_like(bias)
             A_use, lda_use = A_prev, lda_prev
+            scol = 0  # 1: column K of A_use holds the row scale (written by gdmcf_rowscale_f32 below: the copy has room for it)
             if rs is not None:
                 # (rs . dZ)^T A == dZ^T (rs . A): scale the small activation instead of the big dZ
                 _lib.check(lib.gdmcf_rowscale_f32(A_prev.data_ptr(), lda_prev, rs.data_ptr(), B, K, bufs.hs.data_ptr(),
                                                   bufs.hs.stride(0), st))
                 A_use, lda_use = bufs.hs, bufs.hs.stride(0)
+                scol = int(lda_use > K)
             fs = fused.fused_state(w) if fused is not None else None
             if fs is not None:
                 _lib.check(lib.gdmcf_linear_bwd_weight_adamw_f32(
-                    dz.data_ptr(), lddz, A_use.data_ptr(), lda_use, _lib.ptr(rs), B, N, K, w.data_ptr(), w.stride(0),
+                    dz.data_ptr(), lddz, A_use.data_ptr(), lda_use, _lib.ptr(rs), scol, B, N, K, w.data_ptr(), w.stride(0),
                     fs["exp_avg"].data_ptr(), fs["exp_avg_sq"].data_ptr(), db.data_ptr(), fs["lr"], fs["beta1"],
                     fs["beta2"], fs["eps"], fs["weight_decay"], fs["step"], fs["grad_scale"], st))
                 if not (self.gemm_dtype == "bf16" and _lib.shadow_info(w.data_ptr()) is not None):
@@ -450,12 +452,12 @@ class DenoiserEngine:
                     self._side2.wait_stream(torch.cuda.current_stream())
                     with torch.cuda.stream(self._side2):
                         _lib.check(lib.gdmcf_linear_bwd_weight_f32(dz.data_ptr(), lddz, A_use.data_ptr(), lda_use, _lib.ptr(rs),
-                                                                   B, N, K, dW.data_ptr(), dW.stride(0), db.data_ptr(), 0,
+                                                                   scol, B, N, K, dW.data_ptr(), dW.stride(0), db.data_ptr(), 0,
                                                                    _lib.stream_ptr()))
                     self._side2_used = True
                 else:
                     _lib.check(lib.gdmcf_linear_bwd_weight_f32(dz.data_ptr(), lddz, A_use.data_ptr(), lda_use, _lib.ptr(rs),
-                                                               B, N, K, dW.data_ptr(), dW.stride(0), db.data_ptr(), 0, st))
+                                                               scol, B, N, K, dW.data_ptr(), dW.stride(0), db.data_ptr(), 0, st))
             grads_w[li], grads_b[li] = dW, db
             if self.grad_sink is not None:
                 self.grad_sink(w, dW)

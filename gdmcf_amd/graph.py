@@ -37,9 +37,12 @@ class GraphedTrainStep:
                  force_exchange=False):
         dist = torch.distributed
         multi = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force_exchange)
+        # a gradient exchange can only be captured when its collectives are device work (backend "nccl" = RCCL): host-staged
+        # ones (gloo rehearsals) are not -- the step then runs eagerly in this process and `capture_error` says why
+        self._no_capture = None
         if multi and dist.get_backend(group) != "nccl":
-            raise NotImplementedError("GraphedTrainStep with a gradient exchange needs the nccl (RCCL) backend: host-staged "
-                                      "collectives cannot be captured")
+            self._no_capture = ("NotImplementedError: a captured gradient exchange needs the nccl (RCCL) backend; backend "
+                                f"'{dist.get_backend(group)}' stages its collectives through the host")
         if not isinstance(model, DNN) or model.norm or diffusion.mean_type != ModelMeanType.START_X:
             raise NotImplementedError("GraphedTrainStep: plain DNN denoiser without F.normalize, x0 target")
         if getattr(diffusion, "CatOneHot", False) or diffusion.rng != "philox" or diffusion.noise_scale == 0.0:
@@ -122,6 +125,10 @@ class GraphedTrainStep:
             self.lib.gdmcf_graph_state_bind(self._state.data_ptr())
             try:
                 if self.calls <= self.warmup or self.graph is False:
+                    self._dev_step += 1
+                    return self._body().clone()
+                if self._no_capture is not None:
+                    self.graph, self.capture_error = False, self._no_capture
                     self._dev_step += 1
                     return self._body().clone()
                 self.lib.gdmcf_prof_enable(0)  # event records cannot be captured

@@ -283,10 +283,12 @@ class OneHotEngine:
         N, K = w.shape
         dW = torch.empty_like(w)
         db = torch.empty_like(bias) if bias is not None else None
+        scol = 0
         if rs is not None:  # (rs . dZ)^T A == dZ^T (rs . A): scale the small activation instead of the big dZ
             _lib.check(lib.gdmcf_rowscale_f32(A_ptr, lda, rs.data_ptr(), B, K, bufs.hs.data_ptr(), bufs.hs.stride(0), st))
             A_ptr, lda = bufs.hs.data_ptr(), bufs.hs.stride(0)
-        _lib.check(lib.gdmcf_linear_bwd_weight_f32(dz_ptr, lddz, A_ptr, lda, _lib.ptr(rs), B, N, K, dW.data_ptr(),
+            scol = int(lda > K)  # the copy's column K then holds the row scale: db comes out of the product
+        _lib.check(lib.gdmcf_linear_bwd_weight_f32(dz_ptr, lddz, A_ptr, lda, _lib.ptr(rs), scol, B, N, K, dW.data_ptr(),
                                                    dW.stride(0), _lib.ptr(db), 0, st))
         if self.grad_sink is not None and bias is not None:
             self.grad_sink(w, dW)

@@ -89,7 +89,7 @@ class OneHotGCNEngine(OneHotEmbeddingEngine):
             w, bias = conv.lin.weight, conv.bias
             N, K = w.shape
             dW, db = torch.empty_like(w), torch.empty_like(bias)
-            _lib.check(lib.gdmcf_linear_bwd_weight_f32(dz.data_ptr(), dz.stride(0), A.data_ptr(), A.stride(0), None, B, N, K,
+            _lib.check(lib.gdmcf_linear_bwd_weight_f32(dz.data_ptr(), dz.stride(0), A.data_ptr(), A.stride(0), None, 0, B, N, K,
                                                        dW.data_ptr(), dW.stride(0), db.data_ptr(), 0, st))
             _lib.check(lib.gdmcf_linear_bwd_input_f32(dz.data_ptr(), dz.stride(0), w.data_ptr(), w.stride(0), None, A.data_ptr(),
                                                       A.stride(0), 0, B, N, K, dA.data_ptr(), dA.stride(0), bufs.ws.data_ptr(),

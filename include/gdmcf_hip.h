@@ -213,27 +213,28 @@ int gdmcf_linear_bwd_input_f32(const float* dZ, int64_t lddz, const float* W, in
                                size_t ws_bytes, void* stream);
 /* dW[N,K] = dZ[M,N]^T @ A[M,K]  (weight grad; accumulate != 0 adds into dW)
  * db[N]   = sum_m rowscale[m]*dZ[m,n]   (db NULL -> skipped).  When rowscale != NULL the
- * caller passes A already multiplied by rowscale (see gdmcf_rowscale_f32).  When A is the
- * copy the calling thread's LAST gdmcf_rowscale_f32 call wrote with the same rowscale on the
- * same stream and lda > K, column K of that copy holds rowscale[m] and db comes out of the
- * product as its column K (no second pass over dZ); any other A takes a column-sum pass --
- * same result within float32 rounding.  The caller must not overwrite A[:, K] in between;
- * the record of the copy is consumed by the first gdmcf_linear_bwd_weight_* call after it.   */
+ * caller passes A already multiplied by rowscale (see gdmcf_rowscale_f32).
+ * a_scale_col != 0 is the caller's statement that lda > K and A[m, K] == rowscale[m] for every
+ * row m -- which is how gdmcf_rowscale_f32 leaves its output when ldo > K: db then comes out of
+ * the product as its column K (no second pass over dZ).  The library keeps NO record between
+ * calls and does not check the column; with a_scale_col == 0 (any A, any column K) db takes a
+ * column-sum pass over dZ -- the same result within float32 rounding.  Kernels that cannot
+ * carry the extra column (bf16 / f32x3 modes, small shapes) ignore the flag and take the pass. */
 int gdmcf_linear_bwd_weight_f32(const float* dZ, int64_t lddz, const float* A, int64_t lda,
-                                const float* rowscale, int M, int N, int K, float* dW,
-                                int64_t lddw, float* db, int accumulate, void* stream);
-/* Weight gradient fused with the AdamW update of that weight (single-GPU optimiser-in-backward, opt-in):
+                                const float* rowscale, int a_scale_col, int M, int N, int K,
+                                float* dW, int64_t lddw, float* db, int accumulate, void* stream);
+/* Weight gradient fused with the AdamW update of that weight (single-GPU optimiser-in-backward):
  * G = dZ^T @ A stays in the MFMA accumulators and W, exp_avg, exp_avg_sq ([N,K], row stride ldw, all three) are
  * updated in the epilogue with torch.optim.AdamW's single-tensor math for step number `step`
  * (32 -> 24 B/param of HBM traffic; the gradient is never materialised).  W must not be read by later
- * kernels of the same backward pass (the caller computes the input gradient first).              */
+ * kernels of the same backward pass (the caller computes the input gradient first).  a_scale_col: as above. */
 int gdmcf_linear_bwd_weight_adamw_f32(const float* dZ, int64_t lddz, const float* A, int64_t lda,
-                                      const float* rowscale, int M, int N, int K, float* W, int64_t ldw,
-                                      float* exp_avg, float* exp_avg_sq, float* db, float lr, float beta1,
-                                      float beta2, float eps, float weight_decay, int step,
+                                      const float* rowscale, int a_scale_col, int M, int N, int K, float* W,
+                                      int64_t ldw, float* exp_avg, float* exp_avg_sq, float* db, float lr,
+                                      float beta1, float beta2, float eps, float weight_decay, int step,
                                       float grad_scale, void* stream);
 /* out[m, k] = rowscale[m] * A[m, k], k < K (the scaled activation copy of the weight-gradient product: (rs . dZ)^T A ==
- * dZ^T (rs . A)); with ldo > K also out[m, K] = rowscale[m] (see gdmcf_linear_bwd_weight_f32).                         */
+ * dZ^T (rs . A)); with ldo > K also out[m, K] = rowscale[m]: the column gdmcf_linear_bwd_weight_*'s a_scale_col speaks of. */
 int gdmcf_rowscale_f32(const float* A, int64_t lda, const float* rowscale, int M, int K, float* out,
                        int64_t ldo, void* stream);
 /* ---- pieces of the indexIn backbone DNNOneHotEmbedding (models/DNN.py:510-682) ----------------

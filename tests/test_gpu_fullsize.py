@@ -219,7 +219,7 @@ def test_weight_gradient_product_every_element_against_float64(B, N, K):
     for use_db, use_rs in [(0, 0), (1, 0), (1, 1)]:
         dW = torch.full((N, K), float("nan"), device=DEV)
         db = torch.full((N,), float("nan"), device=DEV)
-        _lib.check(lib.gdmcf_linear_bwd_weight_f32(dZ.data_ptr(), ldz, A.data_ptr(), lda, rs.data_ptr() if use_rs else None, B, N, K,
+        _lib.check(lib.gdmcf_linear_bwd_weight_f32(dZ.data_ptr(), ldz, A.data_ptr(), lda, rs.data_ptr() if use_rs else None, 0, B, N, K,
                                                    dW.data_ptr(), K, db.data_ptr() if use_db else None, 0, _lib.stream_ptr()))
         torch.cuda.synchronize()
         assert float((dW.double() - ref).abs().max()) <= 2e-6 * scale * max(1.0, (B / 400) ** 0.5), (use_db, use_rs)
@@ -232,7 +232,7 @@ def test_weight_gradient_product_every_element_against_float64(B, N, K):
     # twenty more launches, each bit-identical to the first
     for _ in range(20):
         dW = torch.full((N, K), float("nan"), device=DEV)
-        _lib.check(lib.gdmcf_linear_bwd_weight_f32(dZ.data_ptr(), ldz, A.data_ptr(), lda, None, B, N, K, dW.data_ptr(), K, None, 0,
+        _lib.check(lib.gdmcf_linear_bwd_weight_f32(dZ.data_ptr(), ldz, A.data_ptr(), lda, None, 0, B, N, K, dW.data_ptr(), K, None, 0,
                                                    _lib.stream_ptr()))
         torch.cuda.synchronize()
         assert torch.equal(dW, outs[0])
@@ -321,7 +321,7 @@ def test_fused_adamw_weight_gradient_every_element_against_float64(B, N, K):
     outs = []
     for _ in range(2):
         W, me, ve = W0.clone(), m0.clone(), v0.clone()
-        _lib.check(lib.gdmcf_linear_bwd_weight_adamw_f32(dZ.data_ptr(), ldz, A.data_ptr(), lda, None, B, N, K, W.data_ptr(), K,
+        _lib.check(lib.gdmcf_linear_bwd_weight_adamw_f32(dZ.data_ptr(), ldz, A.data_ptr(), lda, None, 0, B, N, K, W.data_ptr(), K,
                                                          me.data_ptr(), ve.data_ptr(), None, lr, b1, b2, eps, wd, step, gs,
                                                          _lib.stream_ptr()))
         torch.cuda.synchronize()
@@ -352,12 +352,12 @@ def test_bias_gradient_as_a_column_of_the_weight_gradient_product(B, N, K):
     for ldo in (K + 24, K):
         hs = torch.zeros(B, ldo, device=DEV)
         for rep in range(21 if ldo > K else 1):
-            # (the record of the scaled copy is consumed by the product that follows it: one rowscale call per product)
             _lib.check(lib.gdmcf_rowscale_f32(h.data_ptr(), K, rs.data_ptr(), B, K, hs.data_ptr(), ldo, _lib.stream_ptr()))
             dW = torch.full((N, K), float("nan"), device=DEV)
             db = torch.full((N,), float("nan"), device=DEV)
-            _lib.check(lib.gdmcf_linear_bwd_weight_f32(dZ.data_ptr(), ldz, hs.data_ptr(), ldo, rs.data_ptr(), B, N, K, dW.data_ptr(), K,
-                                                       db.data_ptr(), 0, _lib.stream_ptr()))
+            # a_scale_col: the caller's statement that column K of the operand holds the row scale (ldo > K only)
+            _lib.check(lib.gdmcf_linear_bwd_weight_f32(dZ.data_ptr(), ldz, hs.data_ptr(), ldo, rs.data_ptr(), int(ldo > K), B, N, K,
+                                                       dW.data_ptr(), K, db.data_ptr(), 0, _lib.stream_ptr()))
             torch.cuda.synchronize()
             if rep == 0:
                 if ldo > K:
@@ -367,5 +367,29 @@ def test_bias_gradient_as_a_column_of_the_weight_gradient_product(B, N, K):
                 res.append((dW, db))
             else:
                 assert torch.equal(dW, res[-1][0]) and torch.equal(db, res[-1][1]), rep
+    # No state travels between the two calls (the former thread-local record matched on addresses): a caller that
+    # REWRITES the scaled copy after gdmcf_rowscale_f32 -- same address, same row scale, column K now garbage -- and does not
+    # claim the column gets db from the column-sum pass, right; and the flag alone decides, whatever ran before.
+    ldo = K + 24
+    hs = torch.zeros(B, ldo, device=DEV)
+    _lib.check(lib.gdmcf_rowscale_f32(h.data_ptr(), K, rs.data_ptr(), B, K, hs.data_ptr(), ldo, _lib.stream_ptr()))
+    hs[:, K] = 123.0   # the column is gone
+    hs[:, :K] = h * rs[:, None] * 2.0  # and the operand is another one
+    dW = torch.full((N, K), float("nan"), device=DEV)
+    db = torch.full((N,), float("nan"), device=DEV)
+    _lib.check(lib.gdmcf_linear_bwd_weight_f32(dZ.data_ptr(), ldz, hs.data_ptr(), ldo, rs.data_ptr(), 0, B, N, K, dW.data_ptr(), K,
+                                               db.data_ptr(), 0, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    assert float((db.double() - dref).abs().max()) <= 2e-6 * float(dref.abs().max()) * max(1.0, (B / 400) ** 0.5)
+    assert float((dW.double() - 2.0 * ref).abs().max()) <= 4e-6 * float(ref.abs().max()) * max(1.0, (B / 400) ** 0.5)
+    # the same operand without any preceding gdmcf_rowscale_f32 call, the column written by the caller itself: flag honoured
+    hs2 = torch.zeros(B, ldo, device=DEV)
+    hs2[:, :K] = h * rs[:, None]
+    hs2[:, K] = rs
+    db2 = torch.full((N,), float("nan"), device=DEV)
+    _lib.check(lib.gdmcf_linear_bwd_weight_f32(dZ.data_ptr(), ldz, hs2.data_ptr(), ldo, rs.data_ptr(), 1, B, N, K, dW.data_ptr(), K,
+                                               db2.data_ptr(), 0, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(db2, res[0][1])
     assert torch.equal(res[0][0], res[1][0])  # the product itself does not change with the extra column
     assert float((res[0][1].double() - res[1][1].double()).abs().max()) <= 4e-6 * float(dref.abs().max())

@@ -1289,7 +1289,7 @@ def _linear_entry_points_random_shapes(lib, prec, shadows=False, shapes=None, se
             # backward wrt weight: dW = dZ^T @ A, db = sum_m rs*dZ
             dW = torch.full((N, ldw), float("nan"), device=DEV)
             db = torch.empty(N, device=DEV)
-            _lib.check(lib.gdmcf_linear_bwd_weight_f32(dZ.data_ptr(), ldc, A.data_ptr(), lda, rs.data_ptr(), M, N, K, dW.data_ptr(),
+            _lib.check(lib.gdmcf_linear_bwd_weight_f32(dZ.data_ptr(), ldc, A.data_ptr(), lda, rs.data_ptr(), 0, M, N, K, dW.data_ptr(),
                                                        ldw, db.data_ptr(), 0, st))
             r3 = D(dZ[:, :N]).T @ D(A[:, :K])
             assert close(dW[:, :K].double(), r3), ("bwd_weight", M, N, K, pad)

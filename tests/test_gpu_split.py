@@ -55,7 +55,7 @@ def test_split_products_carry_f32_level_error():
                                                      rowpart.data_ptr(), rowsum.data_ptr(), st))
             _lib.check(lib.gdmcf_linear_bwd_input_f32(dz.data_ptr(), I, W2.data_ptr(), Hd, rs.data_ptr(), h.data_ptr(), Hd, 0, B, I, Hd,
                                                       dA.data_ptr(), Hd, ws.data_ptr(), ws_bytes, st))
-            _lib.check(lib.gdmcf_linear_bwd_weight_f32(dz.data_ptr(), I, h.data_ptr(), Hd, rs.data_ptr(), B, I, Hd, dW.data_ptr(), Hd,
+            _lib.check(lib.gdmcf_linear_bwd_weight_f32(dz.data_ptr(), I, h.data_ptr(), Hd, rs.data_ptr(), 0, B, I, Hd, dW.data_ptr(), Hd,
                                                        db.data_ptr(), 0, st))
             res[mode] = {"fwd": _errors(C1, want["fwd"]), "loss": _errors(out, want["loss"]), "dh": _errors(dA, want["dh"]),
                          "dW": _errors(dW, want["dW"])}

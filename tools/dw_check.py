@@ -12,7 +12,7 @@ for (B, N, K) in [(400, 34395, 1000), (400, 1000, 34405), (400, 94949, 1000), (4
     ref = (dZ[:, :N].double().t() @ A[:, :K].double())
     for use_db, use_rs in [(0, 0), (1, 0), (1, 1)]:
         dW = torch.full((N, K), float("nan"), device=dev); db = torch.full((N,), float("nan"), device=dev)
-        _lib.check(lib.gdmcf_linear_bwd_weight_f32(dZ.data_ptr(), ldz, A.data_ptr(), lda, rs.data_ptr() if use_rs else None, B, N, K,
+        _lib.check(lib.gdmcf_linear_bwd_weight_f32(dZ.data_ptr(), ldz, A.data_ptr(), lda, rs.data_ptr() if use_rs else None, 0, B, N, K,
                                                    dW.data_ptr(), K, db.data_ptr() if use_db else None, 0, _lib.stream_ptr()))
         torch.cuda.synchronize()
         err = float((dW.double() - ref).abs().max() / ref.abs().max())

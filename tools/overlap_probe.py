@@ -16,7 +16,7 @@ opt = gdmcf_amd.FusedAdamW([p], lr=1e-5, weight_decay=0.0)
 s2 = torch.cuda.Stream()
 
 def gemm():
-    _lib.check(lib.gdmcf_linear_bwd_weight_f32(dz.data_ptr(), dz.stride(0), xin.data_ptr(), xin.stride(0), None, B, H, I + 10,
+    _lib.check(lib.gdmcf_linear_bwd_weight_f32(dz.data_ptr(), dz.stride(0), xin.data_ptr(), xin.stride(0), None, 0, B, H, I + 10,
                                                dW.data_ptr(), dW.stride(0), None, 0, _lib.stream_ptr()))
 def timeit(fn, n=30):
     for _ in range(3): fn()

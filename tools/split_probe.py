@@ -40,9 +40,9 @@ calls = {
                                                           rowsum.data_ptr(), st),
     "dh   [B,I]x[I,H]": lambda: lib.gdmcf_linear_bwd_input_f32(dz.data_ptr(), I, W2.data_ptr(), H, rs.data_ptr(), act.data_ptr(), H, 0, B, I, H,
                                                            dA.data_ptr(), H, ws.data_ptr(), ws_bytes, st),
-    "dW2  [I,B]x[B,H]": lambda: lib.gdmcf_linear_bwd_weight_f32(dz.data_ptr(), I, h.data_ptr(), H, rs.data_ptr(), B, I, H, dW2.data_ptr(), H,
+    "dW2  [I,B]x[B,H]": lambda: lib.gdmcf_linear_bwd_weight_f32(dz.data_ptr(), I, h.data_ptr(), H, rs.data_ptr(), 0, B, I, H, dW2.data_ptr(), H,
                                                             db2.data_ptr(), 0, st),
-    "dW1  [H,B]x[B,I]": lambda: lib.gdmcf_linear_bwd_weight_f32(dh.data_ptr(), H, xin.data_ptr(), K1, rs.data_ptr(), B, H, K1, dW1.data_ptr(), K1,
+    "dW1  [H,B]x[B,I]": lambda: lib.gdmcf_linear_bwd_weight_f32(dh.data_ptr(), H, xin.data_ptr(), K1, rs.data_ptr(), 0, B, H, K1, dW1.data_ptr(), K1,
                                                             db1.data_ptr(), 0, st),
 }
 D = lambda t: t.double()
