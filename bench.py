@@ -100,9 +100,15 @@ def parse():
                          "reported under 'strong_scaling'")
     ap.add_argument("--no-strong-leg", action="store_true", help="N > 1: skip the extra strong-scaling leg")
     ap.add_argument("--fuse-optimizer", action="store_true",
-                    help="single GPU: update the two large weights inside the weight-gradient GEMM epilogue "
-                         "(FusedAdamW.fuse_into_backward); same update rule, gradient never materialised")
-    ap.add_argument("--no-fused-leg", action="store_true", help="N = 1: skip the extra leg with AdamW fused into the dW epilogues")
+                    help="(the default at N = 1 with the plain denoiser since round 4) update the two large weights inside "
+                         "their weight-gradient products (FusedAdamW.fuse_into_backward); same update rule, gradient never "
+                         "materialised")
+    ap.add_argument("--separate-optimizer", action="store_true",
+                    help="N = 1: keep AdamW as a separate pass after the backward in the main line (what N > 1 always does: the "
+                         "gradients are exchanged first)")
+    ap.add_argument("--no-fused-leg", action="store_true",
+                    help="N = 1: skip the extra leg that times the OTHER optimiser placement (separate pass when the main line "
+                         "is fused, and vice versa)")
     ap.add_argument("--f32x3-leg", action="store_true",
                     help="N = 1, fp32: also time the step with gemm_dtype='f32x3' (opt-in product mode, DESIGN 4.4b)")
     ap.add_argument("--no-configs2-leg", action="store_true",
@@ -133,6 +139,9 @@ def parse():
     if args.strong and not args.global_batch:
         args.global_batch = 400
     default_line = args.backbone == "dnn" and not args.rehearse_dp
+    # single GPU, plain denoiser: AdamW of the two large weights runs inside their weight-gradient products unless asked otherwise
+    args.fuse_main = (args.gpus == 1 and args.backbone == "dnn" and not args.rehearse_dp and not args.separate_optimizer) \
+        or args.fuse_optimizer
     args.spmm = (args.spmm or default_line) and not args.no_spmm
     args.sampling = (args.sampling or default_line) and not args.no_sampling
     return args
@@ -141,7 +150,7 @@ def parse():
 def default_line_only(args):
     """the command the driver runs (plain denoiser, Yelp shape, fp32, no variant flags): only that line carries the extra legs"""
     return (args.backbone == "dnn" and args.workload == "yelp" and args.gemm_dtype == "f32" and not args.rehearse_dp
-            and not args.fuse_optimizer and not args.global_batch and args.batch == 400 and args.hidden == 1000)
+            and not args.separate_optimizer and not args.global_batch and args.batch == 400 and args.hidden == 1000)
 
 
 def collect_prof(lib, cap=65536):
@@ -372,6 +381,7 @@ def main():
     if args.backbone != "dnn":
         if args.fuse_optimizer:
             raise SystemExit("--backbone onehot*: separate AdamW pass only")
+        args.fuse_main = False
         if args.backbone == "onehot":
             model = gdmcf_amd.DNNOneHot([I, hid], [hid, I], 10, time_type="cat", norm=False, gemm_dtype=args.gemm_dtype).to(dev)
         else:
@@ -385,7 +395,8 @@ def main():
         model = gdmcf_amd.DNN([I, hid], [hid, I], 10, time_type="cat", norm=False, gemm_dtype=args.gemm_dtype).to(dev)
         diffusion = gdmcf_amd.GaussianDiffusion(gdmcf_amd.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, T, dev)
     opt = gdmcf_amd.FusedAdamW(model.parameters(), lr=1e-5, weight_decay=0.0)
-    if args.fuse_optimizer and world == 1:
+    fuse_main = bool(args.fuse_main and world == 1)
+    if fuse_main:
         opt.fuse_into_backward(model)
     model.train()
     torch.manual_seed(1234 + rank)
@@ -533,9 +544,12 @@ def main():
     # ---- N = 1: the same step with AdamW inside the weight-gradient GEMM epilogues (FusedAdamW.fuse_into_backward:
     # same update rule, bit-identical weights by test; opt-in because `.grad` of the two big weights is then never
     # materialised).  Reported beside the main line, which keeps backward(); optimizer.step() as the reference's loop. ----
-    fused_leg = None
-    if world == 1 and args.backbone == "dnn" and not args.fuse_optimizer and not args.rehearse_dp and not args.no_fused_leg:
-        opt.fuse_into_backward(model)
+    fused_leg = separate_leg = None
+    if world == 1 and args.backbone == "dnn" and not args.rehearse_dp and not args.no_fused_leg:
+        if fuse_main:
+            opt.fuse_into_backward(model, min_numel=1 << 62)  # off: the separate pass
+        else:
+            opt.fuse_into_backward(model)
         for i in range(max(3, args.warmup // 4)):
             step(rows_of(i % n_pool), True)
         sync()
@@ -544,10 +558,20 @@ def main():
             loss_f = step(rows_of(i % n_pool), True)
         sync()
         ef = time.perf_counter() - t1
-        fused_leg = dict(ms_per_step=round(1e3 * ef / args.steps, 4), users_per_s=round(B * args.steps / ef, 1), steps=args.steps,
-                         final_loss=float(loss_f), what="AdamW of the two large weights fused into their weight-gradient GEMM "
-                         "epilogues (bench.py --fuse-optimizer makes it the main line)")
-        opt.fuse_into_backward(model, min_numel=1 << 62)  # off again
+        other = dict(ms_per_step=round(1e3 * ef / args.steps, 4), users_per_s=round(B * args.steps / ef, 1), steps=args.steps,
+                     final_loss=float(loss_f))
+        if fuse_main:
+            separate_leg = dict(other, what="the same step with AdamW as a separate pass after the backward (28 B/param, one "
+                                            "launch): bench.py --separate-optimizer makes it the main line; N > 1 always runs it")
+            opt.fuse_into_backward(model)  # back to the main line's placement
+        else:
+            fused_leg = dict(other, what="AdamW of the two large weights inside their weight-gradient products (the default main "
+                                         "line at N = 1)")
+            opt.fuse_into_backward(model, min_numel=1 << 62)
+    if fuse_main:
+        fused_leg = dict(ms_per_step=round(1e3 * el / args.steps, 4), users_per_s=round(world * B * args.steps / el, 1),
+                         steps=args.steps, is_main_line=True,
+                         what="the main line: AdamW of the two large weights inside their weight-gradient products")
 
     # ---- N = 1: the same step captured once in a hipGraph and replayed (gdmcf_amd/graph.py: counters and AdamW scalars in
     # device memory, batch = a fixed id buffer over the resident CSR matrix; bit-identical to the eager step by test).
@@ -556,11 +580,13 @@ def main():
     # With --rehearse-dp (one-rank RCCL group) the captured body includes every collective of the data-parallel step; at N > 1
     # the leg is opt-in (--graph-dp): all ranks capture the same collectives.
     graph_dp = (args.rehearse_dp and world == 1) or (world > 1 and args.graph_dp)
-    if (world == 1 or graph_dp) and args.backbone == "dnn" and sparse_rows and not args.fuse_optimizer \
+    if (world == 1 or graph_dp) and args.backbone == "dnn" and sparse_rows \
             and (not args.rehearse_dp or graph_dp) and not args.no_graph_leg:
         from gdmcf_amd.graph import GraphedTrainStep
         try:
             step.flush()
+            if fuse_main:
+                opt.fuse_into_backward(model, min_numel=1 << 62)  # the captured step keeps the separate pass
             with GraphedTrainStep(diffusion, model, opt, dcsr, B, warmup=3, force_exchange=args.rehearse_dp) as gstep:
                 for i in range(max(5, args.warmup // 4)):
                     gstep(row_ids[i % n_pool])
@@ -572,6 +598,8 @@ def main():
                 sync()
                 eg = time.perf_counter() - t1
                 captured, cap_err = isinstance(gstep.graph, torch.cuda.CUDAGraph), gstep.capture_error
+            if fuse_main:
+                opt.fuse_into_backward(model)
             if dist.is_initialized():
                 tg = torch.tensor([eg, hg], dtype=torch.float64, device=dev)
                 dist.all_reduce(tg, op=dist.ReduceOp.MAX)
@@ -588,7 +616,7 @@ def main():
     # bfloat16 terms, six bf16 MFMAs per block, f32 accumulate: f32-level error -- tests/test_gpu_split.py measures it against
     # float64 beside the native f32 MFMA kernels).  Reported beside the main line, which stays on v_mfma_f32_16x16x4_f32. ----
     x3_leg = None
-    if world == 1 and args.backbone == "dnn" and args.gemm_dtype == "f32" and not args.fuse_optimizer and not args.rehearse_dp \
+    if world == 1 and args.backbone == "dnn" and args.gemm_dtype == "f32" and not args.rehearse_dp \
             and args.f32x3_leg:
         model.gemm_dtype = "f32x3"
         try:
@@ -609,9 +637,19 @@ def main():
     # ---- roofline of the dominant kernel (rank 0's events) ----
     roofline = None
     klist = kernel_table(kernels, args.gemm_dtype, B, hid, I, args.steps, n_profiled, el)
+    if fuse_main:
+        # the weight-gradient launches also carry the optimiser stream of their weight (W, exp_avg, exp_avg_sq read and written
+        # once: 24 B per parameter): report its rate beside the matrix rate -- the launch is bound by max(MFMA time, stream time)
+        for kk in klist:
+            if kk["kernel"] == "bwd_weight_gemm":
+                byt = 24.0 * (I * hid + hid * (I + 10)) / 2.0
+                kk["kernel"] = "bwd_weight_gemm + AdamW stream"
+                kk["optimizer_stream"] = dict(bytes_per_launch=int(byt), achieved=round(byt / (kk["avg_ms"] * 1e-3) / 1e9, 1),
+                                              peak=PEAK_HBM_GBPS, unit="GB/s", frac=round(byt / (kk["avg_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
+                                              what="24 B per parameter of the updated weight, inside the same launch")
     if klist:
         k0 = klist[0]
-        traffic, traffic_note = measured_traffic(k0["kernel"], args.workload, args.gemm_dtype)
+        traffic, traffic_note = measured_traffic(k0["kernel"].split(" + ")[0], args.workload, args.gemm_dtype)
         roofline = dict(bound=k0["bound"], achieved=k0["achieved"], peak=k0["peak"], unit=k0["unit"], frac=k0["frac"],
                         traffic=traffic, traffic_source=traffic_note, kernel=k0["kernel"], avg_ms=k0["avg_ms"],
                         launches_per_step=k0["launches"] // max(n_profiled, 1), profiled_steps=n_profiled,
@@ -619,6 +657,8 @@ def main():
                                      "command (profiles/r03_hbm_traffic.json)",
                         algorithmic_unit=("2*M*N*K FLOP per launch" if k0["bound"] == "mfma" else
                                           "compulsory bytes per launch (operands and results once; AdamW 28 B/param)"))
+        if "optimizer_stream" in k0:
+            roofline["optimizer_stream"] = k0["optimizer_stream"]
 
     if world > 1:
         eval_legs()
@@ -660,10 +700,11 @@ def main():
             "host_enqueue_ms_per_step": round(1e3 * host_el / args.steps, 4), "clock_preheat": preheat,
             "rehearsal": ("ranks share the visible GPU(s), gloo group with host-staged collectives (GDMCF_BENCH_SHARE_GPU=1): "
                           "launcher / step rehearsal, not a measurement") if (share and world > 1) else None,
-            "replicas_in_sync": in_sync, "dp_autotune": dp_autotune, "strong_scaling": strong_leg, "fused_optimizer_leg": fused_leg, "graph_leg": graph_leg, "f32x3_leg": x3_leg,
+            "replicas_in_sync": in_sync, "dp_autotune": dp_autotune, "strong_scaling": strong_leg, "fused_optimizer_leg": fused_leg, "separate_optimizer_leg": separate_leg, "graph_leg": graph_leg, "f32x3_leg": x3_leg,
             "configs2_leg": configs2_leg,
             "ranks_in_group": dist.get_world_size() if dist.is_initialized() else 1,
-            "optimizer": "FusedAdamW" + (" fused into the dW GEMM epilogues" if (args.fuse_optimizer and world == 1) else
+            "optimizer": "FusedAdamW" + (" inside the weight-gradient products of the two large weights (optimiser stream interleaved "
+                                         "into their k loops); separate pass for the small tensors" if fuse_main else
                                          " (row-sharded over the ranks: reduce-scatter, AdamW on 1/N rows, deferred all-gather)"
                                          if (sharded and step.exchange) else
                                          " (separate pass after the gradient all-reduce)" if step.exchange else " (separate pass)"),

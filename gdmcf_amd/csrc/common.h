@@ -76,17 +76,30 @@ struct GdAdamHyper {
     float eps;
     float neg_step;  // -lr / (1 - beta1^step)
     float grad_scale;
+    float inv_bc2_sqrt;  // 1 / sqrt(1 - beta2^step), from the double
+    float pad_[3];       // (16-byte multiple: the struct is copied to the device in tables)
 };
 GdAdamHyper gd_adam_hyper(float lr, float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale);
 
+// One element of torch.optim.AdamW's single-tensor update (torch/optim/adamw.py; reference main.py:258, :351).
+// Every kernel that updates parameters inlines THIS function (the stand-alone pass, the epilogues of the LDS-tiled products, the
+// optimiser stream of the register-streaming product -- whose row groups go through one of three code paths depending on which
+// wave picks a tile when): its rounding must not depend on the instance, or results would differ from run to run.  Hence no
+// compiler contraction (the fused multiply-adds are written out), and the two divisions and the square root of the step --
+// p -= step_size * m / (sqrt(v) / sqrt(bc2) + eps) -- as hardware reciprocal / square root (1 ulp each) instead of the correctly
+// rounded sequences (~45 of the update's ~60 instructions).  v_mfma_f32_16x16x4_f32 runs at the vector rate ON the vector
+// ALUs' issue port (measured round 4: arithmetic placed beside the MFMAs of a SIMD's other wave does not overlap, it adds), so in
+// the fused product those instructions are matrix time lost.  The step term is then within ~3e-7 (relative) of the correctly
+// rounded one, i.e. within 1e-12 absolute at lr = 1e-5: below half an ulp of any weight it is added to, except on rounding
+// ties.  exp_avg and exp_avg_sq are exactly the reference's fused-multiply-add forms.
 __device__ __forceinline__ void gd_adam_elem(float& p, float g, float& m, float& v, const GdAdamHyper& h) {
-    g *= h.grad_scale;
+#pragma clang fp contract(off)
+    g = g * h.grad_scale;
     p = p * h.decay;
-    m = m + (g - m) * h.one_m_b1;
-    v = v * h.beta2;
-    v = v + (h.one_m_b2 * g) * g;
-    const float denom = sqrtf(v) / h.bc2_sqrt + h.eps;
-    p = p + (h.neg_step * m) / denom;
+    m = __builtin_fmaf(g - m, h.one_m_b1, m);
+    v = __builtin_fmaf(h.one_m_b2 * g, g, v * h.beta2);
+    const float denom = __builtin_fmaf(__builtin_amdgcn_sqrtf(v), h.inv_bc2_sqrt, h.eps);
+    p = __builtin_fmaf(h.neg_step * m, __builtin_amdgcn_rcpf(denom), p);
 }
 
 // ---- graph step state (kernels_misc.hip: gdmcf_graph_state_*) ---------------------------------------------------------

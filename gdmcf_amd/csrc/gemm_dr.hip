@@ -69,18 +69,26 @@ __device__ __forceinline__ unsigned int dr_ticket_issue(unsigned int* ctr) {
     return t;
 }
 
+#ifndef GD_ADAMW_DBG
+#define GD_ADAMW_DBG 0
+#endif
+#ifndef DR_ADAM_UB
+#define DR_ADAM_UB 2  // row groups per batch of the fused-AdamW epilogue pipeline (dr_tn_kernel)
+#endif
+
 struct DrArgs {
     GdGemm g;
     int tiles_m, tiles_n, m_fastest;
     int ksp;      // k-steps run per tile (a multiple of the ring size; steps past K load zeros)
     int ctr;      // index into g_dr_ticket (dr_ticket_slot: a set of its own for every launch that may be in flight)
+    const GdAdamHyper* adam_dev;  // fused AdamW: this step's scalars in device memory (graph replay), NULL = GdGemm::adam
     int stagger;  // waves 4-7 of a workgroup start this many x 3.4 us later
 };
 
 // C[M,N] = A[K,M]^T * B[K,N], both operands row-contiguous.  TA / TB: 64-row load units per operand and k-step.
 template <int TA, int TB, int D, int EPI>
 __global__ __launch_bounds__(512, 2) void dr_tn_kernel(const DrArgs d) {
-    static_assert(EPI == GD_EPI_STORE || EPI == GD_EPI_ADAMW, "weight-gradient products");
+    static_assert(EPI == GD_EPI_STORE, "plain weight-gradient product (the fused-AdamW form: dr_tn_adamw_kernel)");
     constexpr int LPS = TA + TB;  // loads per k-step
     constexpr int R = D + 1;
     static_assert(LPS * D <= 63, "vmcnt is a 6-bit counter");
@@ -245,6 +253,12 @@ __global__ __launch_bounds__(512, 2) void dr_tn_kernel(const DrArgs d) {
             const int n = n0 + 64 * b + 4 * r;
             const uint32_t vo = (uint32_t)(16 * q * g.ldc + n) * 4u;
             if (n + 3 < (g.out2 ? g.N - 1 : g.N)) {  // (a bias column, the last one, never goes out with a 16-byte group)
+                // The row offset travels in the VGPR offset, the scalar offset field stays 0.  With an SGPR there hipcc emits
+                // `buffer_store_dwordx4 v[146:149], v0, s[36:39], s10 offen` and refills v146..149 for the next row in the very
+                // next instruction: LLVM's hazard recognizer holds that a store of more than 64 bits needs no wait state before
+                // its data registers are rewritten when soffset is a register -- on gfx950 it does: lanes 12-15 of every
+                // 16-lane row of the FIRST data register went out with the next row's values, in timing-dependent launches
+                // (DESIGN 4.1b).  With soffset = 0 the recognizer inserts the s_nop itself.
 #pragma unroll
                 for (int a = 0; a < TA; ++a)
 #pragma unroll
@@ -252,37 +266,10 @@ __global__ __launch_bounds__(512, 2) void dr_tn_kernel(const DrArgs d) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             f32x4 gv = {acc[a][e][b][0][t], acc[a][e][b][1][t], acc[a][e][b][2][t], acc[a][e][b][3][t]};
-                            // The row offset travels in the VGPR offset, the scalar offset field stays 0.  With an SGPR there hipcc
-                            // emits `buffer_store_dwordx4 v[146:149], v0, s[36:39], s10 offen` and refills v146..149 for the next row
-                            // in the very next instruction: LLVM's hazard recognizer holds that a store of more than 64 bits needs no
-                            // wait state before its data registers are rewritten when soffset is a register -- on gfx950 it does:
-                            // lanes 12-15 of every 16-lane row of the FIRST data register went out with the next row's values, in
-                            // timing-dependent launches.  With soffset = 0 the recognizer inserts the s_nop itself.
                             const uint32_t so = (uint32_t)(m0 + 64 * a + 4 * t + e) * (uint32_t)g.ldc * 4u;
-                            if (EPI == GD_EPI_STORE) {
-                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, gv), srdC, vo + so, 0, 0);
-                            } else {
-                                const __amdgpu_buffer_rsrc_t srdM = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.aux), 0, (int)c_bytes, 0x00020000);
-                                const __amdgpu_buffer_rsrc_t srdV = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.aux2), 0, (int)c_bytes, 0x00020000);
-                                f32x4 pv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdC, vo + so, 0, 0));
-                                f32x4 mv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdM, vo + so, 0, 0));
-                                f32x4 vv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdV, vo + so, 0, 0));
-#pragma unroll
-                                for (int k = 0; k < 4; ++k) {
-                                    float pk = pv[k], mk = mv[k], vk = vv[k];
-                                    gd_adam_elem(pk, gv[k], mk, vk, g.adam);
-                                    pv[k] = pk;
-                                    mv[k] = mk;
-                                    vv[k] = vk;
-                                }
-                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pv), srdC, vo + so, 0, 0);
-                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, mv), srdM, vo + so, 0, 0);
-                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vv), srdV, vo + so, 0, 0);
-                            }
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, gv), srdC, vo + so, 0, 0);
                         }
             } else if (n < g.N) {  // the lane's four columns straddle N (last column tile only)
-                float* __restrict__ Mo = const_cast<float*>(g.aux);
-                float* __restrict__ Vo = const_cast<float*>(g.aux2);
                 for (int a = 0; a < TA; ++a)
                     for (int t = 0; t < 4; ++t)
                         for (int e = 0; e < 4; ++e) {
@@ -290,21 +277,9 @@ __global__ __launch_bounds__(512, 2) void dr_tn_kernel(const DrArgs d) {
                             if (m >= g.M) continue;
                             for (int k = 0; k < 4; ++k) {
                                 if (n + k >= g.N) continue;
-                                const int64_t o = (int64_t)m * g.ldc + n + k;
                                 const float gk = acc[a][e][b][k][t];
-                                if (g.out2 && n + k == g.N - 1) {  // the bias column (operand B's extra column): its own vector
-                                    g.out2[m] = gk;
-                                    continue;
-                                }
-                                if (EPI == GD_EPI_STORE) {
-                                    g.C[o] = gk;
-                                } else {
-                                    float pk = g.C[o], mk = Mo[o], vk = Vo[o];
-                                    gd_adam_elem(pk, gk, mk, vk, g.adam);
-                                    g.C[o] = pk;
-                                    Mo[o] = mk;
-                                    Vo[o] = vk;
-                                }
+                                if (g.out2 && n + k == g.N - 1) g.out2[m] = gk;  // the bias column (operand B's extra column): its own vector
+                                else g.C[(int64_t)m * g.ldc + n + k] = gk;
                             }
                         }
             }
@@ -321,6 +296,433 @@ __global__ __launch_bounds__(512, 2) void dr_tn_kernel(const DrArgs d) {
         for (int a = 0; a < TA; ++a) asm volatile("" ::"v"(ra[u][a]));
 #pragma unroll
         for (int b = 0; b < TB; ++b) asm volatile("" ::"v"(rb[u][b]));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The weight-gradient product with the AdamW update of that weight in the SAME kernel (reference main.py:350-351:
+// loss.backward(); optimizer.step()), single GPU: G = A^T B never reaches memory, W / exp_avg / exp_avg_sq are read and written
+// once -- 24 B per parameter instead of 32 + the separate pass.
+//
+// Round 3 ran the update as the tile's epilogue.  Measured in round 4 (tools/fused_probe.py): the optimiser stream of the
+// launch (826 MB at the Yelp shape) then runs at the full HBM rate -- and the matrix pipe stands still meanwhile: fused time =
+// matrix time + stream time for every reduction length (0.089 + 0.129 ms at K = 128, 0.215 + 0.110 ms at K = 400), i.e. no
+// overlap at all, with one memory round trip per row group or with several in flight alike.  All waves reach their
+// epilogues in phase (same tile length everywhere), the burst saturates HBM, and the waves that should multiply meanwhile wait
+// for operands behind it (vmcnt retires in order; the per-CU memory pipeline queues their L2 hits behind the misses).
+//
+// Here the stream of tile i runs INSIDE the k loop of tile i + 1 of the same wave, at a fixed pace: the finished tile is parked
+// in LDS (16 KB per wave, wave-private: no barrier), and every ring round (R k-steps) updates two of its sixteen row groups
+// (4 rows x 256 B of each of the three arrays): the three loads of a group are issued between the MFMAs of one k-step and
+// consumed four steps later -- gradient from LDS, update, three stores.  The traffic is spread evenly over the matrix time of
+// every wave (3.8 TB/s for the Yelp weights, 60 % of what HBM sustains), no bursts, whatever the phases of the waves.
+//
+// Everything vector-memory in the loop is inline asm with hand-counted waits (as the operand ring): hipcc's own counted waits see
+// only its own instructions (guide 5.7).  vmcnt retires in order, so the extra instructions only shift the counts: the top-of-step
+// wait allows 2 (D - 1) ring loads + the 12 optimiser instructions of a round minus those of the step itself, and the stream's
+// instructions are issued ALWAYS -- parked outside the descriptor (loads return 0 without a fetch, stores are dropped) while no
+// tile is pending -- so that the counts are the same in every round; the ring fill issues the parked instructions a previous
+// round would have issued.  build.py:lint_vmcnt verifies every count and that nothing touches a register in flight.
+// Tiles whose lanes do not all own a full 16-byte group (the last column panel when N % 64 != 0, or with the bias column) are
+// updated on the spot from the accumulators, as in round 3 (1/16 of the Yelp output-layer tiles, 1/538 of the first layer's).
+// ---------------------------------------------------------------------------------------------------------------------
+#ifdef GD_NO_SNOP  // (probe builds only: the build's lint rejects the kernel without the guard)
+#define GD_SNOP ""
+#else
+#define GD_SNOP "s_nop 4\n\t"
+#endif
+#ifndef GD_ADAMW_ST
+#define GD_ADAMW_ST 1  // cache policy of the optimiser stream's stores: 1 = nt (0 default, 2 sc1, 3 sc0 sc1: probe builds)
+#endif
+__device__ __forceinline__ void dr_store(f32x4 v, i32x4 srd, uint32_t voff) {
+    // (trailing s_nop: a store of more than 64 bits reads its data registers after issue; hipcc cannot see that this is a store.
+    // Leading s_nop 4: with ~100 live scalars hipcc keeps descriptors in VGPR lanes and restores them with v_readlane right in
+    // front of the statement; an SGPR written by a VALU instruction must not be read by a vector-memory one for 5 wait states)
+#if GD_ADAMW_ST == 1
+    asm volatile(GD_SNOP "buffer_store_dwordx4 %0, %1, %2, 0 offen nt\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(srd) : "memory");
+#elif GD_ADAMW_ST == 2
+    asm volatile(GD_SNOP "buffer_store_dwordx4 %0, %1, %2, 0 offen sc1\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(srd) : "memory");
+#elif GD_ADAMW_ST == 3
+    asm volatile(GD_SNOP "buffer_store_dwordx4 %0, %1, %2, 0 offen sc0 sc1\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(srd) : "memory");
+#else
+    asm volatile(GD_SNOP "buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(srd) : "memory");
+#endif
+}
+// (read-write operand: the destination stays ONE virtual register for the whole kernel, so hipcc has no new value to place at
+// every load and no PHI copies to insert at loop back edges -- copies that would move a register whose load is in flight)
+#ifndef GD_ADAMW_LD
+#define GD_ADAMW_LD 0  // probe builds: cache policy of the optimiser stream's loads (0 default, 1 nt)
+#endif
+__device__ __forceinline__ void dr_load0_rw(f32x4& v, i32x4 srd, uint32_t voff) {
+#if GD_ADAMW_LD == 1
+    asm volatile(GD_SNOP "buffer_load_dwordx4 %0, %1, %2, 0 offen nt" : "+v"(v) : "v"(voff), "s"(srd) : "memory");
+#elif GD_ADAMW_LD == 2
+    asm volatile(GD_SNOP "buffer_load_dwordx4 %0, %1, %2, 0 offen sc1" : "+v"(v) : "v"(voff), "s"(srd) : "memory");
+#elif GD_ADAMW_LD == 3
+    asm volatile(GD_SNOP "buffer_load_dwordx4 %0, %1, %2, 0 offen sc0 sc1" : "+v"(v) : "v"(voff), "s"(srd) : "memory");
+#elif GD_ADAMW_LD == 4
+    asm volatile(GD_SNOP "buffer_load_dwordx4 %0, %1, %2, 0 offen sc0 sc1 nt" : "+v"(v) : "v"(voff), "s"(srd) : "memory");
+#else
+    asm volatile(GD_SNOP "buffer_load_dwordx4 %0, %1, %2, 0 offen" : "+v"(v) : "v"(voff), "s"(srd) : "memory");
+#endif
+}
+
+template <int D>
+__global__ __launch_bounds__(512, 2) void dr_tn_adamw_kernel(const DrArgs d) {
+    constexpr int LPS = 2;  // ring loads per k-step
+    constexpr int R = D + 1;
+    // the optimiser stream's schedule inside a ring round: slot A is consumed AND reloaded in step UA, slot B in step UB -- a row
+    // group's loads have a whole round (R k-steps, ~4 us with two waves per SIMD) to land
+    constexpr int UA = 1, UB = 1 + R / 2;
+    constexpr int XS = 6;   // optimiser instructions of such a step: 3 stores + 3 loads
+    constexpr int XR = 12;  // ... of a round
+    static_assert(UB < R && UB > UA, "two distinct steps of a round");
+    static_assert(LPS * R + XS <= 63, "vmcnt is a 6-bit counter");
+    constexpr uint32_t PARK = 0xFFFFFF00u;  // outside every descriptor
+    const GdGemm& g = d.g;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    extern __shared__ __attribute__((aligned(16))) float dr_lds[];
+    f32x4* const stash = reinterpret_cast<f32x4*>(dr_lds + wave * 4096) + lane;  // [16 accumulators][64 lanes] x 16 B
+    // this step's AdamW scalars: by value, or -- a step replayed from a hipGraph -- from the device's step state
+    GdAdamHyper hy = g.adam;
+    if (d.adam_dev) hy = *d.adam_dev;
+    // ---- tiles and tickets: as dr_tn_kernel ----
+    const int n_waves = gridDim.x * 8;
+    const int minor = d.m_fastest ? d.tiles_m : d.tiles_n;
+    const int panels = d.m_fastest ? d.tiles_n : d.tiles_m;
+    int xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    int qx = xcc & 7, visited = 0;
+    // (panels dealt round-robin over the queues.  Contiguous blocks of panels per queue -- neighbouring panels on one XCD, close in
+    // time, for the 128-byte lines two neighbouring tiles share -- measured slower: 0.314 / 0.327 against 0.293 / 0.318 ms.)
+    auto q_tiles = [&](int x) { return ((panels - x + 7) >> 3) * minor; };
+    auto tile_of = [&](int x, int t) { return ((t / minor) * 8 + x) * minor + t % minor; };
+    auto draw_blocking = [&]() {
+        for (;;) {
+            if (visited == 8) return -1;
+            unsigned int* c = &g_dr_ticket[d.ctr][qx][0];
+            unsigned int tk = dr_ticket_issue(c);
+            dr_wait<0>();
+            asm volatile("" : "+v"(tk));
+            const int t = __builtin_amdgcn_readfirstlane(tk);
+            const int n = q_tiles(qx);
+            if (t == n + n_waves - 1 && lane == 0) __hip_atomic_store(c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t < n) return tile_of(qx, t);
+            qx = (qx + 1) & 7;
+            ++visited;
+        }
+    };
+    if (d.stagger > 0 && __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256)
+        for (int i = 0; i < d.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    int cur = draw_blocking();
+    if (cur < 0) return;
+    const int ntiles = d.tiles_m * d.tiles_n;
+    const int KSP = d.ksp;
+    const i32x4 srdA = dr_srd(g.A, (uint32_t)(((int64_t)(g.K - 1) * g.lda + g.M) * 4));
+    const i32x4 srdB = dr_srd(g.B, (uint32_t)(((int64_t)(g.K - 1) * g.ldb + g.N) * 4));
+    const uint32_t sa = 16u * (uint32_t)g.lda, sb = 16u * (uint32_t)g.ldb;
+    const int n_lim = g.out2 ? g.N - 1 : g.N;  // columns of C (a bias column, the last one of the product, goes to out2)
+    const uint32_t c_bytes = (uint32_t)(((int64_t)(g.M - 1) * g.ldc + n_lim) * 4);
+    const i32x4 srdW = dr_srd(g.C, c_bytes), srdM = dr_srd(g.aux, c_bytes), srdV = dr_srd(g.aux2, c_bytes);
+    const uint32_t ldc4 = (uint32_t)g.ldc * 4u;
+
+    uint32_t offA, offB, ka = 0, kb = 0;
+    int l_left = KSP;
+    auto set_cursor = [&](int tile) {
+        const bool ok = tile < ntiles;
+        const int tm = d.m_fastest ? (tile % d.tiles_m) : (tile / d.tiles_n);
+        const int tn = d.m_fastest ? (tile / d.tiles_m) : (tile % d.tiles_n);
+        offA = ok ? (uint32_t)(q * g.lda + tm * 64 + 4 * r) * 4u : 0xFFFFFFF0u;
+        offB = ok ? (uint32_t)(q * g.ldb + tn * 64 + 4 * r) * 4u : 0xFFFFFFF0u;
+        ka = kb = 0;
+        l_left = KSP;
+    };
+    set_cursor(cur);
+    // ---- optimiser stream state: the tile parked in LDS, its next row group, the two row groups in flight ----
+    uint32_t pend_base = PARK;  // per-lane byte offset of row group 0 of the pending tile inside W / exp_avg / exp_avg_sq
+    bool pend_lane = false;     // this lane owns a full 16-byte group in the pending tile (else its stream accesses stay parked)
+    int pend_g = 16;            // next row group of the pending tile to issue (16: none left)
+    struct Slot {
+        f32x4 p, m, v;  // W, exp_avg, exp_avg_sq of the row group in flight
+        uint32_t off;   // its per-lane byte offset (PARK: none -- loads return 0 without a fetch, stores are dropped)
+        int gi;         // its index: gradient = element gi >> 2 of the parked accumulators 4 (gi & 3) + f
+        bool live;      // holds a row group (wave-uniform)
+    } sl[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        asm volatile("" : "=v"(sl[k].p));
+        asm volatile("" : "=v"(sl[k].m));
+        asm volatile("" : "=v"(sl[k].v));
+        sl[k].off = PARK;
+        sl[k].gi = 0;
+        sl[k].live = false;
+    }
+    auto opt_pick = [&](Slot& s_) {  // next row group of the pending tile; parked when there is none
+        const bool act = pend_g < 16;
+        s_.live = act;
+        s_.gi = act ? pend_g : 0;
+        s_.off = (act && pend_lane && !(GD_ADAMW_DBG & 2)) ? pend_base + (uint32_t)pend_g * ldc4 : PARK;
+        pend_g += act ? 1 : 0;
+    };
+    auto opt_update_store = [&](Slot& s_) {  // s_.p / m / v have landed
+        const float* sg = reinterpret_cast<const float*>(stash + 256 * (s_.gi & 3)) + (s_.gi >> 2);
+        float gr[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) gr[f] = sg[256 * f];  // accumulator 4 e + f, element t: 64 lanes x 16 B apart
+        f32x4 pn = s_.p, mn = s_.m, vn = s_.v;  // (the slot's registers themselves are only ever written by its loads)
+#if !(GD_ADAMW_DBG & 1)  // (probe builds, tools/build_variant.sh: bit 0 = no arithmetic, bit 1 = every stream access parked)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float pk = pn[k], mk = mn[k], vk = vn[k];
+            gd_adam_elem(pk, gr[k], mk, vk, hy);
+            pn[k] = pk;
+            mn[k] = mk;
+            vn[k] = vk;
+        }
+#else
+        pn[0] += gr[0] + gr[1] + gr[2] + gr[3];
+#endif
+        // (probe bit 3: stores parked; bit 4: stores go to lines the stream has NOT just loaded -- 448 rows further down)
+        const uint32_t so = (GD_ADAMW_DBG & 8) ? PARK : ((GD_ADAMW_DBG & 16) && s_.off != PARK) ? s_.off + 448u * ldc4 : s_.off;
+        dr_store(pn, srdW, so);
+        dr_store(mn, srdM, so);
+        dr_store(vn, srdV, so);
+    };
+    auto opt_load = [&](Slot& s_) {
+        const uint32_t lo = (GD_ADAMW_DBG & 4) ? PARK : s_.off;  // (probe bit 2: loads parked)
+        dr_load0_rw(s_.p, srdW, lo);
+        dr_load0_rw(s_.m, srdM, lo);
+        dr_load0_rw(s_.v, srdV, lo);
+    };
+    auto opt_pin = [&](Slot& s_) {
+        asm volatile("" : "+v"(s_.p));
+        asm volatile("" : "+v"(s_.m));
+        asm volatile("" : "+v"(s_.v));
+    };
+
+    f32x4 ra[R], rb[R];
+    // ring fill, with the parked optimiser instructions a previous round would have issued in step u + 1 (see the header)
+#pragma unroll
+    for (int u = 0; u < D; ++u) {
+        ra[u] = dr_load(srdA, offA, ka);
+        rb[u] = dr_load(srdB, offB, kb);
+        ka += sa;
+        kb += sb;
+        --l_left;
+        const int w = (u + 1) % R;
+        if (w == UA || w == UB) {
+            // (parked STORES stand in for the loads too: a parked load would still write its destination when it lands, and
+            // nothing keeps hipcc from using those registers meanwhile)
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < XS / 3; ++k) {
+                dr_store(z, srdW, PARK);
+                dr_store(z, srdM, PARK);
+                dr_store(z, srdV, PARK);
+            }
+        }
+    }
+    const int q1 = (KSP / R / 4) * R, q2 = (KSP / R / 2) * R, q3 = (KSP / R * 3 / 4) * R;
+    const bool defer_all = KSP / R >= 9;  // ring rounds per tile: two row groups each, issued in rounds 0..7, consumed by round 8
+    for (;;) {
+        unsigned int* tctr = &g_dr_ticket[d.ctr][qx][0];
+        unsigned int tick = visited < 8 ? dr_ticket_issue(tctr) : 0u;
+        const bool drew = visited < 8;
+        int nxt = 0;
+        const int tm = d.m_fastest ? (cur % d.tiles_m) : (cur / d.tiles_n);
+        const int tn = d.m_fastest ? (cur / d.tiles_m) : (cur % d.tiles_n);
+        const int m0 = tm * 64, n0 = tn * 64;
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int f = 0; f < 4; ++f) acc[e][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_s_setprio(0);
+        for (int s0 = 0; s0 < KSP; s0 += R) {
+            if (s0 == q1) __builtin_amdgcn_s_setprio(1);
+            else if (s0 == q2) __builtin_amdgcn_s_setprio(2);
+            else if (s0 == q3) __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+            for (int u = 0; u < R; ++u) {
+                const int v = (u + D) % R;
+                // step s has landed; steps s+1 .. s+D-1 and the optimiser instructions of every other step of a round stay in flight
+                if (u == UA || u == UB) dr_wait<LPS*(D - 1) + XR - XS>();
+                else dr_wait<LPS*(D - 1) + XR>();
+                asm volatile("" : "+v"(ra[u]));
+                asm volatile("" : "+v"(rb[u]));
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int e = i / 4, f = i % 4;
+                    acc[e][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[u][e], rb[u][f], acc[e][f], 0, 0, 0);
+                    if (i == 1) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        ra[v] = dr_load(srdA, offA, ka);
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else if (i == 5) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        rb[v] = dr_load(srdB, offB, kb);
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else if (i == 9) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        ka += sa;
+                        kb += sb;
+                        if (--l_left == 0) {  // once per tile: the cursor moves on to the next tile
+                            nxt = -1;
+                            if (drew) {
+                                if (KSP < 2 * D + 2) dr_wait<0>();
+                                asm volatile("" : "+v"(tick));
+                                const int tk = __builtin_amdgcn_readfirstlane(tick);
+                                const int nq = q_tiles(qx);
+                                if (tk == nq + n_waves - 1 && lane == 0) __hip_atomic_store(tctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (tk < nq) {
+                                    nxt = tile_of(qx, tk);
+                                } else {
+                                    qx = (qx + 1) & 7;
+                                    ++visited;
+                                    nxt = draw_blocking();
+                                }
+                            }
+                            if (nxt < 0) nxt = ntiles;
+                            set_cursor(nxt);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else if ((u == UA || u == UB) && i == 11) {
+                        // ---- the optimiser stream's turn: the slot's row group (loaded one round ago) is updated and stored, and
+                        // the slot reloaded with the next row group of the parked tile ----
+                        __builtin_amdgcn_sched_barrier(0);
+                        Slot& s_ = sl[u == UA ? 0 : 1];
+                        // its loads are older than the ring loads of the R steps since (2 each) and the other slot's turn
+                        dr_wait<LPS * R + XS>();
+                        opt_pin(s_);
+                        opt_update_store(s_);
+                        opt_pick(s_);
+                        opt_load(s_);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- end of tile ----
+        const uint32_t vo = (uint32_t)(16 * q * g.ldc + n0 + 4 * r) * 4u;
+        const int n = n0 + 4 * r;
+        const bool lane_full = n + 3 < n_lim;  // the lane owns a full 16-byte group of every row of the tile
+        if (defer_all) {
+            // A k loop of >= 9 ring rounds has issued and consumed all sixteen row groups of the PREVIOUS tile (the slots hold
+            // parked loads): park this one for the next k loop's stream.  Lanes without a full group (last column panel) stay
+            // parked in the stream; what they own is updated element-wise below.
+            // (The slots' registers are touched nowhere but in the k loop's turns: any other definition would make hipcc place
+            // copies of them -- of registers in flight -- at the loop's back edge.)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int f = 0; f < 4; ++f) stash[64 * (4 * e + f)] = acc[e][f];
+            pend_base = vo + (uint32_t)m0 * ldc4;
+            pend_lane = lane_full;
+            pend_g = 0;
+        } else if (lane_full) {
+            // a reduction too short for the stream (< 9 ring rounds): updated on the spot from the accumulators, as in round 3
+            // (one memory round trip per row group)
+            const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, (int)c_bytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.aux), 0, (int)c_bytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.aux2), 0, (int)c_bytes, 0x00020000);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t o = vo + (uint32_t)(m0 + 4 * t + e) * ldc4;
+                    f32x4 pv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, o, 0, 0));
+                    f32x4 mv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rM, o, 0, 0));
+                    f32x4 vv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rV, o, 0, 0));
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float pk = pv[k], mk = mv[k], vk = vv[k];
+                        gd_adam_elem(pk, acc[e][k][t], mk, vk, hy);
+                        pv[k] = pk;
+                        mv[k] = mk;
+                        vv[k] = vk;
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pv), rW, o, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, mv), rM, o, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vv), rV, o, 0, 0);
+                }
+        }
+        if (!lane_full && n < g.N) {
+            // last column panel: the lane's group straddles the end of the row (N % 4 != 0) or holds the bias column -- element-wise
+            // from the accumulators, now (at most one lane per row)
+            float* __restrict__ Mo = const_cast<float*>(g.aux);
+            float* __restrict__ Vo = const_cast<float*>(g.aux2);
+            for (int t = 0; t < 4; ++t)
+                for (int e = 0; e < 4; ++e) {
+                    const int m = m0 + 16 * q + 4 * t + e;
+                    if (m >= g.M) continue;
+                    for (int k = 0; k < 4; ++k) {
+                        if (n + k >= g.N) continue;
+                        const int64_t o = (int64_t)m * g.ldc + n + k;
+                        const float gk = acc[e][k][t];
+                        if (g.out2 && n + k == g.N - 1) {  // the bias column (operand B's extra column): its own vector
+                            g.out2[m] = gk;
+                            continue;
+                        }
+                        float pk = g.C[o], mk = Mo[o], vk = Vo[o];
+                        gd_adam_elem(pk, gk, mk, vk, hy);
+                        g.C[o] = pk;
+                        Mo[o] = mk;
+                        Vo[o] = vk;
+                    }
+                }
+        }
+        if (nxt >= ntiles) break;
+        cur = nxt;
+    }
+    // the parked cursor's loads and the stream's last instructions are still in flight: their registers stay live until they landed
+    dr_wait<0>();
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+        asm volatile("" ::"v"(ra[u]));
+        asm volatile("" ::"v"(rb[u]));
+    }
+    // ---- the last tile's stream: nothing left to multiply.  What the last k loop left in the slots (landed), then the parked
+    // tile's row groups four at a time -- twelve loads in flight per wave (everything asm has drained: hipcc schedules this) ----
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        opt_pin(sl[k]);
+        opt_update_store(sl[k]);
+    }
+    dr_wait<0>();
+    {
+        const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, (int)c_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.aux), 0, (int)c_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.aux2), 0, (int)c_bytes, 0x00020000);
+        for (; pend_g < 16; pend_g += 4) {
+            f32x4 pv[4], mv[4], vv[4];
+            uint32_t oo[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                oo[u] = (pend_lane && !(GD_ADAMW_DBG & 2)) ? pend_base + (uint32_t)(pend_g + u) * ldc4 : PARK;
+                pv[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, oo[u], 0, 0));
+                mv[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rM, oo[u], 0, 0));
+                vv[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rV, oo[u], 0, 0));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int gi = pend_g + u;
+                const float* sg = reinterpret_cast<const float*>(stash + 256 * (gi & 3)) + (gi >> 2);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float pk = pv[u][k], mk = mv[u][k], vk = vv[u][k];
+                    gd_adam_elem(pk, sg[256 * k], mk, vk, hy);
+                    pv[u][k] = pk;
+                    mv[u][k] = mk;
+                    vv[u][k] = vk;
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pv[u]), rW, oo[u], 0, 2);  // (aux 2 = nt)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, mv[u]), rM, oo[u], 0, 2);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, vv[u]), rV, oo[u], 0, 2);
+            }
+        }
     }
 }
 
@@ -890,8 +1292,23 @@ void dr_nt_go(const DrArgs& d, int n_cu, hipStream_t s) {
 
 int dr_cu_count_fwd();
 template <int D, int EPI>
-void dr_tn_go(const DrArgs& d, hipStream_t s) {
-    hipLaunchKernelGGL((dr_tn_kernel<1, 1, D, EPI>), dim3(dr_cu_count_fwd()), dim3(512), 0, s, d);
+int dr_tn_go(const DrArgs& d, hipStream_t s) {
+    if constexpr (EPI == GD_EPI_ADAMW) {
+        static bool attr_set = false;  // 8 waves x 16 KB: the tile whose optimiser stream is running
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dr_tn_adamw_kernel<D>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            if (e != hipSuccess) {
+                gdmcf_set_error("hipFuncSetAttribute(dr_tn_adamw_kernel, LDS=128 KB): %s", hipGetErrorString(e));
+                return GDMCF_E_HIP;
+            }
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((dr_tn_adamw_kernel<D>), dim3(dr_cu_count_fwd()), dim3(512), 128 * 1024, s, d);
+    } else {
+        hipLaunchKernelGGL((dr_tn_kernel<1, 1, D, EPI>), dim3(dr_cu_count_fwd()), dim3(512), 0, s, d);
+    }
+    return GDMCF_OK;
 }
 
 }  // namespace
@@ -976,13 +1393,14 @@ int gd_gemm_dr_launch(int layA, int layB, int epi, GdGemm& g, hipStream_t s) {
         g.tiles_n = d.tiles_n;
         d.g = g;
         d.ctr = dr_ticket_slot(s);
+        d.adam_dev = (epi == GD_EPI_ADAMW && t_gd_step_state) ? &t_gd_step_state->hyper : nullptr;  // a bound graph step state
         d.g.out2 = bias_db;
         {
             GdProfScope prof(g.prof_tag, 2.0 * g.M * n_user * g.K, s);
 #define GD_DR_GO(DD)                                                      \
     do {                                                                  \
-        if (epi == GD_EPI_STORE) dr_tn_go<DD, GD_EPI_STORE>(d, s);        \
-        else dr_tn_go<DD, GD_EPI_ADAMW>(d, s);                            \
+        int rc_ = (epi == GD_EPI_STORE) ? dr_tn_go<DD, GD_EPI_STORE>(d, s) : dr_tn_go<DD, GD_EPI_ADAMW>(d, s); \
+        if (rc_ != GDMCF_OK) return rc_;                                  \
     } while (0)
             if (best == 9) GD_DR_GO(9);
             else if (best == 8) GD_DR_GO(8);

@@ -1292,6 +1292,7 @@ GdAdamHyper gd_adam_hyper(float lr, float beta1, float beta2, float eps, float w
     h.beta2 = beta2;
     h.one_m_b2 = (float)(1.0 - b2);
     h.bc2_sqrt = (float)sqrt(bc2);
+    h.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
     h.eps = eps;
     h.neg_step = (float)(-(lr_d / bc1));
     h.grad_scale = grad_scale;

@@ -138,6 +138,12 @@ class GraphedTrainStep:
                     # capture mode such a query from ANOTHER thread is an error that kills the process; thread-local mode
                     # only polices the capturing thread.  Nothing of the eager steps may still be in flight either way.
                     torch.cuda.synchronize()
+                    if self.step.exchange:
+                        # ... and the watchdog (it wakes every 100 ms) must have seen them complete and dropped them from its
+                        # list: a poll of one of those events that lands inside the capture aborted the process in about one
+                        # run in twenty (round 4, tests/test_gpu_dp.py under load) although the mode is thread-local
+                        import time
+                        time.sleep(0.35)
                     with torch.cuda.graph(g, capture_error_mode="thread_local" if self.step.exchange else "global"):
                         self.loss = self._body()
                     self.graph = g
