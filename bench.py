@@ -45,11 +45,8 @@ TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")
 
 
 def measured_traffic(kernel_tag, workload, gemm_dtype="f32"):
-    """HBM bytes per launch of the kernel behind `kernel_tag`, from the committed rocprofv3 PMC passes of this same
-    command (FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950 note): profiles/summarize.py
-    writes one row per bench tag (kernel names are mapped to tags there, by layout / epilogue template arguments, not by
-    tile sizes).  PMC counters cannot be collected from inside the process, so this is a lookup -- and it says so loudly
-    when the profile has no row for the kernel instead of silently reporting null.  Returns (bytes or None, note)."""
+    """FALLBACK only (live_traffic below is the measurement): HBM bytes per launch of the kernel behind `kernel_tag` from the
+    committed rocprofv3 PMC passes (profiles/summarize.py writes one row per bench tag).  Returns (bytes or None, note)."""
     if not os.path.exists(TRAFFIC_FILE):
         return None, f"no {os.path.relpath(TRAFFIC_FILE, ROOT)}"
     prof = json.load(open(TRAFFIC_FILE))
@@ -60,7 +57,61 @@ def measured_traffic(kernel_tag, workload, gemm_dtype="f32"):
         msg = f"{os.path.relpath(TRAFFIC_FILE, ROOT)} has no row for tag '{kernel_tag}' (re-run tools/profile_round.sh)"
         print(f"[bench] WARNING: roofline.traffic unavailable: {msg}", file=sys.stderr)
         return None, msg
-    return int(row["hbm_total_MB"] * 1e6), f"{row['kernel']} ({row['launches']} launches profiled)"
+    return int(row["hbm_total_MB"] * 1e6), f"{row['kernel']} ({row['launches']} launches profiled; committed profile, not this run)"
+
+
+def live_traffic(kernel_tag, argv):
+    """HBM bytes per launch of the kernel behind `kernel_tag`, MEASURED in this run: PMC counters cannot be read from inside
+    the process, so two short CHILD runs of this same command (4 steps, no extra legs) are started under
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` (separate passes: the counters do not fit one; FETCH_SIZE doubled per
+    the gfx950 note of MI355X_MICROARCH.md, both in KiB) and their per-kernel averages are mapped to bench tags by
+    profiles/summarize.py.  A child is a new process started with Popen (never an exec from this GPU-initialised one).
+    Returns (bytes or None, note)."""
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        return None, "rocprofv3 not found"
+    sys.path.insert(0, os.path.join(ROOT, "profiles"))
+    import summarize
+    keep = []
+    skip_next = False
+    for a in argv:  # the parent's variant flags (workload, dtype, optimiser placement ...) minus what the child fixes
+        if skip_next:
+            skip_next = False
+            continue
+        if a in ("--steps", "--warmup", "--preheat-seconds", "--cpu-seconds", "--gpus"):
+            skip_next = True
+            continue
+        keep.append(a)
+    child = [sys.executable, os.path.abspath(__file__)] + keep + [
+        "--steps", "4", "--warmup", "2", "--preheat-seconds", "0", "--no-cpu-baseline", "--no-prof", "--no-fused-leg",
+        "--no-graph-leg", "--no-configs2-leg", "--no-spmm", "--no-sampling", "--no-live-traffic"]
+    tmp = tempfile.mkdtemp(prefix="gdmcf_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+    env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
+    csvs = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            r = subprocess.run([rp, "--pmc", ctr, "--kernel-trace", "-d", out, "-o", "p", "--output-format", "csv", "--"] + child,
+                               cwd=tmp, env=env, capture_output=True, text=True, timeout=240)
+            found = [os.path.join(dp, f) for dp, _, fs in os.walk(out) for f in fs if f.endswith("counter_collection.csv")]
+            if r.returncode != 0 or not found:
+                return None, f"rocprofv3 --pmc {ctr} child failed (rc {r.returncode}): {(r.stderr or '')[-160:]}"
+            csvs[ctr] = found[0]
+        rows = summarize.traffic(csvs["FETCH_SIZE"], csvs["WRITE_SIZE"])
+        tags = summarize.by_tag(rows, "", "")["tags"]
+        row = tags.get(kernel_tag)
+        if row is None:
+            return None, f"no kernel of tag '{kernel_tag}' in the PMC passes"
+        return int(row["hbm_total_MB"] * 1e6), (f"measured in this run: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) / WRITE_SIZE child "
+                                                f"passes of this command, {row['kernel']}, {row['launches']} launches: read "
+                                                f"{row['hbm_read_MB']} MB + written {row['hbm_write_MB']} MB per launch")
+    except Exception as exc:  # never fatal for the line
+        return None, f"live traffic failed: {type(exc).__name__}: {exc}"[:200]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def parse():
@@ -85,6 +136,8 @@ def parse():
     ap.add_argument("--preheat-seconds", type=float, default=1.0,
                     help="untimed: run dense products on scratch buffers for this long before the warm-up steps so that the timed "
                          "region does not start on a cold clock (0 = off; reported as clock_preheat)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure roofline.traffic with two rocprofv3 --pmc child passes of this command (N = 1 only; ~40 s)")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--prof-every", type=int, default=4,
                     help="bracket the tagged launches of every Nth timed step with HIP events (an event pair keeps the next "
@@ -395,11 +448,11 @@ def main():
         model = gdmcf_amd.DNN([I, hid], [hid, I], 10, time_type="cat", norm=False, gemm_dtype=args.gemm_dtype).to(dev)
         diffusion = gdmcf_amd.GaussianDiffusion(gdmcf_amd.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, T, dev)
     opt = gdmcf_amd.FusedAdamW(model.parameters(), lr=1e-5, weight_decay=0.0)
+    model.train()
+    torch.manual_seed(1234 + rank)  # (before anything creates the model's engine: its Philox seed is torch.initial_seed() then)
     fuse_main = bool(args.fuse_main and world == 1)
     if fuse_main:
         opt.fuse_into_backward(model)
-    model.train()
-    torch.manual_seed(1234 + rank)
     # N > 1: the same bytes cross xGMI either way (reduce-scatter + all-gather == all-reduce), but the sharded
     # optimiser touches 1/N of the AdamW state per GPU and its all-gathers overlap the next step's first GEMMs
     sharded = (args.shard_optimizer or world > 1) and not args.allreduce_optimizer
@@ -438,8 +491,11 @@ def main():
                             "no training step, no model / optimiser / RNG state touched")
         del pa, pw, pc, pws
     loss = None
+    trace = os.environ.get("GDMCF_BENCH_TRACE") == "1"  # debugging: the loss of every step on stderr (synchronises each step)
     for i in range(args.warmup):
         loss = step(rows_of(i % n_pool), True, **step_kw[i % n_pool])
+        if trace:
+            print(f"[trace] warm-up step {i}: loss {float(loss)!r}", file=sys.stderr)
     sync()
     dp_autotune = None
     if autotune and step.exchange:
@@ -480,6 +536,8 @@ def main():
         if prof:
             lib.gdmcf_prof_enable(1 if i % every == 0 else 2)  # 2 = pause, records kept
         loss = step(rows_of(i % n_pool), True, **step_kw[i % n_pool])
+        if trace:
+            print(f"[trace] step {i}: loss {float(loss)!r}", file=sys.stderr)
     host_el = time.perf_counter() - t0  # enqueue time only: well below `el` when the host runs ahead of the GPU
     sync()
     el = time.perf_counter() - t0
@@ -649,12 +707,17 @@ def main():
                                               what="24 B per parameter of the updated weight, inside the same launch")
     if klist:
         k0 = klist[0]
-        traffic, traffic_note = measured_traffic(k0["kernel"].split(" + ")[0], args.workload, args.gemm_dtype)
+        tag0 = k0["kernel"].split(" + ")[0]
+        traffic, traffic_note = (None, "off (--no-live-traffic)")
+        if world == 1 and rank == 0 and not args.no_live_traffic and not args.rehearse_dp:
+            traffic, traffic_note = live_traffic(tag0, sys.argv[1:])
+        if traffic is None:
+            t2, n2 = measured_traffic(tag0, args.workload, args.gemm_dtype)
+            traffic, traffic_note = t2, f"{traffic_note}; fallback: {n2}"
         roofline = dict(bound=k0["bound"], achieved=k0["achieved"], peak=k0["peak"], unit=k0["unit"], frac=k0["frac"],
                         traffic=traffic, traffic_source=traffic_note, kernel=k0["kernel"], avg_ms=k0["avg_ms"],
                         launches_per_step=k0["launches"] // max(n_profiled, 1), profiled_steps=n_profiled,
-                        traffic_unit="HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE passes of this "
-                                     "command (profiles/r03_hbm_traffic.json)",
+                        traffic_unit="HBM bytes per launch: rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) + WRITE_SIZE, separate passes",
                         algorithmic_unit=("2*M*N*K FLOP per launch" if k0["bound"] == "mfma" else
                                           "compulsory bytes per launch (operands and results once; AdamW 28 B/param)"))
         if "optimizer_stream" in k0:

@@ -320,8 +320,8 @@ def test_bench_data_parallel_path_in_a_one_rank_rccl_group():
     for extra in (["--rehearse-dp", "--shard-optimizer"], ["--rehearse-dp", "--allreduce-optimizer"], [],
                   ["--rehearse-dp", "--autotune-dp"]):
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "2",
-                            "--no-cpu-baseline"] + extra, capture_output=True, text=True, cwd=root, timeout=600,
-                           env=dict(os.environ, MASTER_PORT="29571"))
+                            "--no-cpu-baseline", "--no-live-traffic", "--separate-optimizer"] + extra, capture_output=True,
+                           text=True, cwd=root, timeout=600, env=dict(os.environ, MASTER_PORT="29571"))
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1]))
     sh, ar, plain, auto = outs
