@@ -22,6 +22,7 @@ TABLE_NAMES = (
 P = c_void_p
 _SIGNATURES = {
     "gdmcf_version": (c_int, []),
+    "gdmcf_debug_last_gemm": (c_int, []),
     "gdmcf_last_error": (c_char_p, []),
     "gdmcf_device_info": (c_int, [P, P, c_char_p, c_int]),
     "gdmcf_prof_enable": (c_int, [c_int]),

@@ -66,6 +66,8 @@ bool gd_shadow_lookup(const void* f32, GdShadow* out) {
     return true;
 }
 
+thread_local int t_gd_last_gemm = 0;
+
 extern "C" {
 
 int gdmcf_bf16_shadow_set(const float* f32, void* bf16, int64_t rows, int64_t cols, int64_t ld_bf16) {
@@ -135,6 +137,8 @@ int gdmcf_prof_collect(int cap, int* tags, float* ms, double* work) {
 }
 
 int gdmcf_version(void) { return 1; }
+
+int gdmcf_debug_last_gemm(void) { return t_gd_last_gemm; }
 
 const char* gdmcf_last_error(void) { return g_err; }
 

@@ -165,6 +165,8 @@ struct GdGemm {
                // 2: operands split into three bfloat16 terms, six bf16 MFMAs per product block (gemm_split.hip)
 };
 
+extern thread_local int t_gd_last_gemm;  // gdmcf_debug_last_gemm (include/gdmcf_hip.h)
+
 // shape classes: 0 = "batch-M" (BM=80, BN=128), 1 = square 128x128, 2 = small 64x64,
 //                3 = bf16 only: 208x256 on 8 waves (batch-sized M, see gemm_bf16.hip)
 int gd_gemm_launch(int layA, int layB, int epi, int shape_class, GdGemm& g, hipStream_t s);

@@ -1277,6 +1277,255 @@ __global__ __launch_bounds__(512, 2) void dr_hl_kernel(const DrArgs d) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// C[M,N] = A[M,K] * B[N,K]^T for a batch-sized A and a LARGE B with a fused row-loss / posterior epilogue (the output layer:
+// reference models/DNN.py:83-86 with gaussian_diffusion.py:335 in training, :451-498 in the reverse loop), round 4:
+// ONE FAT TILE PER WAVE, ONE WAVE PER SIMD, ONE PASS.
+//
+// What rounds 2-3 established about this product: the LDS-tiled kernel and the hybrid kernel both end at 0.6 of
+// the matrix rate because (i) 1 345 / 2 690 tiles on 512 / 1 024 slots are 2.63 rounds -- a third of the chip runs three -- and
+// (ii) the loop is bound by instruction ISSUE: v_mfma_f32_16x16x4_f32 shares the vector issue port, so every load, LDS access
+// and barrier beside the MFMAs is matrix time lost (round 4: even another wave's arithmetic does not overlap).  Both have one
+// cure: MORE OUTPUT PER WAVE.  A wave alone on its SIMD may use all 512 registers: 5 x NB accumulator blocks of 16 x 16 (NB =
+// 11: 220 registers) hold an 80 x 176 tile, so the WHOLE [400 x 34 395] output is 980 tiles -- one per wave, 96 % of the 1 024
+// SIMDs busy for the whole launch, no second round, no tail -- and per 16-deep k chunk the wave issues 220 MFMAs beside 16 loads,
+// 11 LDS writes and 11 LDS reads (0.17 other instructions per MFMA; the LDS-tiled kernel: 0.35, plus a barrier per 80).
+//   * A (the hidden activations, L2-resident) is loaded straight into the MFMA layout: lane (j = lane & 15, q = lane >> 4) reads
+//     A[m0 + 16 i + j][k0 + 4 q .. + 3] -- one 16-byte load per row block and chunk; component s is the operand of the MFMA that
+//     takes k = k0 + 4 q + s (A and B permuted alike).  1.6 MB read by every wave: half lines are no concern here (they were for
+//     the STREAMED operand of dr_nt_kernel).
+//   * B (the weight, streamed from HBM once per row tile: the five row tiles of a column panel run on one XCD) is fetched in
+//     pieces of 16 rows x 64 B, staged in registers for two k steps, written to a wave-PRIVATE LDS image (rows of 16 floats,
+//     16-byte slot s of row r at s ^ 2 ((r >> 2) & 1): conflict-free for the ds_read_b128 lane groups) and read back as
+//     fragments -- ordered by the wave's own LDS queue, no barrier.
+//   * No instruction of the loop is inline asm: every load of a chunk is waited for inside the chunk that issued it (nothing is
+//     in flight across the loop's back edge), so hipcc's own counted waits are exact; sched_barriers pin the placement.
+// acc[i][b][t] = C[m0 + 16 i + 4 q + t][n0 + 16 b + r].  Deterministic: fixed k order, one wave per tile, static assignment.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NB, int EPI>
+__global__ __launch_bounds__(256, 1) void dr_fat_kernel(const DrArgs d) {
+    static_assert(EPI == GD_EPI_LOSS || EPI == GD_EPI_POST, "output layer with a fused epilogue");
+    static_assert(NB >= 4 && NB <= 12, "5 x NB accumulator blocks must fit 256 registers");
+    constexpr int TMB = 5;
+    const GdGemm& g = d.g;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    extern __shared__ __attribute__((aligned(16))) float dr_lds[];
+    float* const lds = dr_lds + wave * (2 * NB * 256);  // two chunk images of 16 NB rows x 16 floats
+    // consecutive tiles (the row tiles of one column panel first) on consecutive waves of ONE XCD: blocks b and b + 8 share an XCD
+    const int nblk = gridDim.x, per = nblk >> 3;
+    const int wl = ((nblk & 7) == 0 ? ((int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3)) : (int)blockIdx.x) * 4 + wave;
+    const int n_waves = nblk * 4;
+    const int ntiles = d.tiles_m * d.tiles_n;
+    const __amdgpu_buffer_rsrc_t srdA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, (int)(((int64_t)(g.M - 1) * g.lda + g.K) * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t srdB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B), 0, (int)(((int64_t)(g.N - 1) * g.ldb + g.K) * 4), 0x00020000);
+    const int NCH = d.ksp;       // chunks of 16 k per tile (even: the loop runs them in pairs)
+    const int c_mask = g.K >> 4;  // first chunk that reaches past K
+    // LDS float offsets: write -- piece p = rows 16 p + (lane >> 2), slot lane & 3; read -- block b = rows 16 b + r, slot q
+    const int w_off = (lane >> 2) * 16 + (((lane & 3) ^ ((((lane >> 2) >> 2) & 1) << 1)) << 2);
+    const int r_off = r * 16 + ((q ^ (((r >> 2) & 1) << 1)) << 2);
+    for (int tile = wl; tile < ntiles; tile += n_waves) {
+        const int tm = tile % d.tiles_m, tn = tile / d.tiles_m;
+        const int m0 = tm * (16 * TMB), n0 = tn * (16 * NB);
+        uint32_t offA[TMB], offB[NB];
+#pragma unroll
+        for (int i = 0; i < TMB; ++i) offA[i] = (uint32_t)((m0 + 16 * i + r) * g.lda + 4 * q) * 4u;
+#pragma unroll
+        for (int p = 0; p < NB; ++p) offB[p] = (uint32_t)(((int64_t)(n0 + 16 * p + (lane >> 2)) * g.ldb + 4 * (lane & 3)) * 4);
+        f32x4 acc[TMB][NB];
+#pragma unroll
+        for (int i = 0; i < TMB; ++i)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) acc[i][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 xa[2][TMB], G[NB], FB[NB];
+        // ---- fill: chunk 0 of A into xa[0], chunk 0 of B through LDS image 0 ----
+#pragma unroll
+        for (int i = 0; i < TMB; ++i) xa[0][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdA, offA[i], 0, 0));
+#pragma unroll
+        for (int p = 0; p < NB; ++p) G[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdB, offB[p], 0, 0));
+#pragma unroll
+        for (int p = 0; p < NB; ++p) *reinterpret_cast<f32x4*>(lds + p * 256 + w_off) = G[p];
+
+        // one chunk: PAR = its parity (A registers xa[PAR], LDS image PAR); the loads of chunk c + 1 ride in k steps 0 and 1,
+        // its LDS writes in k step 3
+#define GD_FAT_CHUNK(PAR, c)                                                                                          \
+        {                                                                                                             \
+            /* scalar offset of the next chunk; past the last chunk it parks the loads outside both matrices (0, no fetch) */ \
+            const uint32_t kn = ((c) + 1 < NCH) ? (uint32_t)((c) + 1) * 64u : 0x80000000u;                            \
+            _Pragma("unroll") for (int b = 0; b < NB; ++b)                                                            \
+                FB[b] = *reinterpret_cast<const f32x4*>(lds + (PAR) * (NB * 256) + b * 256 + r_off);                  \
+            if ((c) >= c_mask) { /* the chunk(s) that reach past K: zero every k >= K of A (B's may hold anything finite) */ \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                       \
+                    const bool keep = (c) * 16 + 4 * q + e < g.K;                                                     \
+                    _Pragma("unroll") for (int i = 0; i < TMB; ++i) xa[PAR][i][e] = keep ? xa[PAR][i][e] : 0.f;       \
+                }                                                                                                     \
+            }                                                                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+            _Pragma("unroll") for (int sx = 0; sx < 4; ++sx) {                                                        \
+                _Pragma("unroll") for (int n = 0; n < TMB * NB; ++n) {                                                \
+                    const int i = n / NB, b = n % NB;                                                                 \
+                    if (sx == 0 && i == 0) asm volatile("" : "+v"(FB[b])); /* (operands stay in VGPRs: hipcc otherwise parks them in spare AGPRs) */ \
+                    if (sx == 0 && b == 0) asm volatile("" : "+v"(xa[PAR][i]));                                       \
+                    acc[i][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[PAR][i][sx], FB[b][sx], acc[i][b], 0, 0, 0);  \
+                    /* loads of the next chunk: A's five and the first pieces of B in k step 0, the rest in k step 1 */ \
+                    if (sx < 2 && n % 5 == 2) { /* k step 0 carries loads 0 .. NB - 1, k step 1 the remaining TMB */     \
+                        const int l = (sx == 0) ? n / 5 : NB + n / 5;                                                 \
+                        if (l < TMB + NB) {                                                                           \
+                            __builtin_amdgcn_sched_barrier(0);                                                        \
+                            if (l < TMB)                                                                              \
+                                xa[(PAR) ^ 1][l] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(   \
+                                    srdA, offA[l], kn, 0));                                                           \
+                            else                                                                                      \
+                                G[l - TMB] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(         \
+                                    srdB, offB[l - TMB], kn, 0));                                                     \
+                            __builtin_amdgcn_sched_barrier(0);                                                        \
+                        }                                                                                             \
+                    }                                                                                                 \
+                    if (sx == 3 && n % 4 == 1 && n / 4 < NB) { /* the pieces have landed: into the other LDS image */  \
+                        __builtin_amdgcn_sched_barrier(0);                                                            \
+                        *reinterpret_cast<f32x4*>(lds + ((PAR) ^ 1) * (NB * 256) + (n / 4) * 256 + w_off) = G[n / 4]; \
+                        __builtin_amdgcn_sched_barrier(0);                                                            \
+                    }                                                                                                 \
+                }                                                                                                     \
+                __builtin_amdgcn_sched_barrier(0);                                                                    \
+            }                                                                                                         \
+        }
+        for (int c = 0; c < NCH; c += 2) {
+            GD_FAT_CHUNK(0, c);
+            GD_FAT_CHUNK(1, c + 1);
+        }
+#undef GD_FAT_CHUNK
+
+        // ---- epilogue: the tile goes through the wave's LDS (the chunk images are dead) one block of 16 rows at a time and leaves
+        // in ROWS -- lane (r, q) owns four consecutive columns 4 (r + 16 j) of row 4 p + q: 16-byte accesses, 256 contiguous bytes
+        // per row and instruction, 12 stores per row block instead of 44 (and as many target / x_t loads) ----
+        constexpr int LDS_ = 16 * NB + 4;  // floats per staged row (+4: the four q groups of a ds_write_b32 hit different banks)
+        constexpr int NJ = (4 * NB + 15) / 16;
+        typedef f32x4 f32x4_e __attribute__((aligned(4)));
+        f32x4 bias4[NJ];
+        int col4[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            col4[j] = n0 + 4 * (r + 16 * j);
+            bias4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (g.bias && r + 16 * j < 4 * NB) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bias4[j][e] = g.bias[min(col4[j] + e, g.N - 1)];
+            }
+        }
+        const bool has_z = (EPI == GD_EPI_POST) && (g.aux2 != nullptr);
+        const bool has_r = (EPI == GD_EPI_POST) && (g.r2 != nullptr);
+#pragma unroll
+        for (int i = 0; i < TMB; ++i) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) lds[(4 * q + t) * LDS_ + 16 * b + r] = acc[i][b][t];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int p4 = 0; p4 < 4; ++p4) {
+                const int m = m0 + 16 * i + 4 * p4 + q;
+                const int mc = min(m, g.M - 1);
+                const bool mok = m < g.M;
+                float ss = 0.f;
+                float c1 = 1.f, c2 = 0.f, p1 = 0.f, p2 = 0.f, sg = 0.f;
+                if (EPI == GD_EPI_LOSS) {
+                    if (g.r0) c1 = g.r0[mc];
+                } else {
+                    c1 = g.r0[mc];
+                    c2 = g.r1[mc];
+                    if (has_r) { p1 = g.r2[mc]; p2 = g.r3[mc]; }
+                    if (has_z) sg = g.r4[mc];
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int c4 = r + 16 * j;
+                    const bool inb = c4 < 4 * NB;                      // inside the tile
+                    const int n = col4[j];
+                    const bool full = inb && n + 3 < g.N && mok;       // a whole 16-byte group inside the matrix
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(lds + (4 * p4 + q) * LDS_ + 4 * min(c4, 4 * NB - 1));
+                    f32x4 o, o2 = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (EPI == GD_EPI_LOSS) {
+                        // d = alpha * (acc + bias) - target, stored; per-row sum of d^2 (gaussian_diffusion.py:335)
+                        f32x4 tg;
+                        if (g.aux_bits) {  // {0,1} target rows as bitmaps: four bits of one word (n is a multiple of 4)
+                            const uint32_t w = g.aux_bits[(int64_t)mc * g.ldbits + min((int64_t)(n >> 5), g.ldbits - 1)] >> (n & 31);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) tg[e] = (float)((w >> e) & 1u);
+                        } else if (full) {
+                            tg = *reinterpret_cast<const f32x4_e*>(g.aux + (int64_t)mc * g.ldaux + n);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) tg[e] = g.aux[(int64_t)mc * g.ldaux + min(n + e, g.N - 1)];
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            o2[e] = v[e] + bias4[j][e];
+                            o[e] = c1 * o2[e] - tg[e];
+                            if (inb && mok && n + e < g.N) ss += o[e] * o[e];
+                        }
+                    } else {
+                        // posterior mean of the reverse step (gaussian_diffusion.py:451-471, :495-498, :210-217)
+                        f32x4 xt, zz = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (full) {
+                            xt = *reinterpret_cast<const f32x4_e*>(g.aux + (int64_t)mc * g.ldaux + n);
+                            if (has_z) zz = *reinterpret_cast<const f32x4_e*>(g.aux2 + (int64_t)mc * g.ldaux2 + n);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                xt[e] = g.aux[(int64_t)mc * g.ldaux + min(n + e, g.N - 1)];
+                                if (has_z) zz[e] = g.aux2[(int64_t)mc * g.ldaux2 + min(n + e, g.N - 1)];
+                            }
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float vv = v[e] + bias4[j][e];
+                            o2[e] = has_r ? (p1 * xt[e] - p2 * vv) : vv;  // pred_xstart
+                            o[e] = c1 * o2[e] + c2 * xt[e];
+                            if (has_z) o[e] += sg * zz[e];
+                        }
+                    }
+                    if (full) {
+                        *reinterpret_cast<f32x4_e*>(g.C + (int64_t)m * g.ldc + n) = o;
+                        if (g.out2) *reinterpret_cast<f32x4_e*>(g.out2 + (int64_t)m * g.ldout2 + n) = o2;
+                    } else if (inb && mok) {
+                        for (int e = 0; e < 4 && n + e < g.N; ++e) {
+                            g.C[(int64_t)m * g.ldc + n + e] = o[e];
+                            if (g.out2) g.out2[(int64_t)m * g.ldout2 + n + e] = o2[e];
+                        }
+                    }
+                }
+                if (EPI == GD_EPI_LOSS) {
+                    ss += __shfl_xor(ss, 1);
+                    ss += __shfl_xor(ss, 2);
+                    ss += __shfl_xor(ss, 4);
+                    ss += __shfl_xor(ss, 8);
+                    if (r == 0 && mok) g.rowpart[(int64_t)m * g.ld_rowpart + tn] = ss;
+                }
+                __builtin_amdgcn_sched_barrier(0);  // four rows at a time: keeps the epilogue's live registers bounded
+            }
+        }
+    }
+}
+
+template <int NB>
+int dr_fat_go(const DrArgs& d, int epi, int n_cu, hipStream_t s) {
+    const size_t lds = (size_t)4 * 2 * NB * 256 * sizeof(float);
+    void (*kern)(const DrArgs) = epi == GD_EPI_LOSS ? dr_fat_kernel<NB, GD_EPI_LOSS> : dr_fat_kernel<NB, GD_EPI_POST>;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[epi == GD_EPI_LOSS] && lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            gdmcf_set_error("hipFuncSetAttribute(dr_fat_kernel, LDS=%zu): %s", lds, hipGetErrorString(e));
+            return GDMCF_E_HIP;
+        }
+        attr_set[epi == GD_EPI_LOSS] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(n_cu), dim3(256), lds, s, d);
+    return GDMCF_OK;
+}
+
 void dr_hl_go(const DrArgs& d, int n_cu, hipStream_t s) {
     // GDMCF_HL_WAVES=4: one wave per SIMD (256 threads; 96 KB of LDS requested so that only one workgroup fits a CU)
     static const int waves = getenv("GDMCF_HL_WAVES") ? atoi(getenv("GDMCF_HL_WAVES")) : 8;
@@ -1350,7 +1599,7 @@ static int dr_ticket_slot(hipStream_t s) {
 // Returns GD_DR_NOT_TAKEN when the product is not one this file handles (the caller falls back to the LDS-tiled kernels).
 int g_gd_dr_force = -1;  // tools/gemm_probe.hip: overrides GDMCF_GEMM_DR per call when >= 0
 int gd_gemm_dr_launch(int layA, int layB, int epi, GdGemm& g, hipStream_t s) {
-    static const int on_env = getenv("GDMCF_GEMM_DR") ? atoi(getenv("GDMCF_GEMM_DR")) : 1;
+    static const int on_env = getenv("GDMCF_GEMM_DR") ? atoi(getenv("GDMCF_GEMM_DR")) : 17;
     const int on = g_gd_dr_force >= 0 ? g_gd_dr_force : on_env;  // bit 0: weight gradients (default), bit 1: forward
     // products (opt-in: measured SLOWER than the LDS-tiled kernels -- 0.279 vs 0.270 ms for the Yelp loss product: a K-contiguous
     // operand costs 16 half-line L1 accesses per load instead of 8 full lines, TCP accesses x3.6, 20 % of the wave cycles waiting)
@@ -1408,8 +1657,60 @@ int gd_gemm_dr_launch(int layA, int layB, int epi, GdGemm& g, hipStream_t s) {
 #undef GD_DR_GO
         }
         g.N = n_user;
+        t_gd_last_gemm = epi == GD_EPI_ADAMW ? 3 : 2;
         if (bias_db) g.out2 = nullptr;  // taken: the caller skips its column-sum pass
         return gd_launch_status("gemm_dr");
+    }
+    // bit 4 (default on): the output layer with a fused epilogue as ONE FAT TILE PER WAVE (dr_fat_kernel)
+    if ((on & 16) && layA == GD_LAY_KC && layB == GD_LAY_KC && (epi == GD_EPI_LOSS || epi == GD_EPI_POST)) {
+        const int n_cu = dr_cu_count();
+        const int tiles_m = gd_cdiv(g.M, 80);
+        bool ok = (int64_t)g.M * g.lda * 4 < ((int64_t)1 << 31) && (int64_t)g.N * g.ldb * 4 < lim && g.lda >= g.K && g.ldb >= g.K &&
+                  g.K >= 256 && (long)tiles_m * 80 * 100 <= (long)g.M * 112 &&  // 80-row tiles: at most 12 % padding
+                  ((g.K & 15) == 0 || g.ldb == g.K) &&  // a chunk that reaches past K reads the next row of B: weights, not padding
+                  (n_cu & 7) == 0 && !(epi == GD_EPI_LOSS && g.rowpart == nullptr) &&
+                  !(epi == GD_EPI_LOSS && g.aux_bits && g.ldbits < (g.N + 31) / 32);
+        // width of the tile: the one whose rounds of one tile per SIMD cost the least matrix time (rounds x NB)
+        int nb = 0;
+        long best = 1L << 60;
+        const long slots = 4L * n_cu;
+        for (int c = 12; c >= 8 && ok; --c) {
+            const long t = (long)tiles_m * gd_cdiv(g.N, 16 * c);
+            const long cost = ((t + slots - 1) / slots) * c;
+            if (t >= slots / 2 && cost < best) { best = cost; nb = c; }
+        }
+        if (ok && epi == GD_EPI_POST) {
+            // the reverse step reads x_t and writes x_{t-1} in the epilogue (2 x 4 B per element): with every wave finishing at once
+            // that burst runs under nothing, so this kernel only takes the product when the LDS-tiled kernel's last round of
+            // workgroups would be badly filled (measured: Yelp width 0.248 against 0.267 ms, Amazon-Book width 0.706 against 0.663)
+            const long t128 = (long)gd_cdiv(g.M, 80) * gd_cdiv(g.N, 128);
+            const long rounds = (t128 + 2 * n_cu - 1) / (2 * n_cu);
+            if (t128 * 100 >= rounds * 2 * n_cu * 90) ok = false;
+        }
+        if (ok && nb && !(epi == GD_EPI_LOSS && g.ld_rowpart < gd_cdiv(g.N, 16 * nb))) {
+            d.tiles_m = tiles_m;
+            d.tiles_n = gd_cdiv(g.N, 16 * nb);
+            d.m_fastest = 1;
+            d.ksp = (gd_cdiv(g.K, 16) + 1) & ~1;  // chunks of 16 k, an even number of them
+            g.tiles_m = d.tiles_m;
+            g.tiles_n = d.tiles_n;
+            d.g = g;
+            d.ctr = 0;
+            int rc = GDMCF_OK;
+            {
+                GdProfScope prof(g.prof_tag, 2.0 * g.M * g.N * g.K, s);
+                switch (nb) {
+                    case 8: rc = dr_fat_go<8>(d, epi, n_cu, s); break;
+                    case 9: rc = dr_fat_go<9>(d, epi, n_cu, s); break;
+                    case 10: rc = dr_fat_go<10>(d, epi, n_cu, s); break;
+                    case 11: rc = dr_fat_go<11>(d, epi, n_cu, s); break;
+                    default: rc = dr_fat_go<12>(d, epi, n_cu, s); break;
+                }
+            }
+            if (rc != GDMCF_OK) return rc;
+            t_gd_last_gemm = 4;
+            return gd_launch_status("gemm_dr");
+        }
     }
     // bit 3: the output layer with the fused row loss on the hybrid kernel (A pre-transposed into the tail of the row-sum scratch)
     if ((on & 8) && layA == GD_LAY_KC && layB == GD_LAY_KC && epi == GD_EPI_LOSS) {
@@ -1450,6 +1751,7 @@ int gd_gemm_dr_launch(int layA, int layB, int epi, GdGemm& g, hipStream_t s) {
             hipLaunchKernelGGL(dr_transpose_kernel, dim3(gd_cdiv(g.K, 32), gd_cdiv(g.M, 32)), dim3(256), 0, s, g.A, g.lda, g.M, g.K, at, g.M);
             dr_hl_go(d, dr_cu_count(), s);
         }
+        t_gd_last_gemm = 5;
         return gd_launch_status("gemm_dr");
     }
     if ((on & 2) && layA == GD_LAY_KC && layB == GD_LAY_KC && (epi == GD_EPI_LOSS || epi == GD_EPI_POST)) {
@@ -1494,6 +1796,7 @@ int gd_gemm_dr_launch(int layA, int layB, int epi, GdGemm& g, hipStream_t s) {
             else GD_DR_NT(4, 2, 2);
 #undef GD_DR_NT
         }
+        t_gd_last_gemm = 6;
         return gd_launch_status("gemm_dr");
     }
     return GD_DR_NOT_TAKEN;

@@ -721,18 +721,19 @@ int gd_pick_shape_class(int M, int N) {
 }
 
 int gd_gemm_launch(int layA, int layB, int epi, int cls, GdGemm& g, hipStream_t s) {
-    if (g.bf16 == 2) return gd_gemm_split_launch(layA, layB, epi, cls, g, s);
-    if (g.bf16) return gd_gemm_bf16_launch(layA, layB, epi, cls, g, s);
+    if (g.bf16 == 2) { t_gd_last_gemm = 8; return gd_gemm_split_launch(layA, layB, epi, cls, g, s); }
+    if (g.bf16) { t_gd_last_gemm = 7; return gd_gemm_bf16_launch(layA, layB, epi, cls, g, s); }
     {
         const int rc = gd_gemm_dr_launch(layA, layB, epi, g, s);  // barrier-free register-streaming kernels where they apply
         if (rc != GD_DR_NOT_TAKEN) return rc;
     }
+    t_gd_last_gemm = 1;
     // the branch-free edge loader clamps 16-byte vectors onto valid elements: it needs >= 4 elements along the
     // contiguous axis of every operand (K for K-contiguous operands, rows for row-contiguous ones); anything smaller
     // goes to the element-wise kernel of gemm_small.hip
     if (((layA == GD_LAY_KC || layB == GD_LAY_KC) && g.K < 4) || (layA == GD_LAY_MC && g.M < 4) ||
         (layB == GD_LAY_MC && g.N < 4))
-        return gd_gemm_small_launch(layA, layB, epi, g, s);
+        { t_gd_last_gemm = 9; return gd_gemm_small_launch(layA, layB, epi, g, s); }
     if (layA == GD_LAY_KC && layB == GD_LAY_KC) {
         switch (epi) {
             case GD_EPI_SLAB: return launch_class<GD_LAY_KC, GD_LAY_KC, 32, GD_EPI_SLAB>(cls, g, s);

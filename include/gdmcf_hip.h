@@ -39,6 +39,12 @@ extern "C" {
 int gdmcf_version(void);                 /* ABI version, currently 1 */
 const char* gdmcf_last_error(void);      /* thread-local message of the last failing call */
 int gdmcf_device_info(int* n_cu, int* wave_size, char* arch_host, int arch_len);
+/* Which kernel family the calling thread's LAST dense product was dispatched to (introspection for tests and
+ * profiles -- "did the hand-written path run?"): 1 LDS-tiled f32 MFMA kernel, 2 register-streaming weight-gradient
+ * kernel, 3 the same with the AdamW stream, 4 fat-tile output-layer kernel (one tile per wave), 5 hybrid kernel
+ * (opt-in), 6 register-streaming forward kernel (opt-in), 7 bf16-input kernels, 8 f32x3 kernels, 9 element-wise
+ * kernel for degenerate shapes; 0 none yet.                                                              */
+int gdmcf_debug_last_gemm(void);
 
 /* Optional in-library timing with HIP events on the launch stream (bench.py's live roofline
  * measurement).  While enabled, every tagged kernel launch is bracketed by two hipEventRecord

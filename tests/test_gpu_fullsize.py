@@ -297,6 +297,94 @@ def test_output_layer_loss_product_on_the_opt_in_hybrid_kernel(tmp_path):
     assert r.returncode == 0 and "HL-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
 
 
+@pytest.mark.parametrize("B,N,K,bits", [(400, 34395, 1000, 0), (400, 34395, 1000, 1), (400, 94949, 1000, 1), (240, 40000, 520, 0),
+                                        (400, 200000, 2000, 1)])
+def test_output_layer_loss_product_on_the_fat_tile_kernel(B, N, K, bits):
+    """csrc/gemm_dr.hip dr_fat_kernel (round 4, the DEFAULT for batch-sized M: one 80 x 16 NB tile per wave, one wave per SIMD, one
+    pass) through the C ABI of the fused loss layer (reference models/DNN.py:83-86 + gaussian_diffusion.py:335): EVERY element
+    of alpha * (h W^T + b) - target and the row sums of its square against float64 -- float and bitmap targets, the Yelp,
+    Amazon-Book and stress widths (tile widths 11, 10, ... blocks; one and several rounds of tiles) and a ragged shape with a
+    K tail -- twenty launches bit for bit, and the proof that this kernel (not the LDS-tiled one) served the call."""
+    from gdmcf_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device="cpu").manual_seed(B + N + K + bits)
+    h = torch.randn(B, K, generator=g).to(DEV)
+    W = (torch.randn(N, K, generator=g) * 0.05).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    alpha = (torch.rand(B, generator=g) + 0.5).to(DEV)
+    tgt = (torch.rand(B, N, generator=g) < 0.02).float().to(DEV)
+    ldd = (N + 31) // 32 * 32
+    nt = lib.gdmcf_loss_tiles(N)
+    words = (N + 31) // 32
+    packed = None
+    if bits:
+        pad = torch.zeros(B, words * 32, device=DEV)
+        pad[:, :N] = tgt
+        packed = (pad.view(B, words, 32).to(torch.int64) << torch.arange(32, device=DEV)).sum(-1)  # bit n & 31 of word n >> 5
+        packed = torch.where(packed >= 2 ** 31, packed - 2 ** 32, packed).to(torch.int32).contiguous()
+        del pad
+
+    def run():
+        diff = torch.full((B, ldd), float("nan"), device=DEV)
+        rowpart = torch.zeros(B * nt, device=DEV)
+        rowsum = torch.zeros(B, device=DEV)
+        if bits:
+            _lib.check(lib.gdmcf_linear_loss_fwd_bits_f32(h.data_ptr(), K, W.data_ptr(), K, bias.data_ptr(), packed.data_ptr(), words,
+                                                          alpha.data_ptr(), B, N, K, None, 0, diff.data_ptr(), ldd, rowpart.data_ptr(),
+                                                          rowsum.data_ptr(), _lib.stream_ptr()))
+        else:
+            _lib.check(lib.gdmcf_linear_loss_fwd_f32(h.data_ptr(), K, W.data_ptr(), K, bias.data_ptr(), tgt.data_ptr(), N,
+                                                     alpha.data_ptr(), B, N, K, None, 0, diff.data_ptr(), ldd, rowpart.data_ptr(),
+                                                     rowsum.data_ptr(), _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        return diff, rowsum
+
+    diff, rowsum = run()
+    assert lib.gdmcf_debug_last_gemm() == 4, "the fat-tile kernel did not serve this product"
+    ref = alpha.double()[:, None] * (h.double() @ W.double().t() + bias.double()) - tgt.double()
+    assert float((diff[:, :N].double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    rs = (ref * ref).sum(1)
+    assert float(((rowsum.double() - rs).abs() / rs).max()) <= 2e-6
+    del ref, rs
+    for _ in range(20 if N < 100000 else 3):
+        d2, r2 = run()
+        assert torch.equal(d2[:, :N], diff[:, :N]) and torch.equal(r2, rowsum)
+
+
+@pytest.mark.parametrize("eps_mode,noise", [(False, False), (True, True)])
+def test_reverse_step_product_on_the_fat_tile_kernel(eps_mode, noise):
+    """The same kernel with the posterior epilogue (gdmcf_linear_posterior_fwd_f32; reference gaussian_diffusion.py:451-471,
+    :495-498, :210-217) at the Yelp width: every element of x_{t-1} and of pred_xstart against float64."""
+    from gdmcf_amd import _lib
+    lib = _lib.load()
+    B, N, K = 400, 34395, 1000
+    g = torch.Generator(device="cpu").manual_seed(5 + eps_mode)
+    h = torch.randn(B, K, generator=g).to(DEV)
+    W = (torch.randn(N, K, generator=g) * 0.05).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    xt = torch.randn(B, N, generator=g).to(DEV)
+    c1, c2 = (torch.rand(B, generator=g) + 0.2).to(DEV), (torch.rand(B, generator=g) + 0.2).to(DEV)
+    r1 = (torch.rand(B, generator=g) + 1.0).to(DEV) if eps_mode else None
+    r2 = (torch.rand(B, generator=g) * 0.1).to(DEV) if eps_mode else None
+    sg = (torch.rand(B, generator=g) * 0.01).to(DEV) if noise else None
+    z = torch.randn(B, N, generator=g).to(DEV) if noise else None
+    xn = torch.full((B, N), float("nan"), device=DEV)
+    pred = torch.full((B, N), float("nan"), device=DEV)
+    _lib.check(lib.gdmcf_linear_posterior_fwd_f32(h.data_ptr(), K, W.data_ptr(), K, bias.data_ptr(), xt.data_ptr(), N, c1.data_ptr(),
+                                                  c2.data_ptr(), _lib.ptr(r1), _lib.ptr(r2), _lib.ptr(sg), _lib.ptr(z),
+                                                  N if noise else 0, B, N, K, xn.data_ptr(), N, pred.data_ptr(), N,
+                                                  _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    assert lib.gdmcf_debug_last_gemm() == 4
+    out = h.double() @ W.double().t() + bias.double()
+    p = (r1.double()[:, None] * xt.double() - r2.double()[:, None] * out) if eps_mode else out
+    mean = c1.double()[:, None] * p + c2.double()[:, None] * xt.double()
+    if noise:
+        mean = mean + sg.double()[:, None] * z.double()
+    assert float((pred.double() - p).abs().max()) <= 2e-5 * float(p.abs().max())
+    assert float((xn.double() - mean).abs().max()) <= 2e-5 * float(mean.abs().max())
+
+
 @pytest.mark.parametrize("B,N,K", [(400, 34395, 1000), (400, 1000, 34405), (400, 94949, 1000), (130, 4100, 515)])
 def test_fused_adamw_weight_gradient_every_element_against_float64(B, N, K):
     """gdmcf_linear_bwd_weight_adamw_f32 (dW = dZ^T A never leaves the accumulators; W, exp_avg, exp_avg_sq updated in the
