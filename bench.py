@@ -144,6 +144,9 @@ def parse():
                          "kernel from starting under the tail of the previous one: every step costs +3 %%, every 4th <1 %%)")
     ap.add_argument("--spmm", action="store_true", help="(default on) time the LightGCN SpMM, reported under 'spmm'")
     ap.add_argument("--no-spmm", action="store_true", help="skip the LightGCN SpMM leg")
+    ap.add_argument("--spmm-only", action="store_true",
+                    help="time ONLY the LightGCN propagation of --workload (yelp / amazon-book / stress: BASELINE configs[4]'s 1.2 M-node "
+                         "graph) and print its line; no training step")
     ap.add_argument("--spmm-sharded", action="store_true",
                     help="N > 1: row-shard the adjacency over the ranks (local SpMM + all-gather per layer) instead of timing "
                          "the replica on rank 0")
@@ -397,9 +400,30 @@ def main():
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
 
+    if args.spmm_only:
+        # the SpMM leg alone (reference lightGCN.py:180-194): one line in the contract's shape, metric = layers per second
+        import gdmcf_amd
+        from gdmcf_amd import _lib
+        sp_ = bench_spmm(gdmcf_amd, _lib.load(), args.workload, dev, world=world if args.spmm_sharded else 1)
+        if rank == 0:
+            print(json.dumps({"metric": "LightGCN propagation layers/sec", "value": round(1e3 / sp_["ms_per_layer"], 1), "unit": "layers/s",
+                              "n_gpus": world, "steps": 20, "warmup": 3, "ms_per_step": sp_["ms_per_layer"], "higher_is_better": True,
+                              "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                              "config": {"workload": f"{args.workload}-shape synthetic bipartite graph, d=64, 3 layers "
+                                                     "(lightGCN.py:180-194)" + (" (BASELINE configs[4]: HBM-bound SpMM stress)"
+                                                                                if args.workload == "stress" else "")},
+                              "roofline": {k: sp_[k] for k in ("bound", "achieved", "peak", "unit", "frac")}, "spmm": sp_,
+                              "spmm_split": os.environ.get("GDMCF_SPMM_SPLIT", "0")}))
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     import gdmcf_amd
     from gdmcf_amd import _lib, data
     from gdmcf_amd.parallel import DataParallelStep
+    if os.environ.get("GDMCF_PROBE_LIB"):  # a probe build of the library (tools/build_variant.sh): experiments only, the line says so
+        _lib.LIB_PATH = os.path.abspath(os.environ["GDMCF_PROBE_LIB"])
     lib = _lib.load()
 
     B, hid, T = args.batch, args.hidden, args.T
@@ -643,8 +667,6 @@ def main():
         from gdmcf_amd.graph import GraphedTrainStep
         try:
             step.flush()
-            if fuse_main:
-                opt.fuse_into_backward(model, min_numel=1 << 62)  # the captured step keeps the separate pass
             with GraphedTrainStep(diffusion, model, opt, dcsr, B, warmup=3, force_exchange=args.rehearse_dp) as gstep:
                 for i in range(max(5, args.warmup // 4)):
                     gstep(row_ids[i % n_pool])
@@ -656,8 +678,6 @@ def main():
                 sync()
                 eg = time.perf_counter() - t1
                 captured, cap_err = isinstance(gstep.graph, torch.cuda.CUDAGraph), gstep.capture_error
-            if fuse_main:
-                opt.fuse_into_backward(model)
             if dist.is_initialized():
                 tg = torch.tensor([eg, hg], dtype=torch.float64, device=dev)
                 dist.all_reduce(tg, op=dist.ReduceOp.MAX)
@@ -666,7 +686,8 @@ def main():
                              ms_per_step=round(1e3 * eg / args.steps, 4), users_per_s=round(world * B * args.steps / eg, 1),
                              host_enqueue_ms=round(1e3 * hg / args.steps, 4), eager_host_enqueue_ms=round(1e3 * host_el / args.steps, 4),
                              steps=args.steps, final_loss=float(loss_g),
-                             what="the training step replayed from one hipGraph (gdmcf_amd.graph.GraphedTrainStep)")
+                             optimizer="fused into the weight-gradient products" if fuse_main else "separate pass",
+                             what="the training step (the main line's) replayed from one hipGraph (gdmcf_amd.graph.GraphedTrainStep)")
         except Exception as exc:  # reported, never fatal for the main line
             graph_leg = dict(error=f"{type(exc).__name__}: {exc}"[:300])
 
@@ -761,6 +782,7 @@ def main():
                        "batch_rows": "device CSR rows (CsrBatch)" if sparse_rows else "dense rows densified from the device CSR"},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": klist, "final_loss": final_loss,
             "host_enqueue_ms_per_step": round(1e3 * host_el / args.steps, 4), "clock_preheat": preheat,
+            "probe_lib": os.environ.get("GDMCF_PROBE_LIB") or None,
             "rehearsal": ("ranks share the visible GPU(s), gloo group with host-staged collectives (GDMCF_BENCH_SHARE_GPU=1): "
                           "launcher / step rehearsal, not a measurement") if (share and world > 1) else None,
             "replicas_in_sync": in_sync, "dp_autotune": dp_autotune, "strong_scaling": strong_leg, "fused_optimizer_leg": fused_leg, "separate_optimizer_leg": separate_leg, "graph_leg": graph_leg, "f32x3_leg": x3_leg,
@@ -852,38 +874,40 @@ def bench_configs2(gdmcf_amd, lib, dev, steps, warmup, B=400, hid=1000, T=5, pro
         lib.gdmcf_prof_enable(0)
         return el, k, float(loss)
 
+    # main figure of the leg: AdamW of the two large weights inside their weight-gradient products (the default optimiser
+    # placement at N = 1 since round 4); the separate pass is timed beside it
+    opt.fuse_into_backward(model)
     el, kernels, loss = timed(steps, True)
     klist = kernel_table(kernels, "bf16", B, hid, I, steps, len(range(0, steps, prof_every)), el)
-    opt.fuse_into_backward(model)
-    elf, kf, lossf = timed(steps, True)
     opt.fuse_into_backward(model, min_numel=1 << 62)
+    els, ks, losss = timed(steps, True)
+    kls = kernel_table(ks, "bf16", B, hid, I, steps, len(range(0, steps, prof_every)), els)
     # the fused step's dominant kernel is the weight-gradient product WITH the optimiser stream in its epilogue: HBM-bound,
     # 26 B per parameter (W, exp_avg, exp_avg_sq read and written, the bf16 shadow written) + the bf16 operands once
-    fused_dom = None
-    kw = kf.get(5)
+    dom = None
+    kw = kernels.get(5)
     if kw:
         avg = kw["ms"] / kw["n"]
         byt = 26.0 * I * hid + 2.0 * B * (I + hid)
-        fused_dom = dict(kernel="bwd_weight_gemm + AdamW epilogue", bound="hbm", avg_ms=round(avg, 4), launches_per_step=2,
-                         achieved=round(byt / (avg * 1e-3) / 1e9, 1), peak=PEAK_HBM_GBPS, unit="GB/s",
-                         frac=round(byt / (avg * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
-                         share_of_step=round(2 * avg / (1e3 * elf / steps), 4),
-                         algorithmic_unit="26 B per parameter of the [I, hid] weight + its bf16 operands once, per launch")
-    k0 = klist[0] if klist else None
+        dom = dict(kernel="bwd_weight_gemm + AdamW epilogue", bound="hbm", avg_ms=round(avg, 4), launches_per_step=2,
+                   achieved=round(byt / (avg * 1e-3) / 1e9, 1), peak=PEAK_HBM_GBPS, unit="GB/s",
+                   frac=round(byt / (avg * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4),
+                   share_of_step=round(2 * avg / (1e3 * el / steps), 4),
+                   algorithmic_unit="26 B per parameter of the [I, hid] weight + its bf16 operands once, per launch")
+    k0s = kls[0] if kls else None
     out = dict(what="BASELINE configs[2]: Amazon-Book-shape synthetic rows, batch=400, dims=[1000], T=5, bf16 denoiser GEMM inputs on "
-                    "the bf16 MFMA (f32 accumulate, f32 master weights and AdamW state), 1 GPU",
+                    "the bf16 MFMA (f32 accumulate, f32 master weights and AdamW state), 1 GPU; AdamW of the two large weights inside "
+                    "their weight-gradient products (FusedAdamW.fuse_into_backward, the N = 1 default)",
                n_items=I, dtype="bf16", steps=steps, ms_per_step=round(1e3 * el / steps, 4), users_per_s=round(B * steps / el, 1),
-               final_loss=loss, kernels=klist,
-               dominant_kernel=None if k0 is None else dict(
-                   kernel=k0["kernel"], bound=k0["bound"], achieved=k0["achieved"], peak=k0["peak"], unit=k0["unit"], frac=k0["frac"],
-                   avg_ms=k0["avg_ms"], share_of_step=k0["share_of_step"],
-                   algorithmic_unit="AdamW: 30 B/param (28 + the bf16 shadow of the two large weights); products: operands "
-                                    "(bf16 shadows) and results once"),
-               fused_optimizer=dict(ms_per_step=round(1e3 * elf / steps, 4), users_per_s=round(B * steps / elf, 1), final_loss=lossf,
-                                    dominant_kernel=fused_dom,
-                                    what="the same step with FusedAdamW.fuse_into_backward(model): AdamW of the two large weights "
-                                         "inside their weight-gradient GEMM epilogues (no gradient round trip through HBM) -- the "
-                                         "recommended optimiser path of this configuration"))
+               final_loss=loss, kernels=klist, optimizer="fused into the weight-gradient products", dominant_kernel=dom,
+               fused_optimizer=dict(ms_per_step=round(1e3 * el / steps, 4), users_per_s=round(B * steps / el, 1), final_loss=loss,
+                                    dominant_kernel=dom, is_main_figure=True),
+               separate_optimizer=dict(ms_per_step=round(1e3 * els / steps, 4), users_per_s=round(B * steps / els, 1), final_loss=losss,
+                                       dominant_kernel=None if k0s is None else dict(
+                                           kernel=k0s["kernel"], bound=k0s["bound"], achieved=k0s["achieved"], peak=k0s["peak"],
+                                           unit=k0s["unit"], frac=k0s["frac"], avg_ms=k0s["avg_ms"], share_of_step=k0s["share_of_step"],
+                                           algorithmic_unit="AdamW: 30 B/param (28 + the bf16 shadow of the two large weights)"),
+                                       what="the same step with AdamW as a separate pass (backward(); optimizer.step())"))
     del step, opt, model, dcsr
     torch.cuda.empty_cache()
     return out

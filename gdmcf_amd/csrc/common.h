@@ -152,6 +152,8 @@ struct GdGemm {
     int accumulate;
     int prof_tag;
     GdAdamHyper adam;  // GD_EPI_ADAMW: C = parameter, aux = exp_avg, aux2 = exp_avg_sq (all [M,N], ldc)
+    const GdAdamHyper* adam_dev;  // ... this step's scalars in device memory instead (a bound graph step state: the step replayed from a
+                                  // hipGraph reads them from the block its tick kernel advances); NULL = `adam`
     // bf16 mode only: bf16 copies ("shadows", gdmcf_bf16_shadow_set) of the operands / of the LOSS epilogue's
     // result.  When BOTH operand shadows are present the kernel streams them instead of the f32 matrices.
     const void* A16;

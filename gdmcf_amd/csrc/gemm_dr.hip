@@ -1642,7 +1642,7 @@ int gd_gemm_dr_launch(int layA, int layB, int epi, GdGemm& g, hipStream_t s) {
         g.tiles_n = d.tiles_n;
         d.g = g;
         d.ctr = dr_ticket_slot(s);
-        d.adam_dev = (epi == GD_EPI_ADAMW && t_gd_step_state) ? &t_gd_step_state->hyper : nullptr;  // a bound graph step state
+        d.adam_dev = epi == GD_EPI_ADAMW ? g.adam_dev : nullptr;  // a bound graph step state (linear.hip)
         d.g.out2 = bias_db;
         {
             GdProfScope prof(g.prof_tag, 2.0 * g.M * n_user * g.K, s);

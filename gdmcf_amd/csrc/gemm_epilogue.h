@@ -29,6 +29,8 @@ template <int BM, int BN, int TM, int TN, int WAVES_M, int WAVES_N, int EPI, int
 __device__ __forceinline__ void gemm_epilogue_rows(f32x4 (&acc)[TM][TN], const GdGemm& g, int m0, int n0, int wn0,
                                                    int r, int q, int wave, int tid, float* smem) {
     static_assert(EPI == GD_EPI_STORE || EPI == GD_EPI_ADAMW, "row epilogue: weight-gradient products only");
+    GdAdamHyper hy = g.adam;  // (a step replayed from a hipGraph: this step's scalars come from the device)
+    if (EPI == GD_EPI_ADAMW && g.adam_dev) hy = *g.adam_dev;
     constexpr int LD = BN + 4;
     constexpr int IBMAX = LDS_FLOATS / (WAVES_M * 16 * LD);
     static_assert(IBMAX >= 1, "row epilogue: LDS too small for one 16-row block per wave row");
@@ -85,11 +87,13 @@ __device__ __forceinline__ void gemm_epilogue_rows(f32x4 (&acc)[TM][TN], const G
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         float pk = pv[u][k], mk = mv[u][k], vk = vv[u][k];
-                        gd_adam_elem(pk, gq[u][k], mk, vk, g.adam);
+                        gd_adam_elem(pk, gq[u][k], mk, vk, hy);
                         pv[u][k] = pk;
                         mv[u][k] = mk;
                         vv[u][k] = vk;
                     }
+                    // (nontemporal stores -- the cure for the f32 register-streaming kernel's optimiser stream, DESIGN 4.1d -- change
+                    // nothing here: 0.544 ms per Amazon-Book weight in bf16 mode either way, round 4)
                     *reinterpret_cast<f32x4_ua*>(P + oo[u]) = pv[u];
                     *reinterpret_cast<f32x4_ua*>(Mo + oo[u]) = mv[u];
                     *reinterpret_cast<f32x4_ua*>(Vo + oo[u]) = vv[u];
@@ -119,7 +123,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(f32x4 (&acc)[TM][TN], const G
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         float pk = pv[k], mk = mv[k], vk = vv[k];
-                        gd_adam_elem(pk, gv[k], mk, vk, g.adam);
+                        gd_adam_elem(pk, gv[k], mk, vk, hy);
                         pv[k] = pk;
                         mv[k] = mk;
                         vv[k] = vk;
@@ -139,7 +143,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(f32x4 (&acc)[TM][TN], const G
                         P[o + k] = g.accumulate ? P[o + k] + gv[k] : gv[k];
                     } else {
                         float pk = P[o + k], mk = Mo[o + k], vk = Vo[o + k];
-                        gd_adam_elem(pk, gv[k], mk, vk, g.adam);
+                        gd_adam_elem(pk, gv[k], mk, vk, hy);
                         P[o + k] = pk;
                         Mo[o + k] = mk;
                         Vo[o + k] = vk;
@@ -164,6 +168,8 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GdGemm
     int ncl[TN];
     bool nok[TN];
     float biasv[TN];
+    GdAdamHyper hy = g.adam;
+    if (EPI == GD_EPI_ADAMW && g.adam_dev) hy = *g.adam_dev;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn0 + 16 * j + r;
@@ -197,7 +203,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x4 (&acc)[TM][TN], const GdGemm
                 const int m = m0 + wm0 + 16 * i + 4 * q + e;
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    gd_adam_elem(pv[e][j], acc[i][j][e], mv[e][j], vv[e][j], g.adam);
+                    gd_adam_elem(pv[e][j], acc[i][j][e], mv[e][j], vv[e][j], hy);
                     if (m < g.M && nok[j]) {
                         const int64_t o = (int64_t)m * g.ldc + ncl[j];
                         P[o] = pv[e][j];

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void gemm_f32_small_kernel(const GdGemm g, int
             float* Mo = const_cast<float*>(g.aux);
             float* Vo = const_cast<float*>(g.aux2);
             float p = g.C[o], mo = Mo[o], vo = Vo[o];
-            gd_adam_elem(p, acc, mo, vo, g.adam);
+            gd_adam_elem(p, acc, mo, vo, g.adam_dev ? *g.adam_dev : g.adam);
             g.C[o] = p;
             Mo[o] = mo;
             Vo[o] = vo;

@@ -292,6 +292,7 @@ int gdmcf_linear_bwd_weight_adamw_f32(const float* dZ, int64_t lddz, const float
     g.m_fastest = gd_cdiv(N, gd_gemm_tile_m(cls)) <= gd_cdiv(K, gd_gemm_tile_n(cls));
     g.C = W; g.ldc = ldw; g.aux = exp_avg; g.aux2 = exp_avg_sq; g.prof_tag = 5;
     g.adam = gd_adam_hyper(lr, beta1, beta2, eps, weight_decay, step, grad_scale);
+    g.adam_dev = t_gd_step_state ? &t_gd_step_state->hyper : nullptr;  // bound graph step state: the scalars of the step being replayed
     attach_result_shadow(g);  // the bf16 kernels' row epilogue also refreshes W's bf16 shadow
     attach_shadows(g, GD_LAY_MC, GD_LAY_MC);
     g.out2 = bias_col_request(a_scale_col, lda, rowscale, K, db);

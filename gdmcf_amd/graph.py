@@ -47,8 +47,10 @@ class GraphedTrainStep:
             raise NotImplementedError("GraphedTrainStep: plain DNN denoiser without F.normalize, x0 target")
         if getattr(diffusion, "CatOneHot", False) or diffusion.rng != "philox" or diffusion.noise_scale == 0.0:
             raise NotImplementedError("GraphedTrainStep: continuous diffusion with in-kernel Philox randomness")
-        if len(optimizer.param_groups) != 1 or not hasattr(optimizer, "grad_scale") or getattr(optimizer, "_fused_ids", None):
-            raise NotImplementedError("GraphedTrainStep: a gdmcf_amd.FusedAdamW (not fused into backward), one parameter group")
+        if len(optimizer.param_groups) != 1 or not hasattr(optimizer, "grad_scale"):
+            raise NotImplementedError("GraphedTrainStep: a gdmcf_amd.FusedAdamW, one parameter group")
+        # (FusedAdamW.fuse_into_backward is fine since round 4: the weight-gradient products with the optimiser inside read this
+        # step's AdamW scalars from the bound step state, like the stand-alone AdamW kernel)
         if csr.values is not None:
             raise NotImplementedError("GraphedTrainStep: interaction values must all be 1 (rows stay sparse)")
         self.diffusion, self.model, self.optimizer, self.reweight = diffusion, model, optimizer, reweight

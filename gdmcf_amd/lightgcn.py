@@ -90,7 +90,7 @@ SPMM_NT = int(os.environ.get("GDMCF_SPMM_NT", "0"))  # streaming loads for bundl
 SPMM_MISS_W = float(os.environ.get("GDMCF_SPMM_MISS_W", "1.15"))  # cost of a gather of a rarely gathered row, in warm ones
 
 
-def spmm_bundle_plan(indptr, indices, d=64, n_waves=None, s_max=None, piece=None, classes=8, n_cols=None):
+def spmm_bundle_plan(indptr, indices, d=64, n_waves=None, s_max=None, piece=None, classes=8, n_cols=None, split_at=None):
     """Static schedule for gdmcf_spmm_bundled_f32 (include/gdmcf_hip.h; kernel csrc/spmm_bundle.hip).
 
     Work units: every row of at most s_max nonzeros ("short"), and the pieces (<= piece nonzeros, equal parts) of every
@@ -106,7 +106,10 @@ def spmm_bundle_plan(indptr, indices, d=64, n_waves=None, s_max=None, piece=None
         runs them in this order: the XCD's waves are in the same phase at the same time.
     Cost = nonzeros (those to a column outside the `SPMM_HOT_MB` most gathered megabytes of the table count SPMM_MISS_W
     times: they are served by the Infinity Cache at a third of the L2 rate) + a fixed overhead per row / piece.
-    Rows cut into several pieces get consecutive partial slots (crow / cptr), added up in slot order afterwards."""
+    Rows cut into several pieces get consecutive partial slots (crow / cptr), added up in slot order afterwards.
+    `split_at` (round 4 experiment, GDMCF_SPMM_SPLIT=1): rows below it (the users of the bipartite graph) and rows from it on
+    (the items) are bundled and PHASED apart -- user rows gather only the item half of the table and vice versa, so that all
+    XCDs gather from one half at a time; "most gathered" is then judged per half."""
     s_max = SPMM_SMAX if s_max is None else s_max
     piece = SPMM_PIECE if piece is None else piece
     indptr = np.asarray(indptr, dtype=np.int64)
@@ -120,7 +123,16 @@ def spmm_bundle_plan(indptr, indices, d=64, n_waves=None, s_max=None, piece=None
     # ---- which gathers can hit: the most gathered rows of the table, as many as fit beside the pieces' slice ----
     ccount = np.bincount(indices, minlength=n_cols)
     n_hot = int(SPMM_HOT_MB * 1e6 // (d * 4))
-    if n_hot < n_cols:
+    if split_at is not None and 0 < split_at < n_cols:
+        # per half of the table: the n_hot most gathered rows of the half that is being gathered from
+        cold_col = np.zeros(n_cols, bool)
+        for lo, hi in ((0, int(split_at)), (int(split_at), n_cols)):
+            cc = ccount[lo:hi]
+            if n_hot < hi - lo:
+                th = np.partition(cc, hi - lo - n_hot)[hi - lo - n_hot]
+                cold_col[lo:hi] = cc < max(th, 1)
+        cold = cold_col[indices]
+    elif n_hot < n_cols:
         thresh = np.partition(ccount, n_cols - n_hot)[n_cols - n_hot]
         cold = (ccount < max(thresh, 1))[indices]
     else:
@@ -170,10 +182,15 @@ def spmm_bundle_plan(indptr, indices, d=64, n_waves=None, s_max=None, piece=None
     # (2) short rows: "warm" rows (most of their columns are among the most gathered ones) and "cold" rows apart, each
     # set longest first and dealt to the classes G rows (= one bundle) at a time
     cold_row = (ncold[srows] * 2 > deg[srows]).astype(np.int64)
-    sord = np.lexsort((srows, -deg[srows], cold_row))  # warm before cold, longest first
+    NG = 2  # bundle groups per class = phases after the pieces: (warm, cold), or (users warm, users cold, items warm, items cold)
+    if split_at is not None:
+        NG = 4
+        cold_row = cold_row + 2 * (srows >= int(split_at)).astype(np.int64)
+    sord = np.lexsort((srows, -deg[srows], cold_row))  # group by group, longest first
     s_sorted, s_temp = srows[sord], cold_row[sord]
-    n_warm = int((s_temp == 0).sum())
-    pos_in_temp = np.arange(len(s_sorted)) - np.where(s_temp == 1, n_warm, 0)
+    n_key = np.bincount(s_temp, minlength=NG)
+    key_first = np.cumsum(n_key) - n_key
+    pos_in_temp = np.arange(len(s_sorted)) - key_first[s_temp]
     # Dealing: class c takes the share of the bundles that fills it up to the same total cost as the others (the pieces
     # of a class that straddles two kinds of rows are shorter and more numerous, so that class gets fewer bundles) --
     # stride scheduling: class c picks at times (j + 1/2) / share_c, bundle k goes to whoever picks k-th.
@@ -191,20 +208,22 @@ def spmm_bundle_plan(indptr, indices, d=64, n_waves=None, s_max=None, piece=None
         who = np.repeat(np.arange(classes), quota)
         return who[np.argsort(times, kind="stable")]
 
-    n_cold = len(s_sorted) - n_warm
-    cls_of_bundle = [deal(-(-n_warm // G)), deal(-(-n_cold // G))]
-    s_cls = np.where(s_temp == 0, cls_of_bundle[0][np.minimum(pos_in_temp // G, max(len(cls_of_bundle[0]) - 1, 0))] if n_warm else 0,
-                     cls_of_bundle[1][np.minimum(pos_in_temp // G, max(len(cls_of_bundle[1]) - 1, 0))] if n_cold else 0)
-    grp = s_cls * 2 + s_temp  # (class, temperature) groups, bundles never mix them
+    cls_of_bundle = [deal(-(-int(n_key[k_]) // G)) for k_ in range(NG)]
+    s_cls = np.zeros(len(s_sorted), dtype=np.int64)
+    for k_ in range(NG):
+        sel = s_temp == k_
+        if n_key[k_]:
+            s_cls[sel] = cls_of_bundle[k_][np.minimum(pos_in_temp[sel] // G, len(cls_of_bundle[k_]) - 1)]
+    grp = s_cls * NG + s_temp  # (class, group) pairs, bundles never mix them
     gord = np.argsort(grp, kind="stable")
     s_row, s_grp = s_sorted[gord], grp[gord]
-    n_grp_rows = np.bincount(s_grp, minlength=2 * classes)
+    n_grp_rows = np.bincount(s_grp, minlength=NG * classes)
     nb_grp = -(-n_grp_rows // G)  # bundles per group (last one padded)
     n_b = int(nb_grp.sum())
     gb_first = np.cumsum(nb_grp) - nb_grp
     gr_first = np.cumsum(n_grp_rows) - n_grp_rows
     ent0 = gb_first[s_grp] * G + (np.arange(len(s_row)) - gr_first[s_grp])  # entry index, group-major bundle order
-    b_grp = np.repeat(np.arange(2 * classes), nb_grp)
+    b_grp = np.repeat(np.arange(NG * classes), nb_grp)
     slen0 = np.zeros(n_b * G, dtype=np.int64)
     swd0 = np.zeros(n_b * G, dtype=np.float64)
     slen0[ent0], swd0[ent0] = deg[s_row], wdeg[s_row]
@@ -229,12 +248,12 @@ def spmm_bundle_plan(indptr, indices, d=64, n_waves=None, s_max=None, piece=None
     b_wave = np.zeros(n_b, dtype=np.int64)
     for c in range(classes):
         heap = [(0.0, j) for j in range(wpc)]
-        for phase in range(3):
+        for phase in range(1 + NG):
             if phase == 0:
                 idx = np.nonzero(P["cls"] == c)[0]
                 cost = pcost_sorted[idx]
             else:
-                idx = np.nonzero(b_grp == c * 2 + (phase - 1))[0]
+                idx = np.nonzero(b_grp == c * NG + (phase - 1))[0]
                 cost = bcost0[idx]
             order_ = np.argsort(-cost, kind="stable")
             dest = np.empty(len(idx), dtype=np.int64)
@@ -249,7 +268,7 @@ def spmm_bundle_plan(indptr, indices, d=64, n_waves=None, s_max=None, piece=None
     pw = np.argsort(p_wave, kind="stable")  # wave-major, CSR order inside
     P = {k_: v_[pw] for k_, v_ in P.items()}
     p_wave = p_wave[pw]
-    bw = np.lexsort((np.arange(n_b), b_grp & 1, b_wave))  # wave-major, warm before cold, longest first
+    bw = np.lexsort((np.arange(n_b), b_grp % NG, b_wave))  # wave-major, phase by phase, longest first
     new_of_old = np.empty(n_b, dtype=np.int64)
     new_of_old[bw] = np.arange(n_b)
     ent = new_of_old[ent0 // G] * G + ent0 % G
@@ -416,8 +435,9 @@ class LightGCN(nn.Module):
         self._bundled = fits and gen == "2"
         self._streamed = fits and gen == "3"
         if self._streamed:
-            plan = spmm_stream_pack(spmm_bundle_plan(indptr, indices, d=self.latent_dim, n_cols=N), indptr, indices, vals,
-                                    d=self.latent_dim)
+            split = self.n_users if (os.environ.get("GDMCF_SPMM_SPLIT", "0") == "1" and self._world == 1) else None
+            plan = spmm_stream_pack(spmm_bundle_plan(indptr, indices, d=self.latent_dim, n_cols=N, split_at=split), indptr, indices,
+                                    vals, d=self.latent_dim)
         elif self._bundled:
             plan = spmm_bundle_plan(indptr, indices, d=self.latent_dim, n_cols=N)
         else:

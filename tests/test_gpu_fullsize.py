@@ -297,6 +297,84 @@ def test_output_layer_loss_product_on_the_opt_in_hybrid_kernel(tmp_path):
     assert r.returncode == 0 and "HL-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
 
 
+@pytest.mark.parametrize("which,B,N,K", [("fwd", 400, 1000, 34405), ("fwd", 400, 1000, 94959), ("dinput", 400, 34395, 1000),
+                                         ("dinput", 400, 94949, 1000), ("fwd", 200, 999, 20003), ("loss_lds", 400, 34395, 1000),
+                                         ("loss_lds", 400, 94949, 1000)])
+def test_lds_tiled_products_every_element_against_float64_twenty_launches(which, B, N, K, tmp_path):
+    """The LDS-tiled f32 kernel (csrc/gemm_f32.hip) keeps two tiles in flight in registers that inline-asm loads write and
+    hand-counted s_waitcnt guard; its waits are chosen by the same predicate as its loads, which the build's path-insensitive
+    lint (build.py:lint_vmcnt) cannot follow -- so its guard is THIS test: the first-layer forward product
+    (gdmcf_linear_fwd_f32: split-K slabs + reducer, bias, tanh; reference models/DNN.py:79-81), the input-gradient product
+    (gdmcf_linear_bwd_input_f32; main.py:350) and the fused-loss product ON THE LDS-TILED KERNEL (GDMCF_GEMM_DR=1: the fat-tile
+    kernel that serves it by default since round 4 is switched off) at the Yelp and Amazon-Book shapes and a ragged one: EVERY
+    element against float64, then twenty more launches bit for bit (a register consumed before its load has landed shows up as
+    a few elements off in SOME launches)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "lds_check.py"
+    script.write_text(_LDS_SCRIPT.format(root=root, which=which, B=B, N=N, K=K))
+    env = dict(os.environ, GDMCF_GEMM_DR="1") if which == "loss_lds" else dict(os.environ)
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "LDS-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+_LDS_SCRIPT = r'''
+import sys, torch
+sys.path.insert(0, {root!r})
+from gdmcf_amd import _lib
+lib = _lib.load()
+dev = "cuda:0"
+which, B, N, K = {which!r}, {B}, {N}, {K}
+g = torch.Generator(device="cpu").manual_seed(B + N + K)
+st = _lib.stream_ptr()
+if which == "fwd":        # C[B, N] = tanh(A[B, K] W[N, K]^T + b)
+    A = torch.randn(B, K, generator=g).to(dev); W = (torch.randn(N, K, generator=g) * 0.01).to(dev); bias = torch.randn(N, generator=g).to(dev)
+    ws = torch.empty(max(int(lib.gdmcf_linear_ws_bytes(B, N, K)), 256), dtype=torch.uint8, device=dev)
+    def run():
+        out = torch.full((B, N), float("nan"), device=dev)
+        _lib.check(lib.gdmcf_linear_fwd_f32(A.data_ptr(), K, W.data_ptr(), K, bias.data_ptr(), 1, B, N, K, out.data_ptr(), N,
+                                            ws.data_ptr(), ws.numel(), st))
+        torch.cuda.synchronize()
+        return out
+    ref = torch.tanh(A.double() @ W.double().t() + bias.double())
+    tol = 2e-5
+elif which == "dinput":   # dA[B, K] = rs * (dZ[B, N] W[N, K]) * (1 - act^2)
+    dZ = torch.randn(B, N, generator=g).to(dev); W = (torch.randn(N, K, generator=g) * 0.01).to(dev)
+    rs = (torch.rand(B, generator=g) + 0.5).to(dev); act = torch.tanh(torch.randn(B, K, generator=g)).to(dev)
+    ws = torch.empty(max(int(lib.gdmcf_linear_ws_bytes(B, N, K)), 256), dtype=torch.uint8, device=dev)
+    def run():
+        out = torch.full((B, K), float("nan"), device=dev)
+        _lib.check(lib.gdmcf_linear_bwd_input_f32(dZ.data_ptr(), N, W.data_ptr(), K, rs.data_ptr(), act.data_ptr(), K, 1, B, N, K,
+                                                  out.data_ptr(), K, ws.data_ptr(), ws.numel(), st))
+        torch.cuda.synchronize()
+        return out
+    ref = rs.double()[:, None] * (dZ.double() @ W.double()) * (1 - act.double() ** 2)
+    tol = 2e-5
+else:                     # the fused-loss product on the LDS-tiled kernel
+    h = torch.randn(B, K, generator=g).to(dev); W = (torch.randn(N, K, generator=g) * 0.05).to(dev); bias = torch.randn(N, generator=g).to(dev)
+    tgt = (torch.rand(B, N, generator=g) < 0.02).float().to(dev)
+    ldd = (N + 31) // 32 * 32
+    rowpart = torch.zeros(B * lib.gdmcf_loss_tiles(N), device=dev); rowsum = torch.zeros(B, device=dev)
+    def run():
+        diff = torch.full((B, ldd), float("nan"), device=dev)
+        _lib.check(lib.gdmcf_linear_loss_fwd_f32(h.data_ptr(), K, W.data_ptr(), K, bias.data_ptr(), tgt.data_ptr(), N, None, B, N, K,
+                                                 None, 0, diff.data_ptr(), ldd, rowpart.data_ptr(), rowsum.data_ptr(), st))
+        torch.cuda.synchronize()
+        assert lib.gdmcf_debug_last_gemm() == 1, "the LDS-tiled kernel did not serve this product"
+        return diff[:, :N]
+    ref = h.double() @ W.double().t() + bias.double() - tgt.double()
+    tol = 2e-5
+first = run()
+err = float((first.double() - ref).abs().max()) / float(ref.abs().max())
+print("max err / max|ref|", err)
+assert err <= tol, err
+for rep in range(20):
+    assert torch.equal(run(), first), rep
+print("LDS-OK")
+'''
+
+
 @pytest.mark.parametrize("B,N,K,bits", [(400, 34395, 1000, 0), (400, 34395, 1000, 1), (400, 94949, 1000, 1), (240, 40000, 520, 0),
                                         (400, 200000, 2000, 1)])
 def test_output_layer_loss_product_on_the_fat_tile_kernel(B, N, K, bits):

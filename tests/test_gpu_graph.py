@@ -12,17 +12,19 @@ from gdmcf_amd.gaussian_diffusion import ModelMeanType
 DEV = torch.device("cuda:0")
 
 
-def _setup(gemm_dtype, seed=5):
+def _setup(gemm_dtype, seed=5, fuse=False, big=False):
     import scipy.sparse as sp
     from gdmcf_amd.data_utils import DeviceCSR
     rng = np.random.default_rng(seed)
-    U, I, hid, T = 500, 6001, 96, 7
+    U, I, hid, T = (500, 6001, 96, 7) if not big else (800, 34395, 1000, 5)  # big: the Yelp width (register-streaming kernels)
     dense = (rng.random((U, I)) < 0.006).astype(np.float32)
     dcsr = DeviceCSR(sp.csr_matrix(dense), DEV)
     torch.manual_seed(21)
     model = gdmcf_amd.DNN([I, hid], [hid, I], 10, gemm_dtype=gemm_dtype).to(DEV).train()
     diff = gdmcf_amd.GaussianDiffusion(ModelMeanType.START_X, "linear-var", 0.1, 0.001, 0.01, T, DEV)
     opt = gdmcf_amd.FusedAdamW(model.parameters(), lr=1e-3, weight_decay=0.01)
+    if fuse:  # AdamW of the two large weights inside their weight-gradient products (reads the step's scalars from the device)
+        opt.fuse_into_backward(model, min_numel=1 << 12)
     return dcsr, model, diff, opt
 
 
@@ -33,19 +35,27 @@ def _state(model, diff, opt):
     return out + [diff.Lt_history.clone(), diff.Lt_count.clone()]
 
 
-@pytest.mark.parametrize("gemm_dtype,table_steps", [("f32", 8192), ("bf16", 8192), ("f32", 4)])
-def test_graph_replay_equals_eager_steps(gemm_dtype, table_steps):
+@pytest.mark.parametrize("gemm_dtype,table_steps,fuse,big", [("f32", 8192, False, False), ("bf16", 8192, False, False),
+                                                             ("f32", 4, False, False), ("f32", 8192, True, False),
+                                                             ("bf16", 5, True, False), ("f32", 4, True, True)])
+def test_graph_replay_equals_eager_steps(gemm_dtype, table_steps, fuse, big):
+    """(fuse: FusedAdamW.fuse_into_backward -- the N = 1 default of bench.py since round 4: the products that carry the optimiser
+    read the step's AdamW scalars from the graph's device state; big: batch 400 at the Yelp width, where those products are the
+    register-streaming kernel with the optimiser stream inside its k loop)"""
     from gdmcf_amd.graph import GraphedTrainStep
     from gdmcf_amd.parallel import DataParallelStep
-    B, n_graph, n_after = 64, 14, 3
-    batches = [torch.from_numpy(np.random.default_rng(100 + k).permutation(500)[:B].astype(np.int64)) for k in range(n_graph + n_after)]
+    B, n_graph, n_after = (64, 14, 3) if not big else (400, 9, 2)
+    U = 500 if not big else 800
+    batches = [torch.from_numpy(np.random.default_rng(100 + k).permutation(U)[:B].astype(np.int64)) for k in range(n_graph + n_after)]
 
-    dcsr, model, diff, opt = _setup(gemm_dtype)
+    dcsr, model, diff, opt = _setup(gemm_dtype, fuse=fuse, big=big)
     step = DataParallelStep(diff, model, opt)
     eager_losses = [step(dcsr.batch(b.to(DEV)), True).clone() for b in batches]
     eager = _state(model, diff, opt)
+    del step, model, opt
+    torch.cuda.empty_cache()
 
-    dcsr, model, diff, opt = _setup(gemm_dtype)
+    dcsr, model, diff, opt = _setup(gemm_dtype, fuse=fuse, big=big)
     losses = []
     with GraphedTrainStep(diff, model, opt, dcsr, B, warmup=3, table_steps=table_steps) as gstep:
         for b in batches[:n_graph]:

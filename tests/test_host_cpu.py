@@ -274,8 +274,9 @@ def test_spmm_plan_covers_every_nonzero_once(d):
     assert 8 in pl["lrow"] and 9 not in pl["lrow"] and len(pl["lptr"]) == len(pl["lrow"]) + 1  # only cut rows combine
 
 
-@pytest.mark.parametrize("d,n_waves", [(64, 32), (64, 64), (16, 32), (256, 32), (8, 32)])
-def test_spmm_bundle_plan_is_a_partition_of_the_work(d, n_waves):
+@pytest.mark.parametrize("d,n_waves,split_at", [(64, 32, None), (64, 64, None), (16, 32, None), (256, 32, None), (8, 32, None),
+                                                (64, 32, 100), (16, 64, 100)])
+def test_spmm_bundle_plan_is_a_partition_of_the_work(d, n_waves, split_at):
     """Static schedule of gdmcf_spmm_bundled_f32 (gdmcf_amd/lightgcn.py:spmm_bundle_plan), emulated in numpy wave by wave
     exactly as csrc/spmm_bundle.hip walks it: every nonzero is gathered exactly once, every row is written exactly once
     (whole rows by their wave, cut rows from their partial slots in slot order), bundles hold rows of the same class
@@ -292,7 +293,8 @@ def test_spmm_bundle_plan_is_a_partition_of_the_work(d, n_waves):
     A.sort_indices()
     X = rng.standard_normal((m, d))
     s_max, piece = 12, 40
-    pl = spmm_bundle_plan(A.indptr, A.indices, d=d, n_waves=n_waves, s_max=s_max, piece=piece)
+    # (split_at: the round-4 experiment that phases the rows below / from a row index apart -- still a partition)
+    pl = spmm_bundle_plan(A.indptr, A.indices, d=d, n_waves=n_waves, s_max=s_max, piece=piece, split_at=split_at)
     G = pl["G"]
     assert G == 64 // (d // 4) and pl["n_waves"] == n_waves
     wd = pl["wdesc"].reshape(n_waves, 4)
