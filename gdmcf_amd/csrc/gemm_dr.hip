@@ -1630,12 +1630,20 @@ int gd_gemm_dr_launch(int layA, int layB, int epi, GdGemm& g, hipStream_t s) {
         d.tiles_m = gd_cdiv(g.M, 64);
         d.tiles_n = gd_cdiv(g.N, 64);
         d.m_fastest = d.tiles_m <= d.tiles_n;  // tiles that share the LARGER operand's panel draw consecutive tickets
+        {   // tuning knob: GDMCF_DR_MF=0|1 forces the ticket order of the fused-AdamW product
+            static const int mf = getenv("GDMCF_DR_MF") ? atoi(getenv("GDMCF_DR_MF")) : -1;
+            if (mf >= 0 && epi == GD_EPI_ADAMW) d.m_fastest = mf;
+        }
         const int ks = gd_cdiv(g.K, 4);
         // ring depth: the one whose size wastes the fewest padded steps per tile
         int best = 9, waste = 1 << 30;
         for (int dd : {9, 8, 7}) {
             const int w = gd_cdiv(ks, dd + 1) * (dd + 1) - ks;
             if (w < waste) { waste = w; best = dd; }
+        }
+        {   // tuning knob: GDMCF_DR_D=7|8|9 forces the ring depth
+            static const int forced = getenv("GDMCF_DR_D") ? atoi(getenv("GDMCF_DR_D")) : 0;
+            if (forced >= 7 && forced <= 9) { best = forced; waste = gd_cdiv(ks, best + 1) * (best + 1) - ks; }
         }
         d.ksp = ks + waste;
         g.tiles_m = d.tiles_m;
