@@ -75,6 +75,8 @@ import re
 TAG_RULES = [
     (r"^dr_tn_kernel<", "bwd_weight_gemm"),
     (r"^dr_tn_adamw_kernel<", "bwd_weight_gemm"),
+    (r"^dr_fat_kernel<\d+, 2>$", "loss_fwd_gemm"),
+    (r"^dr_fat_kernel<\d+, 3>$", "posterior_gemm"),
     (r"^dr_nt_kernel<.*, 2>$", "loss_fwd_gemm"),
     (r"^dr_nt_kernel<.*, 3>$", "posterior_gemm"),
     (r"^gemm_f32_spec_kernel<1, 1,", "bwd_weight_gemm"),
