@@ -323,6 +323,10 @@ __global__ __launch_bounds__(512, 2) void dr_tn_kernel(const DrArgs d) {
 // instructions are issued ALWAYS -- parked outside the descriptor (loads return 0 without a fetch, stores are dropped) while no
 // tile is pending -- so that the counts are the same in every round; the ring fill issues the parked instructions a previous
 // round would have issued.  build.py:lint_vmcnt verifies every count and that nothing touches a register in flight.
+// (A wave-specialised form -- eight multiplying waves + four stream waves per CU, hand-over through LDS, so that the stream's HBM
+// accesses do not sit in the multiplying waves' in-order vmcnt -- was built and measured in round 4: bit-identical, and 0.02-0.03 ms
+// SLOWER per launch; with its stream parked it costs only +0.015 ms over the plain product, so what the real stream costs is memory-
+// system contention, not the counter.  profiles/r04_fused_stream_ablations.txt, section G.)
 // Tiles whose lanes do not all own a full 16-byte group (the last column panel when N % 64 != 0, or with the bias column) are
 // updated on the spot from the accumulators, as in round 3 (1/16 of the Yelp output-layer tiles, 1/538 of the first layer's).
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1355,10 +1359,12 @@ __global__ __launch_bounds__(256, 1) void dr_fat_kernel(const DrArgs d) {
             const uint32_t kn = ((c) + 1 < NCH) ? (uint32_t)((c) + 1) * 64u : 0x80000000u;                            \
             _Pragma("unroll") for (int b = 0; b < NB; ++b)                                                            \
                 FB[b] = *reinterpret_cast<const f32x4*>(lds + (PAR) * (NB * 256) + b * 256 + r_off);                  \
-            if ((c) >= c_mask) { /* the chunk(s) that reach past K: zero every k >= K of A (B's may hold anything finite) */ \
+            if ((c) >= c_mask) { /* the chunk(s) that reach past K: zero every k >= K of both operands (what lies behind a row's K */ \
+                /* elements -- the next row, or the padding of a leading dimension > K -- may hold anything, NaN included) */ \
                 _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                       \
                     const bool keep = (c) * 16 + 4 * q + e < g.K;                                                     \
                     _Pragma("unroll") for (int i = 0; i < TMB; ++i) xa[PAR][i][e] = keep ? xa[PAR][i][e] : 0.f;       \
+                    _Pragma("unroll") for (int b = 0; b < NB; ++b) FB[b][e] = keep ? FB[b][e] : 0.f;                  \
                 }                                                                                                     \
             }                                                                                                         \
             __builtin_amdgcn_sched_barrier(0);                                                                        \
@@ -1675,7 +1681,6 @@ int gd_gemm_dr_launch(int layA, int layB, int epi, GdGemm& g, hipStream_t s) {
         const int tiles_m = gd_cdiv(g.M, 80);
         bool ok = (int64_t)g.M * g.lda * 4 < ((int64_t)1 << 31) && (int64_t)g.N * g.ldb * 4 < lim && g.lda >= g.K && g.ldb >= g.K &&
                   g.K >= 256 && (long)tiles_m * 80 * 100 <= (long)g.M * 112 &&  // 80-row tiles: at most 12 % padding
-                  ((g.K & 15) == 0 || g.ldb == g.K) &&  // a chunk that reaches past K reads the next row of B: weights, not padding
                   (n_cu & 7) == 0 && !(epi == GD_EPI_LOSS && g.rowpart == nullptr) &&
                   !(epi == GD_EPI_LOSS && g.aux_bits && g.ldbits < (g.N + 31) / 32);
         // width of the tile: the one whose rounds of one tile per SIMD cost the least matrix time (rounds x NB)

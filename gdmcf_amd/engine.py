@@ -161,8 +161,9 @@ class DenoiserEngine:
         layers = self.model.layer_list()
         for w, b, _ in layers:
             _lib.require_gpu(w, "DNN parameters")
-            if not (w.is_contiguous() and b.is_contiguous() and w.dtype == torch.float32):
-                raise RuntimeError("gdmcf_amd: DNN parameters must be contiguous float32")
+            # (rows of a weight may be further apart than its columns: FusedAdamW.fuse_into_backward seats them on 128-byte lines)
+            if not (w.stride(1) == 1 and w.stride(0) >= w.shape[1] and b.is_contiguous() and w.dtype == torch.float32):
+                raise RuntimeError("gdmcf_amd: DNN parameters must be float32 with unit column stride")
         return layers
 
     def buffers(self, B, device):
@@ -436,6 +437,8 @@ class DenoiserEngine:
                 scol = int(lda_use > K)
             fs = fused.fused_state(w) if fused is not None else None
             if fs is not None:
+                if fs["exp_avg"].stride() != w.stride() or fs["exp_avg_sq"].stride() != w.stride():
+                    raise RuntimeError("gdmcf_amd: the moments of a fused weight must share its leading dimension")
                 _lib.check(lib.gdmcf_linear_bwd_weight_adamw_f32(
                     dz.data_ptr(), lddz, A_use.data_ptr(), lda_use, _lib.ptr(rs), scol, B, N, K, w.data_ptr(), w.stride(0),
                     fs["exp_avg"].data_ptr(), fs["exp_avg_sq"].data_ptr(), db.data_ptr(), fs["lr"], fs["beta1"],

@@ -4,11 +4,26 @@ One HIP launch (gdmcf_adamw_f32) updates every parameter: 28 B of HBM traffic pe
 (read p, g, m, v; write p, m, v).  Same update rule and the same state_dict layout
 (`step`, `exp_avg`, `exp_avg_sq`) as torch.optim.AdamW (amsgrad / maximize are not supported).
 """
+import os
+
 import torch
 
 from . import _lib
 
 _BLOCK = 4096  # elements per workgroup; must match ADAM_BLOCK_ELEMS in kernels_misc.hip
+_ROW_ALIGN = 32  # floats: fuse_into_backward seats the rows of a fused weight (and of its moments) on 128-byte lines
+
+
+def _seat_rows(t, ld):
+    """`t` (2-D, unit column stride) with its values in storage whose row stride is `ld` elements (== columns: contiguous);
+    the elements between the rows are zero and never written afterwards."""
+    n, k = t.shape
+    if t.stride(1) == 1 and t.stride(0) == ld and t.storage_offset() == 0:
+        return t
+    buf = torch.zeros(n, ld, dtype=t.dtype, device=t.device)
+    out = buf[:, :k] if ld != k else buf
+    out.copy_(t)
+    return out
 
 
 class FusedAdamW(torch.optim.Optimizer):
@@ -27,17 +42,54 @@ class FusedAdamW(torch.optim.Optimizer):
         self._fused_ids = set()
 
     # -- optimiser-in-backward (single GPU, opt-in) -------------------------------------------------------------
-    def fuse_into_backward(self, model, min_numel=1 << 20):
+    def fuse_into_backward(self, model, min_numel=1 << 20, align_rows=None):
         """Update the large 2-D weights of `model` (a gdmcf_amd.DNN) inside the epilogue of their weight-gradient
         GEMM instead of in step(): the gradient tile never leaves the MFMA accumulators, the separate AdamW pass over
         those tensors disappears (32 -> 24 B/param of HBM traffic).  The update rule and the resulting weights /
         moments are the same as step()'s.  Consequences: `.grad` of those weights stays None, exactly one
         backward per step() (no gradient accumulation), not for data parallel (gradients must be all-reduced
-        first; DataParallelStep switches it off).  Returns self."""
+        first; DataParallelStep switches it off).  Returns self.
+
+        Layout (align_rows, default on; GDMCF_ALIGN_ROWS=0 switches it off): the optimiser stream inside the product reads
+        and writes W / exp_avg / exp_avg_sq in pieces of 256 B per row, and PyTorch's contiguous [out, in] weight starts its
+        rows wherever `in` puts them (Yelp: 4 000 B and 137 620 B apart): three of four pieces then straddle three 128-byte
+        lines instead of covering two, shared with the neighbouring tiles' pieces.  A fused weight is therefore RE-SEATED:
+        same Parameter object, same shape and values, `.data` a view of storage whose row stride is the next multiple of
+        32 floats (tools/ld_probe.py: the two Yelp products 0.291 -> 0.279 and 0.326 -> 0.285 ms).  Everything here takes
+        leading dimensions, state_dict / load_state_dict / torch.save go through the view; what does need contiguous
+        weights (this optimiser's separate pass, collectives) gets them back from unfuse() or another call of this method."""
+        if align_rows is None:
+            align_rows = os.environ.get("GDMCF_ALIGN_ROWS", "1") != "0"
         mine = {id(p) for g in self.param_groups for p in g["params"]}
         self._fused_ids = {id(w) for (w, _, _) in model.layer_list() if w.numel() >= min_numel and id(w) in mine}
+        with torch.no_grad():
+            for (w, _, _) in model.layer_list():
+                if id(w) not in mine or w.dim() != 2:
+                    continue
+                k = w.shape[1]
+                ld = (k + _ROW_ALIGN - 1) // _ROW_ALIGN * _ROW_ALIGN if (id(w) in self._fused_ids and align_rows) else k
+                self._seat(w, ld)
         model.engine.fused_opt = self if self._fused_ids else None
         return self
+
+    def unfuse(self, model):
+        """Back to the separate pass: nothing is updated inside the backward any more and every weight is contiguous again."""
+        return self.fuse_into_backward(model, min_numel=1 << 62)
+
+    def _seat(self, p, ld):
+        if p.stride(0) != ld or p.stride(1) != 1:
+            p.data = _seat_rows(p.data, ld)
+        st = self.state.get(p)
+        if st:
+            for key in ("exp_avg", "exp_avg_sq"):
+                if key in st and (st[key].stride(0) != ld or st[key].stride(1) != 1):
+                    st[key] = _seat_rows(st[key], ld)
+
+    @staticmethod
+    def _zeros_seated_like(p):
+        if p.dim() == 2 and p.stride(0) != p.shape[1]:
+            return torch.zeros(p.shape[0], p.stride(0), dtype=p.dtype, device=p.device)[:, :p.shape[1]]
+        return torch.zeros_like(p, memory_format=torch.preserve_format)
 
     def fused_state(self, p):
         """Called by the engine during backward: optimiser state + scalars for the coming step of `p`, or None."""
@@ -47,8 +99,10 @@ class FusedAdamW(torch.optim.Optimizer):
         st = self.state[p]
         if len(st) == 0:
             st["step"] = 0
-            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg"] = self._zeros_seated_like(p)
+            st["exp_avg_sq"] = self._zeros_seated_like(p)
+        elif st["exp_avg"].stride() != p.stride() or st["exp_avg_sq"].stride() != p.stride():
+            self._seat(p, p.stride(0))  # (moments loaded from a checkpoint, or the module moved: one leading dimension for all three)
         if st.get("_fused_pending"):
             raise RuntimeError("FusedAdamW(fuse_into_backward): two backward passes without step() in between")
         st["_fused_pending"] = True
@@ -90,7 +144,8 @@ class FusedAdamW(torch.optim.Optimizer):
         for p in plist:
             _lib.require_gpu(p, "FusedAdamW parameter")
             if p.dtype != torch.float32 or not p.is_contiguous():
-                raise RuntimeError("FusedAdamW: parameters must be contiguous float32")
+                raise RuntimeError("FusedAdamW: parameters must be contiguous float32 (a weight seated on aligned rows by "
+                                   "fuse_into_backward is not: unfuse(model) first)")
             if p.grad.is_sparse:
                 raise RuntimeError("FusedAdamW does not support sparse gradients")
             if not p.grad.is_contiguous() or p.grad.dtype != torch.float32:

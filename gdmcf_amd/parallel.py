@@ -173,10 +173,12 @@ class DataParallelStep:
         if self.exchange:
             diffusion.update_history = False  # replayed below on the gathered global batch
             optimizer.grad_scale = 1.0 / self.world
-            broadcast_parameters(model, group, force=True)
-            model.engine.fused_opt = None  # gradients must be all-reduced before the update
+            if hasattr(optimizer, "unfuse") and hasattr(model, "layer_list"):
+                optimizer.unfuse(model)  # gradients must be all-reduced before the update (and collectives want contiguous weights)
+            model.engine.fused_opt = None
             if hasattr(optimizer, "_fused_ids"):
                 optimizer._fused_ids = set()
+            broadcast_parameters(model, group, force=True)
             if overlap and getattr(model.engine, "supports_grad_sink", False):
                 model.engine.grad_sink = self._sink  # (other engines: gradients are exchanged after the backward)
             if getattr(model.engine, "supports_grad_sink", False):

@@ -559,3 +559,125 @@ def test_bias_gradient_as_a_column_of_the_weight_gradient_product(B, N, K):
     assert torch.equal(db2, res[0][1])
     assert torch.equal(res[0][0], res[1][0])  # the product itself does not change with the extra column
     assert float((res[0][1].double() - res[1][1].double()).abs().max()) <= 4e-6 * float(dref.abs().max())
+
+
+def test_products_take_weights_whose_rows_sit_on_128_byte_lines():
+    """FusedAdamW.fuse_into_backward seats a fused weight on rows of round_up(in, 32) floats (optim.py).  Every product that
+    reads or updates a weight (reference models/DNN.py:79-86, main.py:350-351) must give the SAME BITS with that leading
+    dimension as with PyTorch's contiguous one, at the Yelp shapes: the hidden layer, the fused-loss layer on the fat-tile
+    kernel -- whose last 16-k chunk reaches past K = 1000 into the padding, filled with NaN here: both operands are masked --
+    the input gradient, and the fused weight-gradient + AdamW products, which must also leave the padding of W / exp_avg /
+    exp_avg_sq untouched."""
+    from gdmcf_amd import _lib
+    lib = _lib.load()
+    B, I, H, E = 400, 34395, 1000, 10
+    up = lambda n, a: (n + a - 1) // a * a
+    g = torch.Generator(device="cpu").manual_seed(5)
+    ldk, ldi, ldh = up(I + E, 64), up(I, 64), 1024
+    xin = torch.zeros(B, ldk, device=DEV)
+    xin[:, :I + E] = torch.randn(B, I + E, generator=g).to(DEV)
+    hs = torch.zeros(B, ldh, device=DEV)
+    hs[:, :H] = torch.randn(B, H, generator=g).to(DEV)
+    dz2 = torch.zeros(B, ldi, device=DEV)
+    dz2[:, :I] = (torch.randn(B, I, generator=g) * 0.01).to(DEV)
+    tgt = (torch.rand(B, ldi, generator=g) < 0.002).float().to(DEV)
+    b1, b2 = torch.randn(H, generator=g).to(DEV), torch.randn(I, generator=g).to(DEV)
+    W1c = (torch.randn(H, I + E, generator=g) * 0.01).to(DEV)
+    W2c = (torch.randn(I, H, generator=g) * 0.01).to(DEV)
+    ws_bytes = max(lib.gdmcf_linear_ws_bytes(B, H, I + E), lib.gdmcf_linear_ws_bytes(B, I, H), 1 << 20)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=DEV)
+    st = _lib.stream_ptr()
+
+    def seated(t, fill):
+        n, k = t.shape
+        buf = torch.full((n, up(k, 32)), fill, device=DEV)
+        buf[:, :k] = t
+        return buf
+
+    def products(W1, W2):
+        ld1, ld2 = W1.stride(0), W2.stride(0)
+        h_out = torch.full((B, ldh), float("nan"), device=DEV)
+        _lib.check(lib.gdmcf_linear_fwd_f32(xin.data_ptr(), ldk, W1.data_ptr(), ld1, b1.data_ptr(), 1, B, H, I + E, h_out.data_ptr(),
+                                            ldh, ws.data_ptr(), ws_bytes, st))
+        diff = torch.full((B, ldi), float("nan"), device=DEV)
+        rowpart = torch.zeros(B * lib.gdmcf_loss_tiles(I), device=DEV)
+        rowsum = torch.zeros(B, device=DEV)
+        _lib.check(lib.gdmcf_linear_loss_fwd_f32(hs.data_ptr(), ldh, W2.data_ptr(), ld2, b2.data_ptr(), tgt.data_ptr(), ldi, None, B, I,
+                                                 H, None, 0, diff.data_ptr(), ldi, rowpart.data_ptr(), rowsum.data_ptr(), st))
+        fat = lib.gdmcf_debug_last_gemm()
+        dh = torch.full((B, ldh), float("nan"), device=DEV)
+        _lib.check(lib.gdmcf_linear_bwd_input_f32(dz2.data_ptr(), ldi, W2.data_ptr(), ld2, None, hs.data_ptr(), ldh, 1, B, I, H,
+                                                  dh.data_ptr(), ldh, ws.data_ptr(), ws_bytes, st))
+        torch.cuda.synchronize()
+        return h_out[:, :H].clone(), diff[:, :I].clone(), rowsum, dh[:, :H].clone(), fat
+
+    ref = products(W1c, W2c)
+    assert ref[4] == 4 and all(bool(torch.isfinite(t).all()) for t in ref[:4])
+    # hidden layer / input gradient: zero padding (what the optimiser's seating leaves); fused-loss layer: NaN padding
+    got = products(seated(W1c, 0.0)[:, :I + E], seated(W2c, float("nan"))[:, :H])
+    assert got[4] == 4, "the fat-tile kernel refused the padded leading dimension"
+    assert torch.equal(got[0], ref[0]), "hidden layer"
+    assert torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2]), "fused-loss layer (padding behind K must be masked)"
+    got0 = products(W1c, seated(W2c, 0.0)[:, :H])
+    assert torch.equal(got0[3], ref[3]), "input gradient"
+    del got, got0
+    # the fused weight-gradient + AdamW products: real elements bit-identical, the padding (sentinel 7) untouched
+    for (N, K, dZ, ldz, A, lda, Wc) in ((I, H, dz2, ldi, hs, ldh, W2c), (H, I + E, ref[0], None, xin, ldk, W1c)):
+        if ldz is None:
+            dZp = torch.zeros(B, ldh, device=DEV)
+            dZp[:, :H] = dZ
+            dZ, ldz = dZp, ldh
+        outs = []
+        for fill in (None, 7.0):
+            if fill is None:
+                W, m, v = Wc.clone(), torch.full_like(Wc, 0.01), torch.full_like(Wc, 1e-4)
+            else:
+                W, m, v = seated(Wc, fill), seated(torch.full_like(Wc, 0.01), fill), seated(torch.full_like(Wc, 1e-4), fill)
+            _lib.check(lib.gdmcf_linear_bwd_weight_adamw_f32(dZ.data_ptr(), ldz, A.data_ptr(), lda, None, 0, B, N, K, W.data_ptr(),
+                                                             W.stride(0), m.data_ptr(), v.data_ptr(), None, 1e-3, 0.9, 0.999, 1e-8,
+                                                             0.01, 3, 1.0, st))
+            torch.cuda.synchronize()
+            assert lib.gdmcf_debug_last_gemm() == 3
+            if fill is not None and W.stride(0) > K:
+                assert all(bool((t[:, K:] == fill).all()) for t in (W, m, v)), "padding written"
+            outs.append((W[:, :K], m[:, :K], v[:, :K]))
+        assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1])), (N, K)
+        del outs
+
+
+def test_training_steps_with_seated_weights_equal_the_separate_pass_bit_for_bit(monkeypatch):
+    """Five Yelp-shape training steps (reference main.py:343-351) three ways -- AdamW as a separate pass over contiguous weights;
+    inside the weight-gradient products on contiguous weights (GDMCF_ALIGN_ROWS=0); inside them on weights seated on 128-byte
+    rows (the default of fuse_into_backward) -- every loss, weight and moment identical bit for bit."""
+    import scipy.sparse as sp
+    from gdmcf_amd.data_utils import DeviceCSR
+    from gdmcf_amd.parallel import DataParallelStep
+    dev = torch.device(DEV)
+    B, hid, T = 400, 1000, 5
+    indptr, indices, I = D.synth_csr("yelp", n_rows=2 * B, seed=0)
+    dcsr = DeviceCSR(sp.csr_matrix((np.ones(len(indices), np.float32), indices, indptr), shape=(2 * B, I)), dev)
+    res = []
+    for mode in ("separate", "fused-contiguous", "fused-seated"):
+        monkeypatch.setenv("GDMCF_ALIGN_ROWS", "0" if mode == "fused-contiguous" else "1")
+        torch.manual_seed(0)
+        model = gdmcf_amd.DNN([I, hid], [hid, I], 10, time_type="cat", norm=False).to(dev).train()
+        diffusion = gdmcf_amd.GaussianDiffusion(gdmcf_amd.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, T, dev)
+        opt = gdmcf_amd.FusedAdamW(model.parameters(), lr=1e-3, weight_decay=0.01)
+        if mode != "separate":
+            opt.fuse_into_backward(model)
+        strides = [w.stride(0) for (w, _, _) in model.layer_list()]
+        assert strides == ([34432, 1024] if mode == "fused-seated" else [I + 10, hid])
+        step = DataParallelStep(diffusion, model, opt)
+        torch.manual_seed(99)
+        model.engine.manual_seed(7)
+        losses = [float(step(dcsr.batch(torch.arange((i % 2) * B, (i % 2 + 1) * B, device=dev)), True)) for i in range(5)]
+        torch.cuda.synchronize()
+        assert [w.stride(0) for (w, _, _) in model.layer_list()] == strides
+        res.append((losses, [p.detach().clone().contiguous() for p in model.parameters()],
+                    [opt.state[p]["exp_avg"].clone().contiguous() for p in model.parameters()],
+                    [opt.state[p]["exp_avg_sq"].clone().contiguous() for p in model.parameters()]))
+        del model, opt, step
+    for other in res[1:]:
+        assert other[0] == res[0][0]
+        for k in (1, 2, 3):
+            assert all(torch.equal(a, b) for a, b in zip(res[0][k], other[k]))

@@ -591,3 +591,47 @@ def test_build_lint_finds_store_data_rewritten_too_early():
     nop = _fake_kernel("\tglobal_store_dwordx4 v[0:1], v[4:7], off\n\ts_nop 1\n\tv_mov_b32_e32 v4, v9")
     assert lint_store_data(nop) == []
     assert len(lint_store_data(_fake_kernel("\tglobal_store_dwordx4 v[0:1], v[4:7], off\n\ts_nop 0\n\tv_mov_b32_e32 v5, v9"))) == 1
+
+
+def test_fuse_into_backward_seats_weight_rows_on_128_byte_lines(tmp_path, monkeypatch):
+    """FusedAdamW.fuse_into_backward (optim.py; reference main.py:258 constructs the optimiser, models/DNN.py:71-72 the weights):
+    a fused weight keeps its Parameter object, shape and values, its rows move onto 128-byte lines; state_dict / torch.save /
+    load_state_dict go through the view; the moments follow the weight; unfuse() gives contiguous tensors back."""
+    torch.manual_seed(0)
+    m = gdmcf_amd.DNN([3000, 700], [700, 3000], 10, time_type="cat", norm=False)
+    ref = {k: v.clone() for k, v in m.state_dict().items()}
+    ids = [id(w) for (w, _, _) in m.layer_list()]
+    opt = gdmcf_amd.FusedAdamW(m.parameters(), lr=1e-3)
+    assert opt.fuse_into_backward(m, min_numel=1 << 12) is opt and m.engine.fused_opt is opt
+    ws = [w for (w, _, _) in m.layer_list()]
+    assert [id(w) for w in ws] == ids and all(isinstance(w, torch.nn.Parameter) and w.requires_grad for w in ws)
+    assert [tuple(w.shape) for w in ws] == [(700, 3010), (3000, 700)]
+    assert [w.stride() for w in ws] == [(3040, 1), (704, 1)]
+    assert all(torch.equal(m.state_dict()[k], ref[k]) for k in ref)
+    path = tmp_path / "sd.pt"
+    torch.save(m.state_dict(), path)
+    back = torch.load(path)
+    assert all(torch.equal(back[k], ref[k]) for k in ref)
+    m.load_state_dict({k: 2 * v for k, v in ref.items()})
+    assert [w.stride() for w in ws] == [(3040, 1), (704, 1)]
+    assert all(torch.equal(m.state_dict()[k], 2 * ref[k]) for k in ref)
+    # what lies between the rows is zero and stays zero
+    pad = torch.as_strided(ws[1].data, (3000, 4), (704, 1), 700)
+    assert float(pad.abs().max()) == 0.0
+    # moments created for a seated weight share its leading dimension; moments that do not are re-seated with their values
+    fs = opt.fused_state(ws[1])
+    assert fs["exp_avg"].stride() == (704, 1) and fs["exp_avg_sq"].stride() == (704, 1) and fs["step"] == 1
+    opt.state[ws[0]].update(step=3, exp_avg=torch.full((700, 3010), 0.5), exp_avg_sq=torch.full((700, 3010), 0.25))
+    fs0 = opt.fused_state(ws[0])
+    assert fs0["exp_avg"].stride() == (3040, 1) and float(fs0["exp_avg"].min()) == 0.5 and float(fs0["exp_avg_sq"].max()) == 0.25
+    for w in ws:
+        opt.state[w]["_fused_pending"] = False
+    # back to the separate pass: contiguous weights and moments, same values, nothing fused
+    assert opt.unfuse(m) is opt and m.engine.fused_opt is None
+    assert all(w.is_contiguous() for w in ws) and [id(w) for (w, _, _) in m.layer_list()] == ids
+    assert all(torch.equal(m.state_dict()[k], 2 * ref[k]) for k in ref)
+    assert opt.state[ws[0]]["exp_avg"].is_contiguous() and float(opt.state[ws[0]]["exp_avg"].min()) == 0.5
+    # the switch: GDMCF_ALIGN_ROWS=0 fuses without moving anything
+    monkeypatch.setenv("GDMCF_ALIGN_ROWS", "0")
+    opt.fuse_into_backward(m, min_numel=1 << 12)
+    assert all(w.is_contiguous() for w in ws) and m.engine.fused_opt is opt

@@ -21,15 +21,16 @@ for name, N, K in (("dW2 [I,H]", I, H), ("dW1 [H,I+E]", H, I + E)):
         ldz, lda = (N + 63) // 64 * 64, (K + 63) // 64 * 64
         dZ = torch.randn(B, ldz, device=dev) * 0.1
         A = torch.randn(B, lda, device=dev)
-        W = torch.randn(N, K, device=dev) * 0.05
-        m = torch.zeros(N, K, device=dev)
-        v = torch.zeros(N, K, device=dev)
-        dW = torch.empty(N, K, device=dev)
+        ldw = (K + 31) // 32 * 32 if os.environ.get("PROBE_LDW_ALIGN") else K  # rows of W / exp_avg / exp_avg_sq on 128-byte lines
+        W = torch.randn(N, ldw, device=dev) * 0.05
+        m = torch.zeros(N, ldw, device=dev)
+        v = torch.zeros(N, ldw, device=dev)
+        dW = torch.empty(N, ldw, device=dev)
         st = _lib.stream_ptr()
         def plain():
-            _lib.check(lib.gdmcf_linear_bwd_weight_f32(dZ.data_ptr(), ldz, A.data_ptr(), lda, None, 0, B, N, K, dW.data_ptr(), K, None, 0, st))
+            _lib.check(lib.gdmcf_linear_bwd_weight_f32(dZ.data_ptr(), ldz, A.data_ptr(), lda, None, 0, B, N, K, dW.data_ptr(), ldw, None, 0, st))
         def fused():
-            _lib.check(lib.gdmcf_linear_bwd_weight_adamw_f32(dZ.data_ptr(), ldz, A.data_ptr(), lda, None, 0, B, N, K, W.data_ptr(), K,
+            _lib.check(lib.gdmcf_linear_bwd_weight_adamw_f32(dZ.data_ptr(), ldz, A.data_ptr(), lda, None, 0, B, N, K, W.data_ptr(), ldw,
                                                              m.data_ptr(), v.data_ptr(), None, 1e-5, 0.9, 0.999, 1e-8, 0.0, 3, 1.0, st))
         out = []
         for fn in (plain, fused):
