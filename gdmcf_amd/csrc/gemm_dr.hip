@@ -354,10 +354,20 @@ __device__ __forceinline__ void dr_store(f32x4 v, i32x4 srd, uint32_t voff) {
 }
 // (read-write operand: the destination stays ONE virtual register for the whole kernel, so hipcc has no new value to place at
 // every load and no PHI copies to insert at loop back edges -- copies that would move a register whose load is in flight)
+// Cache policy of the stream's loads.  NT (non-temporal: the line is not kept in L2) when every 256-byte piece of a row covers
+// whole 128-byte lines -- rows of W / exp_avg / exp_avg_sq on 128-byte lines, FusedAdamW.fuse_into_backward seats them so --:
+// nothing of a line is left for a neighbouring tile, and the stream stops evicting the operand panels (0.277 -> 0.263 and
+// 0.301 -> 0.276 ms for the two Yelp products).  With rows that start anywhere the neighbouring tiles' pieces share their first and
+// last line, and a line that is not kept is fetched from HBM twice: 0.32 -> 0.40 ms (profiles/r04_fused_stream_ablations.txt D, I).
 #ifndef GD_ADAMW_LD
-#define GD_ADAMW_LD 0  // probe builds: cache policy of the optimiser stream's loads (0 default, 1 nt)
+#define GD_ADAMW_LD 0  // probe builds: policy of the loads when NTL is false (0 default, 1 nt, 2 sc1, 3 sc0 sc1, 4 sc0 sc1 nt)
 #endif
+template <bool NTL>
 __device__ __forceinline__ void dr_load0_rw(f32x4& v, i32x4 srd, uint32_t voff) {
+    if constexpr (NTL) {
+        asm volatile(GD_SNOP "buffer_load_dwordx4 %0, %1, %2, 0 offen nt" : "+v"(v) : "v"(voff), "s"(srd) : "memory");
+        return;
+    }
 #if GD_ADAMW_LD == 1
     asm volatile(GD_SNOP "buffer_load_dwordx4 %0, %1, %2, 0 offen nt" : "+v"(v) : "v"(voff), "s"(srd) : "memory");
 #elif GD_ADAMW_LD == 2
@@ -371,7 +381,7 @@ __device__ __forceinline__ void dr_load0_rw(f32x4& v, i32x4 srd, uint32_t voff) 
 #endif
 }
 
-template <int D>
+template <int D, bool NTL>
 __global__ __launch_bounds__(512, 2) void dr_tn_adamw_kernel(const DrArgs d) {
     constexpr int LPS = 2;  // ring loads per k-step
     constexpr int R = D + 1;
@@ -496,9 +506,9 @@ __global__ __launch_bounds__(512, 2) void dr_tn_adamw_kernel(const DrArgs d) {
     };
     auto opt_load = [&](Slot& s_) {
         const uint32_t lo = (GD_ADAMW_DBG & 4) ? PARK : s_.off;  // (probe bit 2: loads parked)
-        dr_load0_rw(s_.p, srdW, lo);
-        dr_load0_rw(s_.m, srdM, lo);
-        dr_load0_rw(s_.v, srdV, lo);
+        dr_load0_rw<NTL>(s_.p, srdW, lo);
+        dr_load0_rw<NTL>(s_.m, srdM, lo);
+        dr_load0_rw<NTL>(s_.v, srdV, lo);
     };
     auto opt_pin = [&](Slot& s_) {
         asm volatile("" : "+v"(s_.p));
@@ -1546,20 +1556,30 @@ void dr_nt_go(const DrArgs& d, int n_cu, hipStream_t s) {
 }
 
 int dr_cu_count_fwd();
+template <int D, bool NTL>
+int dr_tn_adamw_go(const DrArgs& d, hipStream_t s) {
+    static bool attr_set = false;  // 8 waves x 16 KB: the tile whose optimiser stream is running
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dr_tn_adamw_kernel<D, NTL>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        if (e != hipSuccess) {
+            gdmcf_set_error("hipFuncSetAttribute(dr_tn_adamw_kernel, LDS=128 KB): %s", hipGetErrorString(e));
+            return GDMCF_E_HIP;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((dr_tn_adamw_kernel<D, NTL>), dim3(dr_cu_count_fwd()), dim3(512), 128 * 1024, s, d);
+    return GDMCF_OK;
+}
+
 template <int D, int EPI>
 int dr_tn_go(const DrArgs& d, hipStream_t s) {
     if constexpr (EPI == GD_EPI_ADAMW) {
-        static bool attr_set = false;  // 8 waves x 16 KB: the tile whose optimiser stream is running
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dr_tn_adamw_kernel<D>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            if (e != hipSuccess) {
-                gdmcf_set_error("hipFuncSetAttribute(dr_tn_adamw_kernel, LDS=128 KB): %s", hipGetErrorString(e));
-                return GDMCF_E_HIP;
-            }
-            attr_set = true;
-        }
-        hipLaunchKernelGGL((dr_tn_adamw_kernel<D>), dim3(dr_cu_count_fwd()), dim3(512), 128 * 1024, s, d);
+        // rows of W / exp_avg / exp_avg_sq on 128-byte lines: the stream's loads need not stay in L2 (dr_load0_rw)
+        const GdGemm& g = d.g;
+        const bool lines = (g.ldc & 31) == 0 && (((uintptr_t)g.C | (uintptr_t)g.aux | (uintptr_t)g.aux2) & 127) == 0;
+        static const int force = getenv("GDMCF_DR_NT_LOADS") ? atoi(getenv("GDMCF_DR_NT_LOADS")) : -1;  // tuning knob: 0 / 1
+        return (force >= 0 ? force != 0 : lines) ? dr_tn_adamw_go<D, true>(d, s) : dr_tn_adamw_go<D, false>(d, s);
     } else {
         hipLaunchKernelGGL((dr_tn_kernel<1, 1, D, EPI>), dim3(dr_cu_count_fwd()), dim3(512), 0, s, d);
     }

@@ -22,6 +22,9 @@ __device__ __forceinline__ unsigned short gd_epi_bf16(float x) {
 // LDS image [slot][BN + 4]: (4*LD) % 32 == 16, so the four lane groups of a ds_write_b32 hit disjoint banks.
 // Rounds of IB 16-row blocks per wave row when the whole tile does not fit in LDS_FLOATS.
 typedef f32x4 f32x4_ua __attribute__((aligned(4)));
+#ifndef GD_ROWEPI_NT
+#define GD_ROWEPI_NT 0  // probe builds: bit 0 nontemporal loads, bit 1 nontemporal stores in the fused-AdamW row epilogue
+#endif
 typedef unsigned int gd_u32x2 __attribute__((ext_vector_type(2)));
 typedef gd_u32x2 gd_u32x2_ua __attribute__((aligned(2)));
 
@@ -76,9 +79,15 @@ __device__ __forceinline__ void gemm_epilogue_rows(f32x4 (&acc)[TM][TN], const G
                     mm[u] = min(m, g.M - 1);
                     oo[u] = (int64_t)mm[u] * g.ldc + n;
                     // (plain accesses: nontemporal ones, as in the stand-alone AdamW kernel, measured 2-10 % slower here)
+#if GD_ROWEPI_NT & 1
+                    pv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_ua*>(P + oo[u]));
+                    mv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_ua*>(Mo + oo[u]));
+                    vv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_ua*>(Vo + oo[u]));
+#else
                     pv[u] = *reinterpret_cast<const f32x4_ua*>(P + oo[u]);
                     mv[u] = *reinterpret_cast<const f32x4_ua*>(Mo + oo[u]);
                     vv[u] = *reinterpret_cast<const f32x4_ua*>(Vo + oo[u]);
+#endif
                     gq[u] = *reinterpret_cast<const f32x4*>(&smem[sl * LD + c4]);
                 }
 #pragma unroll
@@ -94,9 +103,15 @@ __device__ __forceinline__ void gemm_epilogue_rows(f32x4 (&acc)[TM][TN], const G
                     }
                     // (nontemporal stores -- the cure for the f32 register-streaming kernel's optimiser stream, DESIGN 4.1d -- change
                     // nothing here: 0.544 ms per Amazon-Book weight in bf16 mode either way, round 4)
+#if GD_ROWEPI_NT & 2
+                    __builtin_nontemporal_store(pv[u], reinterpret_cast<f32x4_ua*>(P + oo[u]));
+                    __builtin_nontemporal_store(mv[u], reinterpret_cast<f32x4_ua*>(Mo + oo[u]));
+                    __builtin_nontemporal_store(vv[u], reinterpret_cast<f32x4_ua*>(Vo + oo[u]));
+#else
                     *reinterpret_cast<f32x4_ua*>(P + oo[u]) = pv[u];
                     *reinterpret_cast<f32x4_ua*>(Mo + oo[u]) = mv[u];
                     *reinterpret_cast<f32x4_ua*>(Vo + oo[u]) = vv[u];
+#endif
                     if (g.C16) {
                         const gd_u32x2 w16 = {gd_epi_bf16(pv[u][0]) | ((unsigned)gd_epi_bf16(pv[u][1]) << 16),
                                               gd_epi_bf16(pv[u][2]) | ((unsigned)gd_epi_bf16(pv[u][3]) << 16)};
