@@ -22,9 +22,7 @@ __device__ __forceinline__ unsigned short gd_epi_bf16(float x) {
 // LDS image [slot][BN + 4]: (4*LD) % 32 == 16, so the four lane groups of a ds_write_b32 hit disjoint banks.
 // Rounds of IB 16-row blocks per wave row when the whole tile does not fit in LDS_FLOATS.
 typedef f32x4 f32x4_ua __attribute__((aligned(4)));
-#ifndef GD_ROWEPI_NT
-#define GD_ROWEPI_NT 0  // probe builds: bit 0 nontemporal loads, bit 1 nontemporal stores in the fused-AdamW row epilogue
-#endif
+
 typedef unsigned int gd_u32x2 __attribute__((ext_vector_type(2)));
 typedef gd_u32x2 gd_u32x2_ua __attribute__((aligned(2)));
 
@@ -46,6 +44,8 @@ __device__ __forceinline__ void gemm_epilogue_rows(f32x4 (&acc)[TM][TN], const G
     float* __restrict__ P = g.C;
     float* __restrict__ Mo = const_cast<float*>(g.aux);
     float* __restrict__ Vo = const_cast<float*>(g.aux2);
+    // every row of W / exp_avg / exp_avg_sq starts on a 128-byte line (a tile's piece of a row then covers whole lines)
+    const bool lines = EPI == GD_EPI_ADAMW && (g.ldc & 31) == 0 && (((uintptr_t)P | (uintptr_t)Mo | (uintptr_t)Vo) & 127) == 0;
 #pragma unroll
     for (int i0 = 0; i0 < TM; i0 += IB) {
 #pragma unroll
@@ -64,7 +64,7 @@ __device__ __forceinline__ void gemm_epilogue_rows(f32x4 (&acc)[TM][TN], const G
             // first one is consumed.  One slot per trip left 48 bytes per thread in flight -- the epilogue then streams its
             // 26-28 bytes per parameter at ~4 TB/s (rocprofv3: 0.63 ms per Amazon-Book weight in bf16 mode, 3.9 TB/s) where the
             // stand-alone AdamW kernel reaches 6.3; loads use row indices clamped into the matrix, only the stores are predicated.
-            constexpr int U = 4;
+            constexpr int U = 4;  // (6 and 8 slots per trip measured slower: 0.522 / 0.542 against 0.509 ms per Amazon-Book weight)
             for (int s0 = tid / TPR; s0 < SLOTS; s0 += RPP * U) {
                 f32x4 pv[U], mv[U], vv[U], gq[U];
                 int64_t oo[U];
@@ -78,16 +78,18 @@ __device__ __forceinline__ void gemm_epilogue_rows(f32x4 (&acc)[TM][TN], const G
                     ok[u] = (s0 + u * RPP < SLOTS) && (i0 + sib < TM) && (m < g.M);
                     mm[u] = min(m, g.M - 1);
                     oo[u] = (int64_t)mm[u] * g.ldc + n;
-                    // (plain accesses: nontemporal ones, as in the stand-alone AdamW kernel, measured 2-10 % slower here)
-#if GD_ROWEPI_NT & 1
-                    pv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_ua*>(P + oo[u]));
-                    mv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_ua*>(Mo + oo[u]));
-                    vv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_ua*>(Vo + oo[u]));
-#else
-                    pv[u] = *reinterpret_cast<const f32x4_ua*>(P + oo[u]);
-                    mv[u] = *reinterpret_cast<const f32x4_ua*>(Mo + oo[u]);
-                    vv[u] = *reinterpret_cast<const f32x4_ua*>(Vo + oo[u]);
-#endif
+                    // (rows that start anywhere: plain accesses -- nontemporal ones measured 2-10 % slower, a piece's first and last
+                    // line are shared with the neighbouring tiles.  Rows on 128-byte lines, as FusedAdamW.fuse_into_backward seats
+                    // them: nontemporal loads and stores, configs[2] 1.79 -> 1.70 ms per step, round 4)
+                    if (lines) {
+                        pv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_ua*>(P + oo[u]));
+                        mv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_ua*>(Mo + oo[u]));
+                        vv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_ua*>(Vo + oo[u]));
+                    } else {
+                        pv[u] = *reinterpret_cast<const f32x4_ua*>(P + oo[u]);
+                        mv[u] = *reinterpret_cast<const f32x4_ua*>(Mo + oo[u]);
+                        vv[u] = *reinterpret_cast<const f32x4_ua*>(Vo + oo[u]);
+                    }
                     gq[u] = *reinterpret_cast<const f32x4*>(&smem[sl * LD + c4]);
                 }
 #pragma unroll
@@ -101,17 +103,15 @@ __device__ __forceinline__ void gemm_epilogue_rows(f32x4 (&acc)[TM][TN], const G
                         mv[u][k] = mk;
                         vv[u][k] = vk;
                     }
-                    // (nontemporal stores -- the cure for the f32 register-streaming kernel's optimiser stream, DESIGN 4.1d -- change
-                    // nothing here: 0.544 ms per Amazon-Book weight in bf16 mode either way, round 4)
-#if GD_ROWEPI_NT & 2
-                    __builtin_nontemporal_store(pv[u], reinterpret_cast<f32x4_ua*>(P + oo[u]));
-                    __builtin_nontemporal_store(mv[u], reinterpret_cast<f32x4_ua*>(Mo + oo[u]));
-                    __builtin_nontemporal_store(vv[u], reinterpret_cast<f32x4_ua*>(Vo + oo[u]));
-#else
-                    *reinterpret_cast<f32x4_ua*>(P + oo[u]) = pv[u];
-                    *reinterpret_cast<f32x4_ua*>(Mo + oo[u]) = mv[u];
-                    *reinterpret_cast<f32x4_ua*>(Vo + oo[u]) = vv[u];
-#endif
+                    if (lines) {
+                        __builtin_nontemporal_store(pv[u], reinterpret_cast<f32x4_ua*>(P + oo[u]));
+                        __builtin_nontemporal_store(mv[u], reinterpret_cast<f32x4_ua*>(Mo + oo[u]));
+                        __builtin_nontemporal_store(vv[u], reinterpret_cast<f32x4_ua*>(Vo + oo[u]));
+                    } else {
+                        *reinterpret_cast<f32x4_ua*>(P + oo[u]) = pv[u];
+                        *reinterpret_cast<f32x4_ua*>(Mo + oo[u]) = mv[u];
+                        *reinterpret_cast<f32x4_ua*>(Vo + oo[u]) = vv[u];
+                    }
                     if (g.C16) {
                         const gd_u32x2 w16 = {gd_epi_bf16(pv[u][0]) | ((unsigned)gd_epi_bf16(pv[u][1]) << 16),
                                               gd_epi_bf16(pv[u][2]) | ((unsigned)gd_epi_bf16(pv[u][3]) << 16)};
