@@ -99,7 +99,7 @@ inline int64_t round4(int64_t x) { return (x + 3) & ~(int64_t)3; }
 // launcher that takes the request clears GdGemm::out2.
 float* bias_col_request(int a_scale_col, int64_t lda, const float* rowscale, int K, float* db) {
     static const int on = getenv("GDMCF_BIAS_COL") ? atoi(getenv("GDMCF_BIAS_COL")) : 1;
-    if (!on || !a_scale_col || db == nullptr || rowscale == nullptr || t_gemm_prec != GDMCF_GEMM_F32 || lda <= K) return nullptr;
+    if (!on || !a_scale_col || db == nullptr || t_gemm_prec != GDMCF_GEMM_F32 || lda <= K) return nullptr;
     return db;
 }
 

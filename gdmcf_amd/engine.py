@@ -231,6 +231,8 @@ class DenoiserEngine:
             xin.stride(0), _lib.ptr(xt_out), xt_out.stride(0) if xt_out is not None else 0, bufs.temb.data_ptr(),
             bufs.rownorm.data_ptr(), _lib.stream_ptr())
         _lib.check(rc)
+        if xin is bufs.xin:
+            bufs.xin_ones = True  # (the builder leaves 1 in column I + E: the bias column of the first layer's weight gradient)
         return x, noise, keep  # keep the (possibly converted) inputs alive until the stream has consumed them
 
     def _prep_csr(self, bufs, batch, ts, ca, cb, noise, drop_mask, training):
@@ -260,6 +262,7 @@ class DenoiserEngine:
             keep.stride(0) if keep is not None else 0, p, self.seed, self.offset, m.emb_layer.weight.data_ptr(),
             m.emb_layer.bias.data_ptr(), self.E, B, I, bufs.xin.data_ptr(), bufs.xin.stride(0), bufs.temb.data_ptr(),
             bufs.x0bits.data_ptr(), bufs.x0bits.stride(0), _lib.stream_ptr()))
+        bufs.xin_ones = True
         return batch, noise, keep
 
     def _hidden_forward(self, bufs, layers, B, xin=None):
@@ -428,7 +431,9 @@ class DenoiserEngine:
         def weight_grad(li, w, bias, A_prev, lda_prev, N, K):
             db = self._grad_like(bias)
             A_use, lda_use = A_prev, lda_prev
-            scol = 0  # 1: column K of A_use holds the row scale (written by gdmcf_rowscale_f32 below: the copy has room for it)
+            # 1: column K of A_use holds the row scale (written by gdmcf_rowscale_f32 below: the copy has room for it) -- or, for
+            # the first layer without a row scale, the 1 the input builder leaves in xin's first padding column
+            scol = int(rs is None and li == 0 and getattr(bufs, "xin_ones", False) and lda_use > K)
             if rs is not None:
                 # (rs . dZ)^T A == dZ^T (rs . A): scale the small activation instead of the big dZ
                 _lib.check(lib.gdmcf_rowscale_f32(A_prev.data_ptr(), lda_prev, rs.data_ptr(), B, K, bufs.hs.data_ptr(),
@@ -559,6 +564,7 @@ class DenoiserEngine:
             # (no per-step input builder: 2 x 55 MB less traffic per step at Yelp shape).
             cur, nxt = bufs.xin, bufs.xin2
             keep.append(self._prep(bufs, x_start, t_vec, ca, cb, noise0, None, False, xin=cur))  # x_T
+            bufs.xin_ones = False  # (gdmcf_dnn_emb_cols_f32 below rewrites the padding columns with zeros)
             for n, i in enumerate(range(T - 1, -1, -1)):
                 ts = step_ts[i]
                 _lib.check(lib.gdmcf_dnn_emb_cols_f32(ts.data_ptr(), m.emb_layer.weight.data_ptr(),

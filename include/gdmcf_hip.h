@@ -221,8 +221,9 @@ int gdmcf_linear_bwd_input_f32(const float* dZ, int64_t lddz, const float* W, in
  * db[N]   = sum_m rowscale[m]*dZ[m,n]   (db NULL -> skipped).  When rowscale != NULL the
  * caller passes A already multiplied by rowscale (see gdmcf_rowscale_f32).
  * a_scale_col != 0 is the caller's statement that lda > K and A[m, K] == rowscale[m] for every
- * row m -- which is how gdmcf_rowscale_f32 leaves its output when ldo > K: db then comes out of
- * the product as its column K (no second pass over dZ).  The library keeps NO record between
+ * row m (== 1 when rowscale is NULL) -- which is how gdmcf_rowscale_f32 leaves its output when
+ * ldo > K, and how gdmcf_dnn_prep_input_*_f32 leave xin (column I + E holds 1 when ldxin > I + E):
+ * db then comes out of the product as its column K (no second pass over dZ).  The library keeps NO record between
  * calls and does not check the column; with a_scale_col == 0 (any A, any column K) db takes a
  * column-sum pass over dZ -- the same result within float32 rounding.  Kernels that cannot
  * carry the extra column (bf16 / f32x3 modes, small shapes) ignore the flag and take the pass. */

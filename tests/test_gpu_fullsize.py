@@ -681,3 +681,78 @@ def test_training_steps_with_seated_weights_equal_the_separate_pass_bit_for_bit(
         assert other[0] == res[0][0]
         for k in (1, 2, 3):
             assert all(torch.equal(a, b) for a, b in zip(res[0][k], other[k]))
+
+
+def test_first_layer_bias_gradient_from_the_ones_column_of_the_input_builder():
+    """gdmcf_dnn_prep_input_csr_f32 leaves 1 in column I + E of xin (its first padding column); the first layer's weight-gradient
+    product (reference main.py:350: dW1 = dz1^T [x_t, emb], db1 = sum_m dz1) then carries db1 as its column K (a_scale_col with
+    rowscale NULL).  Yelp shape through the C ABI: the column as written, dW1 / db1 of the plain and the fused-AdamW entry against
+    float64 and against the column-sum pass (a_scale_col = 0), and the hidden layer's forward -- which reads xin up to column
+    I + E only -- unchanged by what the column holds."""
+    import scipy.sparse as sp
+    from gdmcf_amd import _lib
+    from gdmcf_amd.data_utils import DeviceCSR
+    lib = _lib.load()
+    dev = torch.device(DEV)
+    B, H, E = 400, 1000, 10
+    indptr, indices, I = D.synth_csr("yelp", n_rows=B, seed=0)
+    dcsr = DeviceCSR(sp.csr_matrix((np.ones(len(indices), np.float32), indices, indptr), shape=(B, I)), dev)
+    batch = dcsr.batch(torch.arange(B, device=dev))
+    g = torch.Generator(device="cpu").manual_seed(17)
+    ldk = (I + E + 63) // 64 * 64
+    assert ldk > I + E
+    xin = torch.full((B, ldk), float("nan"), device=DEV)
+    temb = torch.zeros(B, E, device=DEV)
+    bits = torch.zeros(B, (I + 31) // 32, dtype=torch.int32, device=DEV)
+    ts = torch.randint(0, 5, (B,), generator=g).to(DEV)
+    ca = (torch.rand(5, generator=g) * 0.5 + 0.5).to(DEV)
+    cb = (torch.rand(5, generator=g) * 0.1).to(DEV)
+    ew, eb = torch.randn(E, E, generator=g).to(DEV), torch.randn(E, generator=g).to(DEV)
+    c = batch.csr
+    st = _lib.stream_ptr()
+    _lib.check(lib.gdmcf_dnn_prep_input_csr_f32(c.indptr.data_ptr(), c.indices.data_ptr(), batch.row_ids.data_ptr(), ts.data_ptr(),
+                                                ca.data_ptr(), cb.data_ptr(), 2, None, 0, 2, None, 0, 0.5, 1234, 1, ew.data_ptr(),
+                                                eb.data_ptr(), E, B, I, xin.data_ptr(), ldk, temb.data_ptr(), bits.data_ptr(),
+                                                bits.stride(0), st))
+    torch.cuda.synchronize()
+    assert bool((xin[:, I + E] == 1.0).all()) and bool((xin[:, I + E + 1:] == 0.0).all()) and bool(torch.isfinite(xin).all())
+    dz1 = torch.zeros(B, 1024, device=DEV)
+    dz1[:, :H] = (torch.randn(B, H, generator=g) * 0.01).to(DEV)
+    K = I + E
+    ref = dz1[:, :H].double().t() @ xin[:, :K].double()
+    dref = dz1[:, :H].double().sum(0)
+    out = {}
+    for scol in (1, 0):
+        dW = torch.full((H, K), float("nan"), device=DEV)
+        db = torch.full((H,), float("nan"), device=DEV)
+        _lib.check(lib.gdmcf_linear_bwd_weight_f32(dz1.data_ptr(), 1024, xin.data_ptr(), ldk, None, scol, B, H, K, dW.data_ptr(), K,
+                                                   db.data_ptr(), 0, st))
+        torch.cuda.synchronize()
+        assert float((dW.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+        assert float((db.double() - dref).abs().max()) <= 2e-6 * float(dref.abs().max())
+        out[scol] = (dW, db)
+    assert torch.equal(out[0][0], out[1][0])
+    assert float((out[0][1] - out[1][1]).abs().max()) <= 4e-6 * float(dref.abs().max())
+    # the fused entry: same db, from the column
+    W = (torch.randn(H, K, generator=g) * 0.01).to(DEV)
+    m, v = torch.zeros_like(W), torch.zeros_like(W)
+    db = torch.full((H,), float("nan"), device=DEV)
+    _lib.check(lib.gdmcf_linear_bwd_weight_adamw_f32(dz1.data_ptr(), 1024, xin.data_ptr(), ldk, None, 1, B, H, K, W.data_ptr(), K,
+                                                     m.data_ptr(), v.data_ptr(), db.data_ptr(), 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, 1.0, st))
+    torch.cuda.synchronize()
+    assert torch.equal(db, out[1][1])
+    assert float((m.double() - 0.1 * ref).abs().max()) <= 4e-6 * float(0.1 * ref.abs().max())
+    # the hidden layer reads K columns of xin: whatever column K holds
+    W1 = (torch.randn(H, K, generator=g) * 0.01).to(DEV)
+    b1 = torch.randn(H, generator=g).to(DEV)
+    ws_bytes = max(lib.gdmcf_linear_ws_bytes(B, H, K), 1 << 20)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=DEV)
+    hs = []
+    for fill in (1.0, 0.0, float("nan")):
+        xin[:, K] = fill
+        h = torch.full((B, 1024), float("nan"), device=DEV)
+        _lib.check(lib.gdmcf_linear_fwd_f32(xin.data_ptr(), ldk, W1.data_ptr(), K, b1.data_ptr(), 1, B, H, K, h.data_ptr(), 1024,
+                                            ws.data_ptr(), ws_bytes, st))
+        torch.cuda.synchronize()
+        hs.append(h[:, :H].clone())
+    assert bool(torch.isfinite(hs[0]).all()) and torch.equal(hs[0], hs[1]) and torch.equal(hs[0], hs[2])
