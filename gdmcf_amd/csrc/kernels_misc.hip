@@ -8,9 +8,6 @@
 
 #include "common.h"
 
-#ifndef GD_PREP_DBG
-#define GD_PREP_DBG 0
-#endif
 namespace {
 
 // ---------------------------------------------------------------------------------------------
@@ -83,11 +80,7 @@ struct PrepArgs {
     int64_t ldbits;
 };
 
-#if GD_PREP_DBG & 32
-__device__ __noinline__ float temb_value(float t, int f, int E) {
-#else
 __device__ __forceinline__ float temb_value(float t, int f, int E) {
-#endif
     // reference models/DNN.py:1817-1825: [cos(t*freqs), sin(t*freqs), (0 if E odd)]
     const int half = E / 2;
     if (f >= 2 * half) return 0.f;
@@ -128,18 +121,10 @@ __device__ __forceinline__ void xt4(const PrepArgs& a, int b, int col, float ca,
                     if (col + j < a.I) nz[j] = nr[col + j];
             }
         } else if (a.noise_mode == 2) {
-#if GD_PREP_DBG & 1
-            nz[0] = nz[1] = nz[2] = nz[3] = 0.5f + (float)col;
-#else
             const uint4 r = philox4x32_10(make_uint4((uint32_t)(col >> 2), (uint32_t)b, 0u, (uint32_t)a.offset),
                                           make_uint2((uint32_t)a.seed, (uint32_t)(a.seed >> 32)));
-#if GD_PREP_DBG & 4
-            nz[0] = (float)r.x; nz[1] = (float)r.y; nz[2] = (float)r.z; nz[3] = (float)r.w;
-#else
             box_muller(r.x, r.y, nz[0], nz[1]);
             box_muller(r.z, r.w, nz[2], nz[3]);
-#endif
-#endif
         }
 #pragma unroll
         // two rounded products + one rounded sum, exactly as the reference's mul, mul, add (:403-407):
@@ -178,15 +163,9 @@ __global__ __launch_bounds__(256) void prep_rowss_kernel(PrepArgs a, float* __re
 
 // PREP_G column groups of 4 per thread (strided by the workgroup's 1024 columns): the per-row scalars (ts, coefficients)
 // are fetched once per thread and each workgroup moves 16 KB in and out instead of 4 KB.
-#ifndef GD_PREP_G
-#define GD_PREP_G 4
-#endif
-constexpr int PREP_G = GD_PREP_G;
+constexpr int PREP_G = 4;
 
 __global__ __launch_bounds__(256) void prep_input_kernel(PrepArgs a) {
-#if GD_PREP_DBG & 128
-    return;
-#endif
     if (a.step_state) a.offset = a.step_state->prep_offset;
     const int b = blockIdx.y;
     const int64_t t = a.ts ? a.ts[b] : 0;
@@ -195,9 +174,6 @@ __global__ __launch_bounds__(256) void prep_input_kernel(PrepArgs a) {
         ca = a.ca[t];
         cb = a.cb[t];
     }
-#if GD_PREP_DBG & 256
-    if (ca != 123.f) return;
-#endif
     // the workgroup that holds the embedding columns evaluates the E sinusoids ONCE, one per lane, instead of E times
     // per embedding column in a serial chain of libm calls (that chain was a ~15 us tail of the whole launch)
     __shared__ float s_temb[256];
@@ -206,13 +182,8 @@ __global__ __launch_bounds__(256) void prep_input_kernel(PrepArgs a) {
     if (a.csr_indptr) {
         if (threadIdx.x < 256 * PREP_G * 4 / 32) s_bm[threadIdx.x] = 0u;
         __syncthreads();
-#if GD_PREP_DBG & 8
-        const int64_t r = b;
-        const int64_t beg = 0, end = 0;
-#else
         const int64_t r = a.csr_rows[b];
         const int64_t beg = a.csr_indptr[r], end = a.csr_indptr[r + 1];
-#endif
         for (int64_t k = beg + threadIdx.x; k < end; k += 256) {
             const int c = a.csr_indices[k] - bm_col0;
             if (c >= 0 && c < 256 * PREP_G * 4) atomicOr(&s_bm[c >> 5], 1u << (c & 31));
@@ -223,20 +194,13 @@ __global__ __launch_bounds__(256) void prep_input_kernel(PrepArgs a) {
             if (w < a.ldbits) a.bits_out[(int64_t)b * a.ldbits + w] = s_bm[threadIdx.x];
         }
     }
-#if GD_PREP_DBG & 512
-    if (ca != 123.f) return;
-#endif
     const uint32_t* bm = a.csr_indptr ? s_bm : nullptr;
     const bool has_emb = a.E > 0 && a.E <= 256 && (int)((blockIdx.x + 1) * (256 * PREP_G * 4)) > a.I;
     if (has_emb) {
         if ((int)threadIdx.x < a.E) s_temb[threadIdx.x] = temb_value((float)t, threadIdx.x, a.E);
         __syncthreads();
     }
-#if GD_PREP_DBG & 64
-#pragma unroll 1
-#else
 #pragma unroll
-#endif
     for (int u = 0; u < PREP_G; ++u) {
     const int col = (blockIdx.x * (256 * PREP_G) + u * 256 + threadIdx.x) * 4;
     if (col >= a.ldxin) return;
@@ -259,12 +223,8 @@ __global__ __launch_bounds__(256) void prep_input_kernel(PrepArgs a) {
             for (int j = 0; j < 4; ++j)
                 if (col + j < a.I) v[j] = kr[col + j] ? v[j] * a.drop_scale : 0.f;
         } else if (a.drop_mode == 2) {
-#if GD_PREP_DBG & 2
-            const uint4 r = make_uint4(col * 2654435761u, col * 40503u, b * 2654435761u, (col + b) * 2246822519u);
-#else
             const uint4 r = philox4x32_10(make_uint4((uint32_t)(col >> 2), (uint32_t)b, 1u, (uint32_t)a.offset),
                                           make_uint2((uint32_t)a.seed, (uint32_t)(a.seed >> 32)));
-#endif
             const uint32_t u[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = (u[j] < a.keep_thresh) ? v[j] * a.drop_scale : 0.f;
@@ -290,9 +250,6 @@ __global__ __launch_bounds__(256) void prep_input_kernel(PrepArgs a) {
             v[j] = e;
         }
     }
-#if GD_PREP_DBG & 16
-    if (v[0] == 123.456f)
-#endif
     *reinterpret_cast<f32x4*>(a.xin + (int64_t)b * a.ldxin + col) = f32x4{v[0], v[1], v[2], v[3]};
     if (a.xin16 && col < a.ldxin16) {
         const uint2 w = make_uint2(gd_bf16_bits(v[0]) | ((unsigned)gd_bf16_bits(v[1]) << 16),
