@@ -1,5 +1,7 @@
 // Evaluation-side kernels: masked per-row top-k (reference main.py:296-301) and the LightGCN CSR
 // SpMM (reference lightGCN.py:184-189).  Both are HBM / cache-bandwidth bound.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -33,7 +35,9 @@ template <bool STAGE, int NT>
 __global__ __launch_bounds__(NT) void topk_kernel(const float* __restrict__ pred, int64_t ldp, int I,
                                                    const int64_t* __restrict__ indptr,
                                                    const int32_t* __restrict__ indices, int k, int KP,
-                                                   int64_t* __restrict__ idx_out, float* __restrict__ val_out) {
+                                                   int64_t* __restrict__ idx_out, float* __restrict__ val_out, int redo) {
+    // redo: second launch behind topk_fast_kernel -- only the rows it marked (first index -1) are selected here
+    if (redo && idx_out[(int64_t)blockIdx.x * k] != -1) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned long long* cand = reinterpret_cast<unsigned long long*>(smem_raw);  // [KP]
     uint32_t* hist = reinterpret_cast<uint32_t*>(cand + KP);                     // [256]
@@ -179,6 +183,132 @@ __global__ __launch_bounds__(NT) void topk_kernel(const float* __restrict__ pred
     for (int size = 2; size <= KP; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
             for (int j = tid; j < KP / 2; j += NT) {
+                const int lo = ((j / stride) * stride * 2) + (j % stride);
+                const int hi = lo + stride;
+                const bool desc = ((lo & size) == 0);
+                const unsigned long long a = cand[lo], b = cand[hi];
+                if ((a < b) == desc) {
+                    cand[lo] = b;
+                    cand[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int j = tid; j < k; j += NT) {
+        const unsigned long long c = cand[j];
+        idx_out[(int64_t)row_id * k + j] = (int64_t)(0xFFFFFFFFu - (uint32_t)(c & 0xFFFFFFFFull));
+        if (val_out) val_out[(int64_t)row_id * k + j] = key_to_float((uint32_t)(c >> 32));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The fast path (round 4): no radix passes, no staged row.  A thread keeps the upper halves of its KPT keys of the row in REGISTERS and their
+// maximum goes to LDS; the k-th largest of the NT thread maxima, L, is a lower bound of the k-th largest key of the row (k
+// threads hold an element >= L), so every element of the answer -- and every tie of its last element -- is among the elements
+// >= L: for score rows that is k plus a few.  They are collected with their indices and sorted as (key, ~index) pairs: descending
+// score, ascending index among equal scores, the first k are the answer -- the same list as topk_kernel's, bit for bit.
+// ~14 KB of LDS and < 64 registers: two 1024-thread workgroups per CU, 400 rows in one round; the 55 MB of scores are read once.
+// When more than CAP elements are >= L (degenerate rows: all scores equal, the large ones all in a few threads' columns, k above
+// the number of unmasked items) the row is marked -- first index -1 -- and topk_kernel selects it in the launch that follows.
+// ---------------------------------------------------------------------------------------------
+constexpr int TOPK_FAST_CAP = 1024;
+template <int NT, int KPT>
+__global__ __launch_bounds__(NT, 8) void topk_fast_kernel(const float* __restrict__ pred, int64_t ldp, int I,
+                                                         const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                                                         int k, int64_t* __restrict__ idx_out, float* __restrict__ val_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned long long* cand = reinterpret_cast<unsigned long long*>(smem_raw);  // [TOPK_FAST_CAP]
+    uint32_t* tmax = reinterpret_cast<uint32_t*>(cand + TOPK_FAST_CAP);         // [NT]
+    uint32_t* ctl = tmax + NT;                                                   // [4]
+    uint32_t* bitmap = ctl + 4;                                                  // [ceil(I/32)]
+    const int tid = threadIdx.x;
+    const int row_id = blockIdx.x;
+    const float* row = pred + (int64_t)row_id * ldp;
+    const int nwords = (I + 31) >> 5;
+    for (int w = tid; w < nwords; w += NT) bitmap[w] = 0u;
+    if (tid == 0) ctl[0] = 0u;
+    __syncthreads();
+    if (indptr) {
+        const int64_t beg = indptr[row_id], end = indptr[row_id + 1];
+        for (int64_t j = beg + tid; j < end; j += NT) {
+            const int c = indices[j];
+            if (c >= 0 && c < I) atomicOr(&bitmap[c >> 5], 1u << (c & 31));
+        }
+    }
+    __syncthreads();
+    // the thread's elements tid + u NT: the UPPER HALVES of their keys stay in registers, two per register (the exact key of the
+    // few elements whose upper half reaches the bound's is fetched again below: L2); eight loads in flight
+    uint32_t kh[(KPT + 1) / 2];
+#pragma unroll
+    for (int u = 0; u < (KPT + 1) / 2; ++u) kh[u] = 0u;
+    uint32_t best = 0u;
+#pragma unroll
+    for (int u0 = 0; u0 < KPT; u0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = tid + (u0 + j) * NT;
+            v[j] = (u0 + j < KPT && i < I) ? row[i] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (u0 + j < KPT) {
+                const int i = tid + (u0 + j) * NT;
+                // (key 0 -- below every real key -- past the end of the row)
+                const uint32_t kk = (i < I) ? ((bitmap[i >> 5] & (1u << (i & 31))) ? NEG_INF_KEY : order_key(v[j])) : 0u;
+                kh[(u0 + j) >> 1] |= (kk >> 16) << (16 * ((u0 + j) & 1));
+                best = kk > best ? kk : best;
+            }
+        }
+    }
+    tmax[tid] = best;
+    __syncthreads();
+    // bitonic sort of the NT maxima, descending
+    for (int size = 2; size <= NT; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            if (tid < NT / 2) {
+                const int lo = ((tid / stride) * stride * 2) + (tid % stride);
+                const int hi = lo + stride;
+                const bool desc = ((lo & size) == 0);
+                const uint32_t a = tmax[lo], b = tmax[hi];
+                if ((a < b) == desc) {
+                    tmax[lo] = b;
+                    tmax[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const uint32_t L = tmax[k - 1];
+    // collect every element >= L
+    const uint32_t Lh = L >> 16;
+#pragma unroll
+    for (int u = 0; u < KPT; ++u) {
+        const int i = tid + u * NT;
+        const uint32_t h = (kh[u >> 1] >> (16 * (u & 1))) & 0xFFFFu;
+        if (i < I && h >= Lh) {
+            const uint32_t kk = masked_key(row, bitmap, i);  // the exact key
+            if (kk >= L) {
+                const uint32_t slot = atomicAdd(&ctl[0], 1u);
+                if (slot < (uint32_t)TOPK_FAST_CAP) cand[slot] = ((unsigned long long)kk << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)i);
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t C = ctl[0];
+    if (C > (uint32_t)TOPK_FAST_CAP) {  // too many: topk_kernel takes this row in the next launch
+        if (tid == 0) idx_out[(int64_t)row_id * k] = -1;
+        return;
+    }
+    // sort the candidates (padded with key 0 up to the next power of two >= C, at least k)
+    int CP = 2;
+    while (CP < (int)C || CP < k) CP <<= 1;
+    for (int j = (int)C + tid; j < CP; j += NT) cand[j] = 0ull;
+    __syncthreads();
+    for (int size = 2; size <= CP; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int j = tid; j < CP / 2; j += NT) {
                 const int lo = ((j / stride) * stride * 2) + (j % stride);
                 const int hi = lo + stride;
                 const bool desc = ((lo & size) == 0);
@@ -452,7 +582,26 @@ int gdmcf_topk_masked_f32(const float* pred, int64_t ldp, int B, int I, const in
     int KP = 2;
     while (KP < k) KP <<= 1;
     const size_t lds_base = (size_t)KP * 8 + (256 + 24) * 4 + (size_t)((I + 31) / 32) * 4;
-    const bool stage = lds_base + (size_t)I * 4 <= 150 * 1024;
+    GdProfScope prof(9, 4.0 * B * (double)I, (hipStream_t)stream);  // (both launches)
+    // the fast path (topk_fast_kernel): rows up to 40 960 wide, k <= 256 -- followed by topk_kernel for the rows it marks
+    static const int fast_on = getenv("GDMCF_TOPK_FAST") ? atoi(getenv("GDMCF_TOPK_FAST")) : 1;  // 0: the radix-select kernel only
+    const bool fast = fast_on && k <= 256 && I <= 1024 * 40 && k <= I;
+    if (fast) {
+        const size_t lds_f = (size_t)TOPK_FAST_CAP * 8 + (1024 + 4) * 4 + (size_t)((I + 31) / 32) * 4;
+        if (I <= 1024 * 8)
+            hipLaunchKernelGGL((topk_fast_kernel<1024, 8>), dim3(B), dim3(1024), lds_f, (hipStream_t)stream, pred, ldp, I, mask_indptr,
+                               mask_indices, k, idx_out, val_out);
+        else if (I <= 1024 * 34)
+            hipLaunchKernelGGL((topk_fast_kernel<1024, 34>), dim3(B), dim3(1024), lds_f, (hipStream_t)stream, pred, ldp, I, mask_indptr,
+                               mask_indices, k, idx_out, val_out);
+        else
+            hipLaunchKernelGGL((topk_fast_kernel<1024, 40>), dim3(B), dim3(1024), lds_f, (hipStream_t)stream, pred, ldp, I, mask_indptr,
+                               mask_indices, k, idx_out, val_out);
+    }
+    const int redo = fast ? 1 : 0;
+    // (behind the fast path the marked rows are rare: the variant that does not stage the row needs 6 KB of LDS instead of 140 and
+    // its workgroups -- all but the marked ones return at once -- are dispatched many per CU)
+    const bool stage = !redo && lds_base + (size_t)I * 4 <= 150 * 1024;
     const size_t lds = lds_base + (stage ? (size_t)I * 4 : 0);
     if (lds > 160 * 1024) {
         gdmcf_set_error("topk: row width %d needs %zu B of LDS (> 160 KiB)", I, lds);
@@ -470,13 +619,12 @@ int gdmcf_topk_masked_f32(const float* pred, int64_t ldp, int B, int I, const in
         }
         attr_set = true;
     }
-    GdProfScope prof(9, 4.0 * B * (double)I, (hipStream_t)stream);
     if (stage)
         hipLaunchKernelGGL((topk_kernel<true, 1024>), dim3(B), dim3(1024), lds, (hipStream_t)stream, pred, ldp, I, mask_indptr,
-                           mask_indices, k, KP, idx_out, val_out);
+                           mask_indices, k, KP, idx_out, val_out, redo);
     else
         hipLaunchKernelGGL((topk_kernel<false, 1024>), dim3(B), dim3(1024), lds, (hipStream_t)stream, pred, ldp, I, mask_indptr,
-                           mask_indices, k, KP, idx_out, val_out);
+                           mask_indices, k, KP, idx_out, val_out, redo);
     return gd_launch_status("topk");
 }
 

@@ -1387,3 +1387,56 @@ def test_bench_emits_the_contract_line():
         r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
                             capture_output=True, text=True, cwd=root, timeout=600)
         assert r2.returncode != 0 and "{" not in r2.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("I,k", [(34395, 100), (34395, 1), (34395, 256), (5000, 20), (40960, 50), (41000, 50), (300, 300)])
+def test_topk_fast_path_and_its_redo_rows_against_a_stable_sort(I, k):
+    """gdmcf_topk_masked_f32 (reference main.py:296-301: history items to -inf, torch.topk) selects through topk_fast_kernel since
+    round 4 (k <= 256, rows up to 40 960 wide) and hands the rows it cannot bound -- more than 1 024 elements at or above the k-th
+    thread maximum -- to the radix-select kernel in a second launch.  Row kinds here: random scores; all scores equal (every
+    element ties: redo); two distinct values with the threshold inside the large tie group (redo); the k largest values all in
+    one thread's columns (index = 7 mod 1024: the bound is weak, redo); masked rows with fewer than k unmasked items (the tail is
+    -inf in index order); a row with NaN-free negatives only.  Expected: indices of a STABLE descending sort (lower index first
+    among equal scores), exactly; GDMCF_TOPK_FAST=0 (radix select only) is covered by the other top-k tests via small k > 256."""
+    from gdmcf_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device="cpu").manual_seed(I + k)
+    rows = []
+    rows.append(torch.randn(I, generator=g))
+    rows.append(torch.full((I,), 0.25))
+    two = torch.where(torch.rand(I, generator=g) < 0.001, 1.0, 0.5)
+    rows.append(two)
+    adv = torch.randn(I, generator=g) * 0.01
+    sel = torch.arange(7, I, 1024)[: max(1, min(k, (I - 7 + 1023) // 1024))]
+    adv[sel] = 5.0 + torch.rand(len(sel), generator=g)
+    rows.append(adv)
+    rows.append(torch.randn(I, generator=g))       # masked heavily below
+    rows.append(-torch.rand(I, generator=g) - 1.0)
+    pred = torch.stack(rows).to(DEV)
+    B = pred.shape[0]
+    # history: row 4 keeps only k // 2 + 1 items unmasked; the others mask a random 1 %
+    indptr, indices = [0], []
+    for b in range(B):
+        if b == 4:
+            keep = torch.randperm(I, generator=g)[: k // 2 + 1]
+            m = torch.ones(I, dtype=torch.bool)
+            m[keep] = False
+            cols = torch.nonzero(m).flatten()
+        else:
+            cols = torch.nonzero(torch.rand(I, generator=g) < 0.01).flatten()
+        indices.append(cols)
+        indptr.append(indptr[-1] + len(cols))
+    indptr_t = torch.tensor(indptr, dtype=torch.int64, device=DEV)
+    indices_t = torch.cat(indices).to(torch.int32).to(DEV)
+    idx = torch.full((B, k), -7, dtype=torch.int64, device=DEV)
+    val = torch.full((B, k), float("nan"), device=DEV)
+    _lib.check(lib.gdmcf_topk_masked_f32(pred.data_ptr(), pred.stride(0), B, I, indptr_t.data_ptr(), indices_t.data_ptr(), k,
+                                         idx.data_ptr(), val.data_ptr(), _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    masked = pred.clone()
+    for b in range(B):
+        masked[b, indices[b].to(DEV)] = float("-inf")
+    want_val, want_idx = torch.sort(masked, dim=1, descending=True, stable=True)
+    assert torch.equal(idx, want_idx[:, :k]), [int((idx[b] != want_idx[b, :k]).sum()) for b in range(B)]
+    assert torch.equal(val, want_val[:, :k])
