@@ -89,6 +89,7 @@ TAG_RULES = [
     (r"^prep_input_kernel", "prep_input"),
     (r"^spmm_stream_kernel|^spmm_short_kernel", "spmm_csr"),
     (r"^spmm_vec_kernel", "spmm_csr_long_rows"),
+    (r"^topk_fast_kernel", "topk"),
     (r"^topk_kernel", "topk"),
     (r"^onehot_noise", "onehot_noise"),
 ]
