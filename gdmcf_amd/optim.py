@@ -172,6 +172,10 @@ class FusedAdamW(torch.optim.Optimizer):
             st["step"] = 0
             st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
             st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        elif p.dim() == 2 and (st["exp_avg"].stride() != p.stride() or st["exp_avg_sq"].stride() != p.stride()):
+            # moments loaded from a checkpoint written while the weight sat on aligned rows (or the other way round): the kernels
+            # address W, exp_avg and exp_avg_sq with ONE leading dimension
+            self._seat(p, p.stride(0))
         return st
 
     @torch.no_grad()

@@ -1440,3 +1440,56 @@ def test_topk_fast_path_and_its_redo_rows_against_a_stable_sort(I, k):
     want_val, want_idx = torch.sort(masked, dim=1, descending=True, stable=True)
     assert torch.equal(idx, want_idx[:, :k]), [int((idx[b] != want_idx[b, :k]).sum()) for b in range(B)]
     assert torch.equal(val, want_val[:, :k])
+
+
+def test_checkpoint_resume_with_the_fused_optimiser_on_seated_weights(tmp_path):
+    """The same resume (reference main.py:258, :343-351 with a save between steps) with AdamW inside the weight-gradient products:
+    the weights and their moments sit on 128-byte rows (FusedAdamW.fuse_into_backward), the checkpoint goes through the views,
+    and a fresh model / optimiser -- fused before OR after loading -- continues bit for bit; the model part still loads into the
+    oracle's (= the reference's) contiguous layout, and into a model that never fuses."""
+    from gdmcf_amd import checkpoint
+
+    def build(fuse):
+        torch.manual_seed(7)
+        m = gdmcf_amd.DNN([515, 64], [64, 515], 10).to(DEV)
+        d = gdmcf_amd.GaussianDiffusion(ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, 5, DEV)
+        o = gdmcf_amd.FusedAdamW(m.parameters(), lr=1e-3, weight_decay=0.01)
+        if fuse:
+            o.fuse_into_backward(m, min_numel=1 << 12)
+        return m.train(), d, o
+
+    g = torch.Generator().manual_seed(0)
+    xs = [(torch.rand(32, 515, generator=g) < 0.05).float().to(DEV) for _ in range(4)]
+
+    def run(m, d, o, batches):
+        out = []
+        for x in batches:
+            o.zero_grad()
+            l = d.training_losses(m, x, True)["loss"].mean()
+            l.backward()
+            o.step()
+            out.append(float(l.detach()))
+        return out
+
+    m, d, o = build(True)
+    assert [w.stride(0) for (w, _, _) in m.layer_list()] == [544, 64]  # 525 -> 544 floats per row; 64 already on lines
+    run(m, d, o, xs[:2])
+    checkpoint.save_checkpoint(tmp_path / "ck.pt", m, d, o, epoch=3)
+    ref_losses = run(m, d, o, xs[2:])
+    for order in ("fuse-then-load", "load-then-fuse", "never-fused"):
+        m2, d2, o2 = build(order == "fuse-then-load")
+        epoch, _ = checkpoint.load_checkpoint(tmp_path / "ck.pt", m2, d2, o2)
+        if order == "load-then-fuse":
+            o2.fuse_into_backward(m2, min_numel=1 << 12)
+        assert epoch == 3
+        got = run(m2, d2, o2, xs[2:])
+        assert got == ref_losses, order
+        for a, b in zip(m.parameters(), m2.parameters()):
+            assert torch.equal(a, b), order
+        for a, b in zip(m.parameters(), m2.parameters()):
+            assert torch.equal(o.state[a]["exp_avg"], o2.state[b]["exp_avg"]), order
+            assert torch.equal(o.state[a]["exp_avg_sq"], o2.state[b]["exp_avg_sq"]), order
+        assert torch.equal(d.Lt_history, d2.Lt_history) and torch.equal(d.Lt_count, d2.Lt_count)
+    om = O.DNN([515, 64], [64, 515], 10)
+    om.load_state_dict(torch.load(tmp_path / "ck.pt", weights_only=False)["model"])
+    assert all(p.is_contiguous() for p in om.parameters())

@@ -631,6 +631,13 @@ def test_fuse_into_backward_seats_weight_rows_on_128_byte_lines(tmp_path, monkey
     assert all(w.is_contiguous() for w in ws) and [id(w) for (w, _, _) in m.layer_list()] == ids
     assert all(torch.equal(m.state_dict()[k], 2 * ref[k]) for k in ref)
     assert opt.state[ws[0]]["exp_avg"].is_contiguous() and float(opt.state[ws[0]]["exp_avg"].min()) == 0.5
+    # moments that arrive in the other layout (a checkpoint written while the weight was seated) follow the contiguous weight in the
+    # separate pass too: W, exp_avg, exp_avg_sq are addressed with one leading dimension
+    seated = torch.zeros(700, 3040)[:, :3010]
+    seated.copy_(opt.state[ws[0]]["exp_avg"])
+    opt.state[ws[0]]["exp_avg"] = seated
+    st = opt._init_state(ws[0])
+    assert st["exp_avg"].is_contiguous() and float(st["exp_avg"].min()) == 0.5 and st["exp_avg_sq"].is_contiguous()
     # the switch: GDMCF_ALIGN_ROWS=0 fuses without moving anything
     monkeypatch.setenv("GDMCF_ALIGN_ROWS", "0")
     opt.fuse_into_backward(m, min_numel=1 << 12)
