@@ -53,6 +53,30 @@ def run_graph(table_steps=256):
 t = time.time(); l3, w3 = run_graph(); t3 = time.time() - t
 print("graph soak: 1500 replayed steps in %.1f s; equal to the eager run: losses %s weights %s" % (
     t3, bool((l1 == l3).all()), all(torch.equal(a, b) for a, b in zip(w1, w3))))
+# 3b) round 4: the same 1500 steps with AdamW INSIDE the weight-gradient products, weights seated on 128-byte rows
+#     (FusedAdamW.fuse_into_backward, the bench.py default at N = 1), eager and replayed from a hipGraph: bit for bit the separate-pass run
+def run_fused(graph):
+    torch.manual_seed(1)
+    model = gdmcf_amd.DNN([I, 1000], [1000, I], 10).to("cuda:0").train()
+    d = gdmcf_amd.GaussianDiffusion(gdmcf_amd.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, 5, "cuda:0")
+    opt = gdmcf_amd.FusedAdamW(model.parameters(), lr=1e-4)
+    opt.fuse_into_backward(model)
+    assert [w.stride(0) for (w, _, _) in model.layer_list()] == [34432, 1024]
+    losses = []
+    if graph:
+        with GraphedTrainStep(d, model, opt, dcsr, 400, table_steps=256) as g:
+            for s in range(1500):
+                losses.append(g(torch.arange((s % 10) * 400, (s % 10) * 400 + 400)))
+    else:
+        step = gdmcf_amd.parallel.DataParallelStep(d, model, opt)
+        for s in range(1500):
+            losses.append(step(dcsr.batch(torch.arange((s % 10) * 400, (s % 10) * 400 + 400)), True))
+    torch.cuda.synchronize()
+    return torch.stack(losses).cpu().numpy(), [p.detach().clone().contiguous() for p in model.parameters()]
+for graph in (False, True):
+    t = time.time(); lf, wf = run_fused(graph); tf = time.time() - t
+    print("fused-optimiser soak (%s): 1500 steps in %.1f s; equal to the separate-pass run: losses %s weights %s" % (
+        "hipGraph replay" if graph else "eager", tf, bool((l1 == lf).all()), all(torch.equal(a, b) for a, b in zip(w1, wf))))
 def run_x3():
     torch.manual_seed(1)
     model = gdmcf_amd.DNN([I, 1000], [1000, I], 10, gemm_dtype="f32x3").to("cuda:0").train()
