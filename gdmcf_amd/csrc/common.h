@@ -162,11 +162,15 @@ struct GdGemm {
     int64_t ldb16;
     void* C16;
     int64_t ldc16;
+    size_t ws_cap;  // GD_EPI_SLAB: bytes of workspace behind C (0: unknown) -- a launcher that wants more splits than the caller sized checks it
     int dbg;   // timing ablations of gemm_split.hip (GDMCF_SPLIT_DBG; 0 in production)
     int bf16;  // 1: operands rounded to bfloat16 on the way to LDS, bf16 MFMA, f32 accumulate (gemm_bf16.hip)
                // 2: operands split into three bfloat16 terms, six bf16 MFMAs per product block (gemm_split.hip)
 };
 
+// Split count the register-streaming input-gradient kernel (csrc/gemm_dr.hip: dr_kn_kernel) would use for C[M, N] = A[M, K] B[K, N],
+// or 0 when it does not take the product: gdmcf_linear_ws_bytes sizes the slab workspace with it.
+int gd_dr_kn_splits(int M, int N, int K);
 extern thread_local int t_gd_last_gemm;  // gdmcf_debug_last_gemm (include/gdmcf_hip.h)
 
 // shape classes: 0 = "batch-M" (BM=80, BN=128), 1 = square 128x128, 2 = small 64x64,

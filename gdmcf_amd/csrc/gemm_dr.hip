@@ -1554,6 +1554,140 @@ __global__ __launch_bounds__(256, 1) void dr_fat_kernel(const DrArgs d) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// C[M,N] = A[M,K] * B[K,N] as split-K partial slabs, A K-contiguous, B row-contiguous along N (the input gradient
+// dh = dZ * W of reference main.py:350 / models/DNN.py:83-86: A = dZ [batch, items], B = the output layer's weight [items, hidden]).
+// Round 4, end: both operands go STRAIGHT into the MFMA register layout -- no LDS at all, no barrier, no inline asm:
+//   A as in dr_fat_kernel: lane (r, q) loads A[m0 + 16 a + r][k0 + 4 q .. + 3], component s feeds the MFMA whose k slot q stands
+//     for k0 + 4 q + s;
+//   B as in dr_tn_kernel: load (s, l) brings rows k0 + 4 q + s, columns n0 + 64 l + 4 r .. + 3; register e is the operand of the
+//     block whose sixteen columns are n0 + 64 l + 4 r + e -- so a lane ends with four CONSECUTIVE columns (e) per row.
+// One wave per SIMD owns an 80 x (64 NL) tile over one K range (5 x 4 NL accumulator blocks): per 16-deep chunk 80 NL MFMAs beside
+// 5 + 4 NL loads (0.08 other instructions per MFMA; the LDS-tiled kernel that served this product: 0.35 and a barrier per 80,
+// MFMA pipe busy 0.72).  Tasks (split, tile) are dealt statically, the tiles of one split to one XCD (they share its rows of B).
+// The slabs go to the same reducer as before (gd_splitk_reduce: row scale, tanh').  Deterministic: static assignment, fixed k order.
+// ---------------------------------------------------------------------------------------------------------------------
+#ifndef GD_KN_EVERY
+#define GD_KN_EVERY 4
+#endif
+template <int NL>
+__global__ __launch_bounds__(256, 1) void dr_kn_kernel(const DrArgs d) {
+    constexpr int TMB = 5;
+    const GdGemm& g = d.g;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int nblk = gridDim.x, per = nblk >> 3;
+    const int wl = ((nblk & 7) == 0 ? ((int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3)) : (int)blockIdx.x) * 4 + wave;
+    const int n_waves = nblk * 4;
+    const int ntiles = d.tiles_m * d.tiles_n;
+    const int CPS = d.ksp;                      // chunks of 16 k per split (even)
+    const int total_chunks = (g.K + 15) >> 4;
+    const int ntasks = ntiles * g.splits;
+    const __amdgpu_buffer_rsrc_t srdA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, (int)(((int64_t)(g.M - 1) * g.lda + g.K) * 4), 0x00020000);
+    // (rows k >= K of B lie outside the descriptor and read as 0)
+    const __amdgpu_buffer_rsrc_t srdB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B), 0, (int)(((int64_t)(g.K - 1) * g.ldb + g.N) * 4), 0x00020000);
+    const uint32_t ldb16 = (uint32_t)g.ldb * 64u;  // bytes per chunk of 16 rows of B
+    for (int task = wl; task < ntasks; task += n_waves) {
+        const int split = task / ntiles, tile = task - split * ntiles;
+        const int tm = tile % d.tiles_m, tn = tile / d.tiles_m;
+        const int m0 = tm * (16 * TMB), n0 = tn * (64 * NL);
+        const int c_lo = split * CPS;
+        uint32_t offA[TMB], offB[4][NL];
+#pragma unroll
+        for (int a = 0; a < TMB; ++a) offA[a] = (uint32_t)(((int64_t)min(m0 + 16 * a + r, g.M - 1) * g.lda + 4 * q) * 4);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+                const int n = n0 + 64 * l + 4 * r;
+                // a group that would start past the row's N columns is parked outside the matrix (reads 0)
+                offB[s][l] = n < g.N ? (uint32_t)(((int64_t)(4 * q + s) * g.ldb + n) * 4) : 0x80000000u;
+            }
+        f32x4 acc[TMB][NL][4];
+#pragma unroll
+        for (int a = 0; a < TMB; ++a)
+#pragma unroll
+            for (int l = 0; l < NL; ++l)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[a][l][e] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 xa[2][TMB], xb[2][4][NL];
+        {   // fill: chunk c_lo
+            const uint32_t ka = (uint32_t)c_lo * 64u, kb = (uint32_t)c_lo * ldb16;
+#pragma unroll
+            for (int a = 0; a < TMB; ++a) xa[0][a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdA, offA[a], ka, 0));
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int l = 0; l < NL; ++l)
+                    xb[0][s][l] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdB, offB[s][l], kb, 0));
+        }
+        // one chunk: PAR = its parity; the 5 + 4 NL loads of chunk c + 1 ride between its first MFMAs, one every GD_KN_EVERY -- early, so
+        // that the rest of the chunk covers their latency (B comes from HBM)
+#define GD_KN_CHUNK(PAR, c)                                                                                            \
+        {                                                                                                              \
+            const bool more = (c) + 1 < c_lo + CPS && (c) + 1 < total_chunks;                                          \
+            const uint32_t ka = more ? (uint32_t)((c) + 1) * 64u : 0x80000000u;                                        \
+            const uint32_t kb = more ? (uint32_t)((c) + 1) * ldb16 : 0x80000000u;                                      \
+            if ((c) * 16 + 15 >= g.K) { /* the chunk that reaches past K: zero A's k >= K (B's rows there read as 0) */ \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                        \
+                    const bool keep = (c) * 16 + 4 * q + e < g.K;                                                      \
+                    _Pragma("unroll") for (int a = 0; a < TMB; ++a) xa[PAR][a][e] = keep ? xa[PAR][a][e] : 0.f;        \
+                }                                                                                                      \
+            }                                                                                                          \
+            /* (operands stay in VGPRs: hipcc otherwise parks them in spare AGPRs and moves them back per use) */        \
+            _Pragma("unroll") for (int a = 0; a < TMB; ++a) asm volatile("" : "+v"(xa[PAR][a]));                       \
+            _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                              \
+                _Pragma("unroll") for (int l = 0; l < NL; ++l) asm volatile("" : "+v"(xb[PAR][s][l]));                 \
+            __builtin_amdgcn_sched_barrier(0);                                                                         \
+            _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                            \
+                _Pragma("unroll") for (int n = 0; n < TMB * NL * 4; ++n) {                                             \
+                    const int a = n / (NL * 4), l = (n / 4) % NL, e = n % 4;                                           \
+                    acc[a][l][e] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[PAR][a][s], xb[PAR][s][l][e], acc[a][l][e], 0, 0, 0); \
+                    const int idx = s * (TMB * NL * 4) + n;                                                            \
+                    if (idx % GD_KN_EVERY == 2 && idx / GD_KN_EVERY < TMB + 4 * NL) {                                  \
+                        const int ld = idx / GD_KN_EVERY;                                                              \
+                        __builtin_amdgcn_sched_barrier(0);                                                             \
+                        if (ld < TMB)                                                                                  \
+                            xa[(PAR) ^ 1][ld] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdA, offA[ld], ka, 0)); \
+                        else                                                                                           \
+                            xb[(PAR) ^ 1][(ld - TMB) / NL][(ld - TMB) % NL] = __builtin_bit_cast(                      \
+                                f32x4, __builtin_amdgcn_raw_buffer_load_b128(srdB, offB[(ld - TMB) / NL][(ld - TMB) % NL], kb, 0)); \
+                        __builtin_amdgcn_sched_barrier(0);                                                             \
+                    }                                                                                                  \
+                }                                                                                                      \
+                __builtin_amdgcn_sched_barrier(0);                                                                     \
+            }                                                                                                          \
+        }
+        for (int c = c_lo; c < c_lo + CPS && c < total_chunks; c += 2) {
+            GD_KN_CHUNK(0, c);
+            GD_KN_CHUNK(1, c + 1);
+        }
+#undef GD_KN_CHUNK
+        // ---- epilogue: the partial tile into slab `split`; lane (r, q) owns columns n0 + 64 l + 4 r .. + 3 of rows 16 a + 4 q + t ----
+        float* __restrict__ slab = g.C + (int64_t)split * g.slab_stride;
+#pragma unroll
+        for (int a = 0; a < TMB; ++a)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int m = m0 + 16 * a + 4 * q + t;
+                if (m >= g.M) continue;
+#pragma unroll
+                for (int l = 0; l < NL; ++l) {
+                    const int n = n0 + 64 * l + 4 * r;
+                    const f32x4 v = {acc[a][l][0][t], acc[a][l][1][t], acc[a][l][2][t], acc[a][l][3][t]};
+                    if (n + 3 < g.ldc) {  // (slab rows are round4(N) wide: a whole group or nothing)
+                        *reinterpret_cast<f32x4*>(slab + (int64_t)m * g.ldc + n) = v;
+                    } else {
+                        for (int e = 0; e < 4; ++e)
+                            if (n + e < g.N) slab[(int64_t)m * g.ldc + n + e] = v[e];
+                    }
+                }
+            }
+    }
+}
+
 template <int NB>
 int dr_fat_go(const DrArgs& d, int epi, int n_cu, hipStream_t s) {
     const size_t lds = (size_t)4 * 2 * NB * 256 * sizeof(float);
@@ -1629,6 +1763,23 @@ static int dr_cu_count() {
     return n_cu;
 }
 
+// dr_kn_kernel: 80 x 128 tiles, one (split, tile) task per wave slot (4 per CU): as many splits as fill the slots once -- or 0 when the
+// product is not one the kernel takes (rows that do not tile by 80 within 12 %, a reduction too short to split, few slots).
+int gd_dr_kn_splits(int M, int N, int K) {
+    static const int on_env = getenv("GDMCF_GEMM_DR") ? atoi(getenv("GDMCF_GEMM_DR")) : 49;
+    if (!(on_env & 32) || M < 16 || N < 64 || K < 4096) return 0;
+    const long tiles = (long)gd_cdiv(M, 80) * gd_cdiv(N, 128);
+    if ((long)gd_cdiv(M, 80) * 80 * 100 > (long)M * 112) return 0;  // 80-row tiles: at most 12 % padding
+    if ((long)gd_cdiv(N, 128) * 128 * 100 > (long)N * 112) return 0;
+    const long slots = 4L * dr_cu_count();
+    if (tiles > slots) return 0;
+    int splits = (int)(slots / tiles);
+    const int total_chunks = gd_cdiv(K, 16);
+    if (splits > total_chunks / 8) splits = total_chunks / 8;  // at least eight chunks per split
+    if (splits < 2 || splits > 64) return splits > 64 ? 64 : 0;
+    return splits;
+}
+
 // Ticket-counter set of one launch.  Two launches that overlap in time -- the two weight gradients of a step on two streams
 // (GDMCF_GEMM_SIDE=1), two host threads, a replayed graph beside an eager step -- must not draw from the same counters, or each
 // computes only a subset of its tiles.  The set therefore belongs to the LAUNCH, not to the call site: eager launches rotate
@@ -1654,12 +1805,12 @@ static int dr_ticket_slot(hipStream_t s) {
 // Returns GD_DR_NOT_TAKEN when the product is not one this file handles (the caller falls back to the LDS-tiled kernels).
 int g_gd_dr_force = -1;  // tools/gemm_probe.hip: overrides GDMCF_GEMM_DR per call when >= 0
 int gd_gemm_dr_launch(int layA, int layB, int epi, GdGemm& g, hipStream_t s) {
-    static const int on_env = getenv("GDMCF_GEMM_DR") ? atoi(getenv("GDMCF_GEMM_DR")) : 17;
+    static const int on_env = getenv("GDMCF_GEMM_DR") ? atoi(getenv("GDMCF_GEMM_DR")) : 49;
     const int on = g_gd_dr_force >= 0 ? g_gd_dr_force : on_env;  // bit 0: weight gradients (default), bit 1: forward
     // products (opt-in: measured SLOWER than the LDS-tiled kernels -- 0.279 vs 0.270 ms for the Yelp loss product: a K-contiguous
     // operand costs 16 half-line L1 accesses per load instead of 8 full lines, TCP accesses x3.6, 20 % of the wave cycles waiting)
     if (!on || g.bf16) return GD_DR_NOT_TAKEN;
-    if (g.accumulate || g.splits > 1 || g.C16) return GD_DR_NOT_TAKEN;
+    if (g.accumulate || g.C16 || (g.splits > 1 && epi != GD_EPI_SLAB)) return GD_DR_NOT_TAKEN;  // (slabs: dr_kn_kernel sets its own split count)
     static const int stagger = getenv("GDMCF_DR_STAGGER") ? atoi(getenv("GDMCF_DR_STAGGER")) : 3;
     const int64_t lim = (int64_t)1 << 32;  // 32-bit byte offsets inside every matrix
     DrArgs d = {};
@@ -1723,6 +1874,32 @@ int gd_gemm_dr_launch(int layA, int layB, int epi, GdGemm& g, hipStream_t s) {
         t_gd_last_gemm = epi == GD_EPI_ADAMW ? 3 : 2;
         if (bias_db) g.out2 = nullptr;  // taken: the caller skips its column-sum pass
         return gd_launch_status("gemm_dr");
+    }
+    // bit 5 (default on): the input gradient, split-K slabs, both operands straight into registers (dr_kn_kernel)
+    if ((on & 32) && layA == GD_LAY_KC && layB == GD_LAY_MC && epi == GD_EPI_SLAB) {
+        const int splits = gd_dr_kn_splits(g.M, g.N, g.K);
+        const size_t need = (size_t)splits * g.M * g.ldc * sizeof(float);
+        if (splits > 0 && g.ldc >= g.N && (g.ldc & 3) == 0 && g.ws_cap >= need && g.slab_stride >= (int64_t)g.M * g.ldc &&
+            (int64_t)g.M * g.lda * 4 < ((int64_t)1 << 31) && (int64_t)g.K * g.ldb * 4 < ((int64_t)1 << 31) && g.lda >= g.K && g.ldb >= g.N &&
+            (reinterpret_cast<uintptr_t>(g.B) & 15) == 0 && (g.ldb & 3) == 0 && (reinterpret_cast<uintptr_t>(g.C) & 15) == 0) {
+            const int n_cu = dr_cu_count();
+            const int total_chunks = gd_cdiv(g.K, 16);
+            const int cps = (gd_cdiv(total_chunks, splits) + 1) & ~1;  // chunks per split, even (the loop runs them in pairs)
+            d.tiles_m = gd_cdiv(g.M, 80);
+            d.tiles_n = gd_cdiv(g.N, 128);
+            d.ksp = cps;
+            g.splits = gd_cdiv(total_chunks, cps);
+            g.kchunk = cps * 16;
+            g.tiles_m = d.tiles_m;
+            g.tiles_n = d.tiles_n;
+            d.g = g;
+            {
+                GdProfScope prof(g.prof_tag, 2.0 * g.M * g.N * g.K, s);
+                hipLaunchKernelGGL((dr_kn_kernel<2>), dim3(n_cu), dim3(256), 0, s, d);
+            }
+            t_gd_last_gemm = 5;
+            return gd_launch_status("gemm_dr_kn");
+        }
     }
     // bit 4 (default on): the output layer with a fused epilogue as ONE FAT TILE PER WAVE (dr_fat_kernel)
     if ((on & 16) && layA == GD_LAY_KC && layB == GD_LAY_KC && (epi == GD_EPI_LOSS || epi == GD_EPI_POST)) {

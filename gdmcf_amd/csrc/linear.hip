@@ -120,7 +120,11 @@ size_t gdmcf_linear_ws_bytes(int M, int N, int K) {
     for (int prec = GDMCF_GEMM_F32; prec <= GDMCF_GEMM_F32X3; ++prec) {  // the caller may switch precision later
         const int cf = pick_class(M, N, false, prec), cb = pick_class(M, K, false, prec);
         const size_t f = (size_t)pick_splits(M, N, K, cf, prec) * M * round4(N);
-        const size_t b = (size_t)pick_splits(M, K, N, cb, prec) * M * round4(K);
+        size_t b = (size_t)pick_splits(M, K, N, cb, prec) * M * round4(K);
+        if (prec == GDMCF_GEMM_F32) {  // the input gradient on dr_kn_kernel: one (split, tile) task per wave slot
+            const size_t bk = (size_t)gd_dr_kn_splits(M, K, N) * M * round4(K);
+            b = b > bk ? b : bk;
+        }
         need = need > f ? need : f;
         need = need > b ? need : b;
     }
@@ -248,6 +252,7 @@ int gdmcf_linear_bwd_input_f32(const float* dZ, int64_t lddz, const float* W, in
     g.A = dZ; g.lda = lddz; g.B = W; g.ldb = ldw; g.M = M; g.N = K; g.K = N;
     g.m_fastest = gd_cdiv(M, gd_gemm_tile_m(cls)) <= gd_cdiv(K, gd_gemm_tile_n(cls));
     g.splits = splits; g.C = (float*)ws; g.ldc = lds_; g.slab_stride = (int64_t)M * lds_; g.prof_tag = 4;
+    g.ws_cap = ws_bytes;  // (the register-streaming kernel splits further when the workspace allows: gdmcf_linear_ws_bytes sizes for it)
     attach_shadows(g, GD_LAY_KC, GD_LAY_MC);
     int rc = gd_gemm_launch(GD_LAY_KC, GD_LAY_MC, GD_EPI_SLAB, cls, g, s);
     if (rc) return rc;

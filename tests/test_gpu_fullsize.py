@@ -298,23 +298,26 @@ def test_output_layer_loss_product_on_the_opt_in_hybrid_kernel(tmp_path):
 
 
 @pytest.mark.parametrize("which,B,N,K", [("fwd", 400, 1000, 34405), ("fwd", 400, 1000, 94959), ("dinput", 400, 34395, 1000),
-                                         ("dinput", 400, 94949, 1000), ("fwd", 200, 999, 20003), ("loss_lds", 400, 34395, 1000),
-                                         ("loss_lds", 400, 94949, 1000)])
+                                         ("dinput", 400, 94949, 1000), ("dinput_lds", 400, 34395, 1000), ("dinput", 230, 20003, 1000),
+                                         ("fwd", 200, 999, 20003), ("loss_lds", 400, 34395, 1000), ("loss_lds", 400, 94949, 1000)])
 def test_lds_tiled_products_every_element_against_float64_twenty_launches(which, B, N, K, tmp_path):
     """The LDS-tiled f32 kernel (csrc/gemm_f32.hip) keeps two tiles in flight in registers that inline-asm loads write and
     hand-counted s_waitcnt guard; its waits are chosen by the same predicate as its loads, which the build's path-insensitive
     lint (build.py:lint_vmcnt) cannot follow -- so its guard is THIS test: the first-layer forward product
     (gdmcf_linear_fwd_f32: split-K slabs + reducer, bias, tanh; reference models/DNN.py:79-81), the input-gradient product
-    (gdmcf_linear_bwd_input_f32; main.py:350) and the fused-loss product ON THE LDS-TILED KERNEL (GDMCF_GEMM_DR=1: the fat-tile
-    kernel that serves it by default since round 4 is switched off) at the Yelp and Amazon-Book shapes and a ragged one: EVERY
+    (gdmcf_linear_bwd_input_f32; main.py:350: on dr_kn_kernel, both operands straight into registers, by default -- a ragged shape
+    with row / column / K tails included -- and on the LDS-tiled kernel with GDMCF_GEMM_DR=17) and the fused-loss product ON THE
+    LDS-TILED KERNEL (GDMCF_GEMM_DR=1: the fat-tile kernel that serves it by default since round 4 is switched off) at the Yelp and Amazon-Book shapes and a ragged one: EVERY
     element against float64, then twenty more launches bit for bit (a register consumed before its load has landed shows up as
     a few elements off in SOME launches)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "lds_check.py"
-    script.write_text(_LDS_SCRIPT.format(root=root, which=which, B=B, N=N, K=K))
+    script.write_text(_LDS_SCRIPT.format(root=root, which=which.replace("_lds", "") if which.startswith("dinput") else which, B=B, N=N, K=K))
     env = dict(os.environ, GDMCF_GEMM_DR="1") if which == "loss_lds" else dict(os.environ)
+    if which == "dinput_lds":  # the input gradient ON THE LDS-TILED KERNEL (dr_kn_kernel, its default since round 4, switched off)
+        env["GDMCF_GEMM_DR"] = "17"
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "LDS-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
 
@@ -348,6 +351,10 @@ elif which == "dinput":   # dA[B, K] = rs * (dZ[B, N] W[N, K]) * (1 - act^2)
         _lib.check(lib.gdmcf_linear_bwd_input_f32(dZ.data_ptr(), N, W.data_ptr(), K, rs.data_ptr(), act.data_ptr(), K, 1, B, N, K,
                                                   out.data_ptr(), K, ws.data_ptr(), ws.numel(), st))
         torch.cuda.synchronize()
+        # since the end of round 4 the register-streaming kernel dr_kn_kernel serves this product (5); GDMCF_GEMM_DR=17 -> LDS-tiled (1)
+        import os
+        want = 1 if os.environ.get("GDMCF_GEMM_DR") == "17" else 5
+        assert lib.gdmcf_debug_last_gemm() == want, (lib.gdmcf_debug_last_gemm(), want)
         return out
     ref = rs.double()[:, None] * (dZ.double() @ W.double()) * (1 - act.double() ** 2)
     tol = 2e-5

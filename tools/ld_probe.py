@@ -6,6 +6,8 @@ import sys, os
 import torch
 sys.path.insert(0, ".")
 from gdmcf_amd import _lib
+if os.environ.get("GDMCF_PROBE_LIB"):  # a probe build (tools/build_variant.sh)
+    _lib.LIB_PATH = os.path.abspath(os.environ["GDMCF_PROBE_LIB"])
 lib = _lib.load()
 dev = "cuda:0"
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 60
