@@ -41,6 +41,7 @@ _SIGNATURES = {
     "gdmcf_bf16_shadow_sync": (c_int, [P, c_int64, P]),
     "gdmcf_linear_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gdmcf_linear_fwd_f32": (c_int, [P, c_int64, P, c_int64, P, c_int, c_int, c_int, c_int, P, c_int64, P, c_size_t, P]),
+    "gdmcf_linear_fwd_wt_f32": (c_int, [P, c_int64, P, c_int64, P, c_int, c_int, c_int, c_int, P, c_int64, P, c_size_t, P]),
     "gdmcf_loss_tiles": (c_int, [c_int]),
     "gdmcf_linear_loss_fwd_f32": (c_int, [P, c_int64, P, c_int64, P, P, c_int64, P, c_int, c_int, c_int, P, c_int64, P,
                                           c_int64, P, P, P]),

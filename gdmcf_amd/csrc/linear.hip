@@ -119,7 +119,11 @@ size_t gdmcf_linear_ws_bytes(int M, int N, int K) {
     size_t need = 0;
     for (int prec = GDMCF_GEMM_F32; prec <= GDMCF_GEMM_F32X3; ++prec) {  // the caller may switch precision later
         const int cf = pick_class(M, N, false, prec), cb = pick_class(M, K, false, prec);
-        const size_t f = (size_t)pick_splits(M, N, K, cf, prec) * M * round4(N);
+        size_t f = (size_t)pick_splits(M, N, K, cf, prec) * M * round4(N);
+        if (prec == GDMCF_GEMM_F32) {  // gdmcf_linear_fwd_wt_f32 on dr_kn_kernel
+            const size_t fk = (size_t)gd_dr_kn_splits(M, N, K) * M * round4(N);
+            f = f > fk ? f : fk;
+        }
         size_t b = (size_t)pick_splits(M, K, N, cb, prec) * M * round4(K);
         if (prec == GDMCF_GEMM_F32) {  // the input gradient on dr_kn_kernel: one (split, tile) task per wave slot
             const size_t bk = (size_t)gd_dr_kn_splits(M, K, N) * M * round4(K);
@@ -164,6 +168,35 @@ int gdmcf_linear_fwd_f32(const float* A, int64_t lda, const float* W, int64_t ld
     const int real_splits = gd_cdiv(K, g.kchunk);
     return gd_splitk_reduce((const float*)ws, g.slab_stride, real_splits, lds_, M, N, 0, bias, nullptr, nullptr, 0,
                             act, C, ldc, s);
+}
+
+int gdmcf_linear_fwd_wt_f32(const float* A, int64_t lda, const float* Wt, int64_t ldwt, const float* bias, int act, int M, int N,
+                            int K, float* C, int64_t ldc, void* ws, size_t ws_bytes, void* stream) {
+    GD_CHECK_SHAPE(M > 0 && N > 0 && K > 0 && lda >= K && ldwt >= N && ldc >= N, "linear_fwd_wt: bad shape");
+    GD_CHECK_ARG(act == 0 || act == 1, "linear_fwd_wt: bad activation");
+    if (t_gemm_prec != GDMCF_GEMM_F32) {
+        gdmcf_set_error("linear_fwd_wt: float32 GEMM mode only (the bf16 / f32x3 modes keep the weight in its own orientation)");
+        return GDMCF_E_UNSUPPORTED;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    // the product of the input gradient, with a forward reducer: [M x N] = A[M x K] * Wt[K x N], split over K
+    const int cls = pick_class(M, N, false, t_gemm_prec);
+    const int splits = pick_splits(M, N, K, cls, t_gemm_prec);
+    const int64_t lds_ = round4(N);
+    const size_t need = (size_t)splits * M * lds_ * sizeof(float);
+    if (ws == nullptr || ws_bytes < need) {
+        gdmcf_set_error("linear_fwd_wt: workspace %zu < %zu bytes", ws_bytes, need);
+        return GDMCF_E_WORKSPACE;
+    }
+    GdGemm g = {};
+    g.A = A; g.lda = lda; g.B = Wt; g.ldb = ldwt; g.M = M; g.N = N; g.K = K;
+    g.m_fastest = gd_cdiv(M, gd_gemm_tile_m(cls)) <= gd_cdiv(N, gd_gemm_tile_n(cls));
+    g.splits = splits; g.C = (float*)ws; g.ldc = lds_; g.slab_stride = (int64_t)M * lds_; g.prof_tag = 1;
+    g.ws_cap = ws_bytes;
+    int rc = gd_gemm_launch(GD_LAY_KC, GD_LAY_MC, GD_EPI_SLAB, cls, g, s);
+    if (rc) return rc;
+    const int real_splits = gd_cdiv(K, g.kchunk);
+    return gd_splitk_reduce((const float*)ws, g.slab_stride, real_splits, lds_, M, N, 0, bias, nullptr, nullptr, 0, act, C, ldc, s);
 }
 
 int gdmcf_linear_loss_fwd_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,

@@ -183,6 +183,13 @@ size_t gdmcf_linear_ws_bytes(int M, int N, int K);
 int gdmcf_linear_fwd_f32(const float* A, int64_t lda, const float* W, int64_t ldw,
                          const float* bias, int act, int M, int N, int K, float* C, int64_t ldc,
                          void* ws, size_t ws_bytes, void* stream);
+/* The same layer with the weight given TRANSPOSED: Wt[K, N] row-major (ldwt >= N), out = act(A @ Wt + bias).  For loops over
+ * FROZEN weights (the reverse-diffusion loop of evaluation, gaussian_diffusion.py:161-220 over models/DNN.py:79-81): with a
+ * K-contiguous A and an N-contiguous Wt the product runs on the register-streaming kernel of the input gradient (both operands
+ * straight into the MFMA layout, no LDS).  The caller keeps Wt equal to W^T; float32 GEMM mode only; ws as gdmcf_linear_ws_bytes. */
+int gdmcf_linear_fwd_wt_f32(const float* A, int64_t lda, const float* Wt, int64_t ldwt,
+                            const float* bias, int act, int M, int N, int K, float* C, int64_t ldc,
+                            void* ws, size_t ws_bytes, void* stream);
 /* Last layer fused with the per-row diffusion loss (gaussian_diffusion.py:335 mean_flat):
  *   out = A @ W^T + bias ;  diff[m,n] = alpha[m]*out[m,n] - target[m,n]   (alpha NULL -> 1)
  *   rowsum[m] = sum_n diff[m,n]^2  (deterministic two-stage reduction)

@@ -299,6 +299,7 @@ def test_output_layer_loss_product_on_the_opt_in_hybrid_kernel(tmp_path):
 
 @pytest.mark.parametrize("which,B,N,K", [("fwd", 400, 1000, 34405), ("fwd", 400, 1000, 94959), ("dinput", 400, 34395, 1000),
                                          ("dinput", 400, 94949, 1000), ("dinput_lds", 400, 34395, 1000), ("dinput", 230, 20003, 1000),
+                                         ("fwd_wt", 400, 1000, 34405), ("fwd_wt", 400, 1000, 94959), ("fwd_wt", 230, 1000, 20003),
                                          ("fwd", 200, 999, 20003), ("loss_lds", 400, 34395, 1000), ("loss_lds", 400, 94949, 1000)])
 def test_lds_tiled_products_every_element_against_float64_twenty_launches(which, B, N, K, tmp_path):
     """The LDS-tiled f32 kernel (csrc/gemm_f32.hip) keeps two tiles in flight in registers that inline-asm loads write and
@@ -339,6 +340,20 @@ if which == "fwd":        # C[B, N] = tanh(A[B, K] W[N, K]^T + b)
         _lib.check(lib.gdmcf_linear_fwd_f32(A.data_ptr(), K, W.data_ptr(), K, bias.data_ptr(), 1, B, N, K, out.data_ptr(), N,
                                             ws.data_ptr(), ws.numel(), st))
         torch.cuda.synchronize()
+        return out
+    ref = torch.tanh(A.double() @ W.double().t() + bias.double())
+    tol = 2e-5
+elif which == "fwd_wt":   # the same layer through the TRANSPOSED weight (gdmcf_linear_fwd_wt_f32: the reverse loop's hidden layer)
+    A = torch.randn(B, K, generator=g).to(dev); W = (torch.randn(N, K, generator=g) * 0.01).to(dev); bias = torch.randn(N, generator=g).to(dev)
+    ldn = (N + 31) // 32 * 32
+    Wt = torch.full((K, ldn), float("nan"), device=dev); Wt[:, :N] = W.t()
+    ws = torch.empty(max(int(lib.gdmcf_linear_ws_bytes(B, N, K)), 256), dtype=torch.uint8, device=dev)
+    def run():
+        out = torch.full((B, N), float("nan"), device=dev)
+        _lib.check(lib.gdmcf_linear_fwd_wt_f32(A.data_ptr(), K, Wt.data_ptr(), ldn, bias.data_ptr(), 1, B, N, K, out.data_ptr(), N,
+                                               ws.data_ptr(), ws.numel(), st))
+        torch.cuda.synchronize()
+        assert lib.gdmcf_debug_last_gemm() == 5, "dr_kn_kernel did not serve this product"
         return out
     ref = torch.tanh(A.double() @ W.double().t() + bias.double())
     tol = 2e-5
@@ -763,3 +778,44 @@ def test_first_layer_bias_gradient_from_the_ones_column_of_the_input_builder():
         torch.cuda.synchronize()
         hs.append(h[:, :H].clone())
     assert bool(torch.isfinite(hs[0]).all()) and torch.equal(hs[0], hs[1]) and torch.equal(hs[0], hs[2])
+
+
+def test_reverse_loop_through_cached_transposed_weights_follows_weight_updates():
+    """engine._transposed: the reverse-diffusion loop (reference gaussian_diffusion.py:161-220) runs its hidden layer through a
+    cached W^T (gdmcf_linear_fwd_wt_f32 -> dr_kn_kernel).  Yelp shape: predictions with the cache equal the plain path within
+    float32 summation order and give the same top-k lists; after a training step the cache must follow the new weights (version
+    check) -- compared with a model that never uses it."""
+    import scipy.sparse as sp
+    from gdmcf_amd.data_utils import DeviceCSR
+    from gdmcf_amd.parallel import DataParallelStep
+    dev = torch.device(DEV)
+    B, hid, T = 400, 1000, 5
+    indptr, indices, I = D.synth_csr("yelp", n_rows=B, seed=0)
+    dcsr = DeviceCSR(sp.csr_matrix((np.ones(len(indices), np.float32), indices, indptr), shape=(B, I)), dev)
+    x = torch.zeros(B, I, device=dev)
+    x[torch.as_tensor(np.repeat(np.arange(B), np.diff(indptr)), device=dev), torch.as_tensor(indices.astype(np.int64), device=dev)] = 1.0
+    torch.manual_seed(0)
+    model = gdmcf_amd.DNN([I, hid], [hid, I], 10, time_type="cat", norm=False).to(dev)
+    diffusion = gdmcf_amd.GaussianDiffusion(gdmcf_amd.ModelMeanType.START_X, "linear-var", 0.01, 0.001, 0.01, T, dev)
+    opt = gdmcf_amd.FusedAdamW(model.parameters(), lr=1e-3)
+    step = DataParallelStep(diffusion, model, opt)
+    noise0 = torch.randn(B, I, generator=torch.Generator().manual_seed(3)).to(dev)  # the same x_T for every prediction
+
+    def predict(cached):
+        model.eval()
+        model.engine._wt_on = cached
+        with torch.no_grad():
+            p = diffusion.p_sample(model, x, T, False, noise0=noise0)
+        torch.cuda.synchronize()
+        model.train()
+        return p
+
+    for round_ in range(2):
+        a, b = predict(True), predict(False)
+        assert model.engine._wt, "the transposed cache was not used"
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()), round_
+        assert torch.equal(a.topk(20, dim=1).indices, b.topk(20, dim=1).indices), round_
+        torch.manual_seed(5)
+        step(dcsr.batch(torch.arange(B, device=dev)), True)  # the weights move: the next prediction must see them
+        c = predict(True)
+        assert float((c - a).abs().max()) > 0.0
