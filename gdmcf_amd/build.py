@@ -292,9 +292,9 @@ def build(force=False, verbose=True):
                 if "Function Name:" in line:
                     name = line.split("Function Name:")[1].split()[0]
                 elif "VGPRs Spill:" in line and int(line.split("VGPRs Spill:")[1].split()[0]) > 0:
-                    # (dr_fat_kernel has no inline-asm loads: every wait in it is hipcc's own, a spilled register -- two lane
-                    # constants saved across its 512-register loop -- is reloaded like any other value)
-                    if "dr_fat_kernel" not in (name or ""):
+                    # (dr_fat_kernel and dr_kn_kernel have no inline-asm loads: every wait in them is hipcc's own, a spilled register
+                    # -- lane constants saved across their 512-register loops -- is reloaded like any other value)
+                    if "dr_fat_kernel" not in (name or "") and "dr_kn_kernel" not in (name or ""):
                         bad.append(name)
             if bad:
                 raise RuntimeError(f"{src}: register spills in {len(bad)} kernel(s) with uncounted asm loads, e.g. {bad[0]}")
