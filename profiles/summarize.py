@@ -75,6 +75,7 @@ import re
 TAG_RULES = [
     (r"^dr_tn_kernel<", "bwd_weight_gemm"),
     (r"^dr_tn_adamw_kernel<", "bwd_weight_gemm"),
+    (r"^dr_kn_kernel<", "bwd_input_gemm"),  # (also the reverse loop's hidden layer through the transposed weight)
     (r"^dr_fat_kernel<\d+, 2>$", "loss_fwd_gemm"),
     (r"^dr_fat_kernel<\d+, 3>$", "posterior_gemm"),
     (r"^dr_nt_kernel<.*, 2>$", "loss_fwd_gemm"),
