@@ -39,9 +39,9 @@ PEAK_F32_MATRIX_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_* = 64 FLOP/cl
 PEAK_BF16_MATRIX_TFLOPS = 2516.6  # dense bf16 MFMA = 16 x the f32 matrix rate (same guide)
 PEAK_HBM_GBPS = 8000.0
 TAGS = {1: "linear_fwd_gemm", 2: "loss_fwd_gemm", 3: "posterior_gemm", 4: "bwd_input_gemm", 5: "bwd_weight_gemm",
-        6: "adamw", 7: "prep_input", 8: "spmm_csr", 9: "topk", 10: "onehot_noise"}
+        6: "adamw", 7: "prep_input", 8: "spmm_csr", 9: "topk", 10: "onehot_noise", 11: "randn"}
 GEMM_TAGS = (1, 2, 3, 4, 5)
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_hbm_traffic.json")
 
 
 def measured_traffic(kernel_tag, workload, gemm_dtype="f32"):

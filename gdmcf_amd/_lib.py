@@ -65,6 +65,8 @@ _SIGNATURES = {
     "gdmcf_scatter_add_rows_f32": (c_int, [P, c_int64, P, c_int, c_int, P, c_int64, P]),
     "gdmcf_dp_pack_f64": (c_int, [P, P, c_int, P, P, c_int, c_int, c_int, P, P]),
     "gdmcf_dp_unpack_f64": (c_int, [P, P, P, c_int, c_int, c_int, P, P, P]),
+    "gdmcf_randn_f32": (c_int, [P, c_int64, c_int, c_int, c_int, c_uint64, c_uint64, P]),
+    "gdmcf_eps_target_f32": (c_int, [P, c_int64, P, c_int64, P, c_int64, P, P, P, c_int, c_int, c_int, P, c_int64, P, P, P]),
     "gdmcf_sample_timesteps": (c_int, [P, P, c_int, c_int, c_int, c_double, c_uint64, c_uint64, P, P, P, P]),
     "gdmcf_adamw_f32": (c_int, [P, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_int, c_float, P]),
     "gdmcf_adamw_bf16s_f32": (c_int, [P, P, c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_int, c_float, P]),
@@ -149,6 +151,19 @@ def shadow_info(data_ptr):
 def stream_ptr():
     import torch
     return torch.cuda.current_stream().cuda_stream
+
+
+def philox_randn(shape, device, seed, offset, stream_id=4, out=None):
+    """[rows, cols] float32 N(0,1) drawn by gdmcf_randn_f32 (Philox4x32-10, Box-Muller) -- the device draw that stands where
+    the reference calls th.randn_like (gaussian_diffusion.py:328-331, :210-217).  No CPU path: `device` must be a GPU."""
+    import torch
+    rows, cols = int(shape[0]), int(shape[1])
+    if out is None:
+        out = torch.empty(rows, cols, dtype=torch.float32, device=device)
+    require_gpu(out, "philox_randn output")
+    check(load().gdmcf_randn_f32(out.data_ptr(), out.stride(0), rows, cols, int(stream_id), int(seed) & (2 ** 64 - 1),
+                                 int(offset) & (2 ** 64 - 1), stream_ptr()))
+    return out
 
 
 def schedule_tables(kind, noise_scale, noise_min, noise_max, steps, beta_fixed=True):

@@ -18,8 +18,11 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
     constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
-        const uint32_t hi0 = __umulhi(M0, c.x), lo0 = M0 * c.x;
-        const uint32_t hi1 = __umulhi(M1, c.z), lo1 = M1 * c.z;
+        // (one 32 x 32 -> 64 product per word pair: v_mad_u64_u32 where hipcc picks it -- half the quarter-rate multiplies of a
+        // v_mul_lo_u32 / v_mul_hi_u32 pair)
+        const uint64_t p0 = (uint64_t)M0 * (uint64_t)c.x, p1 = (uint64_t)M1 * (uint64_t)c.z;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
         k.x += W0;
         k.y += W1;
@@ -57,7 +60,8 @@ struct PrepArgs {
     const uint8_t* keep;
     int64_t ldkeep;
     float drop_scale;  // 1/(1-p)
-    uint32_t keep_thresh;  // Philox: keep iff u < thresh
+    uint32_t keep_thresh;  // Philox: keep iff (16-bit uniform) < keep_thresh = round((1 - p) * 65536): the keep probability is
+                           // quantised to 2^-16 (exact for p = 0.5); ONE block gives the 8 uniforms of two column groups
     uint64_t seed, offset;
     const GdStepState* step_state;  // graph mode: the Philox offset is read from the device (NULL: `offset`)
     const float* rownorm;  // [B] L2 norms of x_t rows (normalize) or NULL
@@ -80,7 +84,10 @@ struct PrepArgs {
     int64_t ldbits;
 };
 
-__device__ __forceinline__ float temb_value(float t, int f, int E) {
+// (out of line: a few hundred threads of a launch evaluate it, but inlined its libm sinusoids -- Payne-Hanek reductions and all --
+// were two thirds of the input builder's 8 500 lines of ISA and cost the hot loop ~3.5 us of instruction fetch,
+// profiles/r04_prep_input_ablation.txt)
+__device__ __noinline__ float temb_value(float t, int f, int E) {
     // reference models/DNN.py:1817-1825: [cos(t*freqs), sin(t*freqs), (0 if E odd)]
     const int half = E / 2;
     if (f >= 2 * half) return 0.f;
@@ -91,14 +98,15 @@ __device__ __forceinline__ float temb_value(float t, int f, int E) {
 }
 
 // x_t for 4 consecutive columns of one row (shared by the row-norm pass and the main pass)
+template <bool FULL = false>  // FULL: the caller knows col + 3 < I (no per-element bounds checks)
 __device__ __forceinline__ void xt4(const PrepArgs& a, int b, int col, float ca, float cb, float (&v)[4],
                                     const uint32_t* bm = nullptr, int bm_col0 = 0) {
     const float* xr = a.x + (int64_t)b * a.ldx;
     if (bm) {  // CSR source: the workgroup's span as a bitmap in LDS (col is a multiple of 4: one word holds all four)
         const uint32_t w = bm[(col - bm_col0) >> 5] >> ((col - bm_col0) & 31);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (col + j < a.I && ((w >> j) & 1u)) ? 1.f : 0.f;
-    } else if (col + 3 < a.I) {
+        for (int j = 0; j < 4; ++j) v[j] = ((FULL || col + j < a.I) && ((w >> j) & 1u)) ? 1.f : 0.f;
+    } else if (FULL || col + 3 < a.I) {
         // one 16-byte load (rows of the dense batch are only 4-byte aligned when I is odd: gfx950 takes that)
         typedef f32x4 f32x4_u4 __attribute__((aligned(4)));
         const f32x4 t4 = *reinterpret_cast<const f32x4_u4*>(xr + col);
@@ -111,7 +119,7 @@ __device__ __forceinline__ void xt4(const PrepArgs& a, int b, int col, float ca,
         float nz[4] = {0.f, 0.f, 0.f, 0.f};
         if (a.noise_mode == 1) {
             const float* nr = a.noise + (int64_t)b * a.ldn;
-            if (col + 3 < a.I) {
+            if (FULL || col + 3 < a.I) {
                 typedef f32x4 f32x4_u4 __attribute__((aligned(4)));
                 const f32x4 t4 = *reinterpret_cast<const f32x4_u4*>(nr + col);
                 nz[0] = t4.x; nz[1] = t4.y; nz[2] = t4.z; nz[3] = t4.w;
@@ -200,17 +208,23 @@ __global__ __launch_bounds__(256) void prep_input_kernel(PrepArgs a) {
         if ((int)threadIdx.x < a.E) s_temb[threadIdx.x] = temb_value((float)t, threadIdx.x, a.E);
         __syncthreads();
     }
+    const uint2 key = make_uint2((uint32_t)a.seed, (uint32_t)(a.seed >> 32));
+    const int col_base = (blockIdx.x * (256 * PREP_G) + threadIdx.x) * 4;  // group u of this thread: col_base + 1024 u
+    // ---- the hot path: whole groups of four item columns (all but the last group or two of a row) ----
+    uint4 dr = make_uint4(0u, 0u, 0u, 0u);  // dropout uniforms of a PAIR of column groups (u, u + 1): 16 bits per element
 #pragma unroll
     for (int u = 0; u < PREP_G; ++u) {
-    const int col = (blockIdx.x * (256 * PREP_G) + u * 256 + threadIdx.x) * 4;
-    if (col >= a.ldxin) return;
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
-    if (col < a.I) {
-        xt4(a, b, col, ca, cb, v, bm, bm_col0);
+        const int col = col_base + u * 1024;
+        if (a.drop_mode == 2 && (u & 1) == 0 && col < a.I)
+            dr = philox4x32_10(make_uint4((uint32_t)(col >> 2), (uint32_t)b, 1u, (uint32_t)a.offset), key);
+        if (col + 3 >= a.I) continue;  // (the tail pass below)
+        const int dsh = 16 * (u & 1);
+        const uint32_t du[4] = {(dr.x >> dsh) & 0xFFFFu, (dr.y >> dsh) & 0xFFFFu, (dr.z >> dsh) & 0xFFFFu, (dr.w >> dsh) & 0xFFFFu};
+        float v[4];
+        xt4<true>(a, b, col, ca, cb, v, bm, bm_col0);
         if (a.xt_out) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (col + j < a.I) a.xt_out[(int64_t)b * a.ldxt + col + j] = v[j];
+            for (int j = 0; j < 4; ++j) a.xt_out[(int64_t)b * a.ldxt + col + j] = v[j];
         }
         if (a.rownorm) {
             const float dn = fmaxf(a.rownorm[b], 1e-12f);
@@ -218,49 +232,73 @@ __global__ __launch_bounds__(256) void prep_input_kernel(PrepArgs a) {
             for (int j = 0; j < 4; ++j) v[j] = v[j] / dn;
         }
         if (a.drop_mode == 1) {
-            const uint8_t* kr = a.keep + (int64_t)b * a.ldkeep;
+            const uint8_t* kr = a.keep + (int64_t)b * a.ldkeep + col;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (col + j < a.I) v[j] = kr[col + j] ? v[j] * a.drop_scale : 0.f;
+            for (int j = 0; j < 4; ++j) v[j] = kr[j] ? v[j] * a.drop_scale : 0.f;
         } else if (a.drop_mode == 2) {
-            const uint4 r = philox4x32_10(make_uint4((uint32_t)(col >> 2), (uint32_t)b, 1u, (uint32_t)a.offset),
-                                          make_uint2((uint32_t)a.seed, (uint32_t)(a.seed >> 32)));
-            const uint32_t u[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = (u[j] < a.keep_thresh) ? v[j] * a.drop_scale : 0.f;
+            for (int j = 0; j < 4; ++j) v[j] = (du[j] < a.keep_thresh) ? v[j] * a.drop_scale : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(a.xin + (int64_t)b * a.ldxin + col) = f32x4{v[0], v[1], v[2], v[3]};
+        if (a.xin16 && col < a.ldxin16) {
+            const uint2 w = make_uint2(gd_bf16_bits(v[0]) | ((unsigned)gd_bf16_bits(v[1]) << 16),
+                                       gd_bf16_bits(v[2]) | ((unsigned)gd_bf16_bits(v[3]) << 16));
+            *reinterpret_cast<uint2*>(a.xin16 + (int64_t)b * a.ldxin16 + col) = w;
         }
     }
-    // timestep-embedding columns [I, I+E) and zero padding up to ldxin
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int i = col + j;
-        if (i >= a.I) {
-            float e = 0.f;
-            if (i < a.I + a.E) {
-                const int eo = i - a.I;
-                e = a.emb_b[eo];
-                if (has_emb) {
-                    for (int f = 0; f < a.E; ++f) e += a.emb_w[eo * a.E + f] * s_temb[f];
-                    if (a.temb_out) a.temb_out[(int64_t)b * a.E + eo] = s_temb[eo];
-                } else {
-                    for (int f = 0; f < a.E; ++f) e += a.emb_w[eo * a.E + f] * temb_value((float)t, f, a.E);
-                    if (a.temb_out) a.temb_out[(int64_t)b * a.E + eo] = temb_value((float)t, eo, a.E);
-                }
+    // ---- the tail pass: the row's last (ragged) item group, the timestep-embedding columns [I, I+E) and the zero padding up to
+    // ldxin -- a few dozen groups of a row, ONE rolled instance of the code (unrolled beside the hot path it was most of the
+    // kernel's 8 500 lines of ISA: ~3.5 us of instruction fetch, profiles/r04_prep_input_ablation.txt) ----
+#pragma unroll 1
+    for (int u = 0; u < PREP_G; ++u) {
+        const int col = col_base + u * 1024;
+        if (col + 3 < a.I || col >= a.ldxin) continue;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (col < a.I) {
+            xt4(a, b, col, ca, cb, v, bm, bm_col0);
+            if (a.xt_out) {
+                for (int j = 0; j < 4; ++j)
+                    if (col + j < a.I) a.xt_out[(int64_t)b * a.ldxt + col + j] = v[j];
             }
-            v[j] = e;
+            if (a.rownorm) {
+                const float dn = fmaxf(a.rownorm[b], 1e-12f);
+                for (int j = 0; j < 4; ++j) v[j] = v[j] / dn;
+            }
+            if (a.drop_mode == 1) {
+                const uint8_t* kr = a.keep + (int64_t)b * a.ldkeep;
+                for (int j = 0; j < 4; ++j)
+                    if (col + j < a.I) v[j] = kr[col + j] ? v[j] * a.drop_scale : 0.f;
+            } else if (a.drop_mode == 2) {  // the pair's block again (same counter as in the hot path: group u & ~1 of this thread)
+                const uint4 d2 = philox4x32_10(make_uint4((uint32_t)((col - (u & 1) * 1024) >> 2), (uint32_t)b, 1u, (uint32_t)a.offset), key);
+                const int dsh = 16 * (u & 1);
+                const uint32_t du[4] = {(d2.x >> dsh) & 0xFFFFu, (d2.y >> dsh) & 0xFFFFu, (d2.z >> dsh) & 0xFFFFu, (d2.w >> dsh) & 0xFFFFu};
+                for (int j = 0; j < 4; ++j) v[j] = (du[j] < a.keep_thresh) ? v[j] * a.drop_scale : 0.f;
+            }
         }
-    }
-    *reinterpret_cast<f32x4*>(a.xin + (int64_t)b * a.ldxin + col) = f32x4{v[0], v[1], v[2], v[3]};
-    if (a.xin16 && col < a.ldxin16) {
-        const uint2 w = make_uint2(gd_bf16_bits(v[0]) | ((unsigned)gd_bf16_bits(v[1]) << 16),
-                                   gd_bf16_bits(v[2]) | ((unsigned)gd_bf16_bits(v[3]) << 16));
-        *reinterpret_cast<uint2*>(a.xin16 + (int64_t)b * a.ldxin16 + col) = w;
-    }
-    // column I + E of the float32 matrix (the first padding column, when there is one) holds 1: as one more column of the first
-    // layer's weight-gradient product's operand it makes that layer's bias gradient a column of the product
-    // (gdmcf_linear_bwd_weight_f32, a_scale_col).  The bf16 shadow keeps its zero there.  (Same thread, same address, program order.)
-    const int oc = a.I + a.E;
-    if (oc < a.ldxin && col <= oc && oc < col + 4) a.xin[(int64_t)b * a.ldxin + oc] = 1.f;
+        for (int j = 0; j < 4; ++j) {
+            const int i = col + j;
+            if (i >= a.I) {
+                float e = 0.f;
+                if (i < a.I + a.E) {
+                    const int eo = i - a.I;
+                    e = a.emb_b[eo];
+                    for (int f = 0; f < a.E; ++f) e += a.emb_w[eo * a.E + f] * (has_emb ? s_temb[f] : temb_value((float)t, f, a.E));
+                    if (a.temb_out) a.temb_out[(int64_t)b * a.E + eo] = has_emb ? s_temb[eo] : temb_value((float)t, eo, a.E);
+                }
+                v[j] = e;
+            }
+        }
+        *reinterpret_cast<f32x4*>(a.xin + (int64_t)b * a.ldxin + col) = f32x4{v[0], v[1], v[2], v[3]};
+        if (a.xin16 && col < a.ldxin16) {
+            const uint2 w = make_uint2(gd_bf16_bits(v[0]) | ((unsigned)gd_bf16_bits(v[1]) << 16),
+                                       gd_bf16_bits(v[2]) | ((unsigned)gd_bf16_bits(v[3]) << 16));
+            *reinterpret_cast<uint2*>(a.xin16 + (int64_t)b * a.ldxin16 + col) = w;
+        }
+        // column I + E of the float32 matrix (the first padding column, when there is one) holds 1: as one more column of the first
+        // layer's weight-gradient product's operand it makes that layer's bias gradient a column of the product
+        // (gdmcf_linear_bwd_weight_f32, a_scale_col).  The bf16 shadow keeps its zero there.  (Same thread, same address, program order.)
+        const int oc = a.I + a.E;
+        if (oc < a.ldxin && col <= oc && oc < col + 4) a.xin[(int64_t)b * a.ldxin + oc] = 1.f;
     }
 }
 
@@ -336,6 +374,69 @@ __global__ __launch_bounds__(256) void onehot_noise_kernel(const float* __restri
     if (sampled_out)
         for (int j = 0; j < 4; ++j)
             if (i0 + j < I) sampled_out[(int64_t)b * ldso + i0 + j] = (uint8_t)((so >> (8 * j)) & 1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// N(0,1) fill (reference gaussian_diffusion.py:328-331 `noise = th.randn_like(x_start)` when eps is the TARGET and so has to
+// exist in memory, :210-217 the reverse loop's `noise = th.randn_like(x_t)`): the SAME normals the input builder draws in
+// place (noise_mode 2) for the same (seed, offset) when stream == 0 -- element (b, i) is normal i & 3 of the block with
+// counter (i >> 2, b, stream, offset), Box-Muller on (x, y) and (z, w) -- so a row written here and handed to the builder
+// as given noise reproduces the in-kernel stream bit for bit.  Four elements per thread, 16-byte stores where the row allows.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void randn_kernel(float* __restrict__ out, int64_t ld, int rows, int cols, uint32_t stream,
+                                                   uint64_t seed, uint64_t offset) {
+    const int b = blockIdx.y;
+    const uint2 key = make_uint2((uint32_t)seed, (uint32_t)(seed >> 32));
+    float* __restrict__ orow = out + (int64_t)b * ld;
+    typedef f32x4 f32x4_u4 __attribute__((aligned(4)));
+#pragma unroll
+    for (int u = 0; u < PREP_G; ++u) {
+        const int col = (blockIdx.x * (256 * PREP_G) + u * 256 + threadIdx.x) * 4;
+        if (col >= cols) return;
+        const uint4 r = philox4x32_10(make_uint4((uint32_t)(col >> 2), (uint32_t)b, stream, (uint32_t)offset), key);
+        float z[4];
+        box_muller(r.x, r.y, z[0], z[1]);
+        box_muller(r.z, r.w, z[2], z[3]);
+        if (col + 3 < cols) {
+            *reinterpret_cast<f32x4_u4*>(orow + col) = f32x4{z[0], z[1], z[2], z[3]};
+        } else {
+            for (int j = 0; j < 4; ++j)
+                if (col + j < cols) orow[col + j] = z[j];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Loss target of the eps parameterisation (reference gaussian_diffusion.py:344-348): target = eps, except rows with t == 0
+// (when the x0-likelihood term is on) whose target is r1[0]*x_t - x0 with weight r2[0] on the model output and twice the
+// divisor.  target may BE the noise buffer: then only the t == 0 rows are touched (a few KB instead of three [B, I] passes).
+// The product and the difference are rounded separately, as torch's mul and sub are.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void eps_target_kernel(const float* __restrict__ noise, int64_t ldn, const float* __restrict__ xt,
+                                                        int64_t ldxt, const float* __restrict__ x0, int64_t ldx0,
+                                                        const int64_t* __restrict__ ts, const float* __restrict__ r1,
+                                                        const float* __restrict__ r2, int t0_likelihood, int I,
+                                                        float* target, int64_t ldt, float* __restrict__ alpha,
+                                                        float* __restrict__ rowdiv) {
+    const int b = blockIdx.y;
+    const bool is0 = t0_likelihood && ts[b] == 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        alpha[b] = is0 ? r2[0] : 1.f;
+        rowdiv[b] = is0 ? 2.f * (float)I : (float)I;
+    }
+    if (!is0 && target == noise) return;
+    const float c = r1[0];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < I; i += gridDim.x * 256) {
+        float v;
+        if (is0) {
+#pragma clang fp contract(off)
+            const float p = c * xt[(int64_t)b * ldxt + i];
+            v = p - x0[(int64_t)b * ldx0 + i];
+        } else {
+            v = noise[(int64_t)b * ldn + i];
+        }
+        target[(int64_t)b * ldt + i] = v;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -628,17 +729,35 @@ __global__ __launch_bounds__(256) void emb_gather_w_kernel(const float* __restri
     if (idx < N * E) W1e[idx] = W1[(int64_t)(idx / E) * ldw + I + (idx % E)];
 }
 
-// demb[m,e] = sum_n dZ1[m,n] * W1e[n,e]   (one workgroup per row m, waves stride over e)
+// demb[m,e] = sum_n dZ1[m,n] * W1[n, I+e]: one WAVE per row m; a lane reads dZ1[m,n] once and feeds the E accumulators of its n
+// from the weight's embedding columns where they lie (40 contiguous bytes per n at E = 10: no gathered copy, one launch less).
+// Per e the summation order is what it always was: n = lane, lane + 64, ... in a lane, then the xor tree.
 __global__ __launch_bounds__(256) void emb_bwd_demb_kernel(const float* __restrict__ dZ1, int64_t lddz,
-                                                           const float* __restrict__ W1e, int E, int N,
+                                                           const float* __restrict__ W1, int64_t ldw, int I, int E, int N, int M,
                                                            float* __restrict__ demb) {
-    const int m = blockIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int e = wave; e < E; e += 4) {
-        float s = 0.f;
-        for (int n = lane; n < N; n += 64) s += dZ1[(int64_t)m * lddz + n] * W1e[(int64_t)n * E + e];
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if (lane == 0) demb[(int64_t)m * E + e] = s;
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const float* __restrict__ dz = dZ1 + (int64_t)m * lddz;
+    for (int e0 = 0; e0 < E; e0 += 16) {
+        float acc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+        for (int n = lane; n < N; n += 64) {
+            const float d = dz[n];
+            const float* __restrict__ w = W1 + (int64_t)n * ldw + I + e0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j)
+                if (e0 + j < E) acc[j] += d * w[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (e0 + j < E) {
+                float s_ = acc[j];
+                for (int o = 32; o > 0; o >>= 1) s_ += __shfl_xor(s_, o);
+                if (lane == 0) demb[(int64_t)m * E + e0 + j] = s_;
+            }
+        }
     }
 }
 
@@ -987,8 +1106,7 @@ int gdmcf_dnn_prep_input_f32(const float* x, int64_t ldx, const int64_t* ts, con
     PrepArgs a;
     a.x = x; a.ldx = ldx; a.ts = ts; a.ca = ca; a.cb = cb; a.noise_mode = ca ? noise_mode : 0; a.noise = noise;
     a.ldn = ldn; a.drop_mode = drop_mode; a.keep = keep; a.ldkeep = ldkeep; a.drop_scale = 1.0f / (1.0f - drop_p);
-    const double th = (1.0 - (double)drop_p) * 4294967296.0;
-    a.keep_thresh = th >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)th;
+    a.keep_thresh = (uint32_t)fmin(fmax(rint((1.0 - (double)drop_p) * 65536.0), 0.0), 65536.0);
     a.seed = seed; a.offset = offset; a.step_state = t_gd_step_state; a.rownorm = nullptr; a.emb_w = emb_w; a.emb_b = emb_b; a.E = E; a.B = B;
     a.I = I; a.xin = xin; a.ldxin = ldxin; a.xt_out = xt_out; a.ldxt = ldxt; a.temb_out = temb_out;
     a.xin16 = nullptr; a.ldxin16 = 0;
@@ -1035,8 +1153,7 @@ int gdmcf_dnn_prep_input_csr_f32(const int64_t* indptr, const int32_t* indices, 
     PrepArgs a;
     a.x = nullptr; a.ldx = 0; a.ts = ts; a.ca = ca; a.cb = cb; a.noise_mode = ca ? noise_mode : 0; a.noise = noise;
     a.ldn = ldn; a.drop_mode = drop_mode; a.keep = keep; a.ldkeep = ldkeep; a.drop_scale = 1.0f / (1.0f - drop_p);
-    const double th = (1.0 - (double)drop_p) * 4294967296.0;
-    a.keep_thresh = th >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)th;
+    a.keep_thresh = (uint32_t)fmin(fmax(rint((1.0 - (double)drop_p) * 65536.0), 0.0), 65536.0);
     a.seed = seed; a.offset = offset; a.step_state = t_gd_step_state; a.rownorm = nullptr; a.emb_w = emb_w; a.emb_b = emb_b; a.E = E; a.B = B;
     a.I = I; a.xin = xin; a.ldxin = ldxin; a.xt_out = nullptr; a.ldxt = 0; a.temb_out = temb_out;
     a.xin16 = nullptr; a.ldxin16 = 0;
@@ -1083,6 +1200,28 @@ int gdmcf_onehot_noise_f32(const float* x0, int64_t ldx, const int64_t* ts, int 
                            I, p1_off, sampled, lds, seed, offset, xU, ldu, sampled_out, ldso);
     }
     return gd_launch_status("onehot_noise");
+}
+
+int gdmcf_randn_f32(float* out, int64_t ld, int rows, int cols, int stream_id, uint64_t seed, uint64_t offset, void* stream) {
+    GD_CHECK_SHAPE(rows > 0 && cols > 0 && ld >= cols, "randn: bad shape");
+    GD_CHECK_ARG(out && stream_id >= 0 && stream_id < 256, "randn: null pointer / bad stream id");
+    {
+        GdProfScope prof(11, (double)rows * cols * 4.0, (hipStream_t)stream);  // algorithmic bytes: the store
+        hipLaunchKernelGGL(randn_kernel, dim3(gd_cdiv(cols, 256 * PREP_G * 4), rows), dim3(256), 0, (hipStream_t)stream, out,
+                           ld, rows, cols, (uint32_t)stream_id, seed, offset);
+    }
+    return gd_launch_status("randn");
+}
+
+int gdmcf_eps_target_f32(const float* noise, int64_t ldn, const float* xt, int64_t ldxt, const float* x0, int64_t ldx0,
+                         const int64_t* ts, const float* r1, const float* r2, int t0_likelihood, int B, int I, float* target,
+                         int64_t ldt, float* alpha, float* rowdiv, void* stream) {
+    GD_CHECK_SHAPE(B > 0 && I > 0 && ldn >= I && ldxt >= I && ldx0 >= I && ldt >= I, "eps_target: bad shape");
+    GD_CHECK_ARG(noise && xt && x0 && ts && r1 && r2 && target && alpha && rowdiv, "eps_target: null pointer");
+    GD_CHECK_ARG(target != noise || ldt == ldn, "eps_target: in-place target needs the noise buffer's leading dimension");
+    hipLaunchKernelGGL(eps_target_kernel, dim3(gd_cdiv(I, 2048), B), dim3(256), 0, (hipStream_t)stream, noise, ldn, xt, ldxt, x0,
+                       ldx0, ts, r1, r2, t0_likelihood, I, target, ldt, alpha, rowdiv);
+    return gd_launch_status("eps_target");
 }
 
 int gdmcf_graph_guided_step_u8(uint8_t* graph, int64_t ldg, const int64_t* ts, int B, int I, float discrete,
@@ -1157,9 +1296,8 @@ int gdmcf_emb_bwd_f32(const float* dZ1, int64_t lddz, const float* W1, int64_t l
                       int M, int N, float* demb_ws, float* dWe, float* dbe, void* stream) {
     GD_CHECK_SHAPE(M > 0 && N > 0 && E > 0 && ldw >= I + E && lddz >= N, "emb_bwd: bad shape");
     hipStream_t s = (hipStream_t)stream;
-    float* W1e = demb_ws + (size_t)M * E;  // demb_ws holds [M*E] demb followed by [N*E] gathered weights
-    hipLaunchKernelGGL(emb_gather_w_kernel, dim3(gd_cdiv(N * E, 256)), dim3(256), 0, s, W1, ldw, I, E, N, W1e);
-    hipLaunchKernelGGL(emb_bwd_demb_kernel, dim3(M), dim3(256), 0, s, dZ1, lddz, W1e, E, N, demb_ws);
+    // (demb_ws holds [M*E] demb; the [N*E] floats behind it, once a gathered copy of the embedding columns, are no longer used)
+    hipLaunchKernelGGL(emb_bwd_demb_kernel, dim3(gd_cdiv(M, 4)), dim3(256), 0, s, dZ1, lddz, W1, ldw, I, E, N, M, demb_ws);
     hipLaunchKernelGGL(emb_bwd_w_kernel, dim3(E * E + E), dim3(64), 0, s, demb_ws, temb, M, E, dWe, dbe);
     return gd_launch_status("emb_bwd");
 }

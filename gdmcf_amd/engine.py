@@ -267,6 +267,22 @@ class DenoiserEngine:
         bufs.xin_ones = True
         return batch, noise, keep
 
+    def _eps_target(self, bufs, spec, ts, x0, noise):
+        """(target, alpha, rowdiv) of the eps parameterisation in one launch (gdmcf_eps_target_f32; reference
+        gaussian_diffusion.py:344-348).  A noise tensor this package drew itself (spec["noise_owned"]) IS the target: only its
+        t == 0 rows are rewritten; a caller's tensor is left alone."""
+        B, dev = ts.shape[0], ts.device
+        if x0.dtype != torch.float32 or x0.stride(-1) != 1:
+            x0 = x0.float().contiguous()
+        target = noise if spec.get("noise_owned", False) else torch.empty(B, self.I, dtype=torch.float32, device=dev)
+        alpha = torch.empty(B, dtype=torch.float32, device=dev)
+        rowdiv = torch.empty(B, dtype=torch.float32, device=dev)
+        _lib.check(self.lib.gdmcf_eps_target_f32(
+            noise.data_ptr(), noise.stride(0), bufs.xt.data_ptr(), bufs.xt.stride(0), x0.data_ptr(), x0.stride(0), ts.data_ptr(),
+            spec["r1_0"].data_ptr(), spec["r2_0"].data_ptr(), int(bool(spec.get("t0_likelihood", True))), B, self.I,
+            target.data_ptr(), target.stride(0), alpha.data_ptr(), rowdiv.data_ptr(), _lib.stream_ptr()))
+        return target, alpha, rowdiv
+
     def _transposed(self, w):
         """W^T of a large weight, [in, out] row-major on 128-byte rows, cached per weight VERSION: the reverse-diffusion loop of an
         evaluation runs many batches over frozen weights, and with the weight in this orientation the hidden layer's product runs
@@ -329,11 +345,7 @@ class DenoiserEngine:
         if eps_mode:
             # target = eps, except rows with t == 0 whose term is the x0-likelihood
             # mean((x0 - (r1*x_t - r2*eps_hat))^2 / 2)  (reference gaussian_diffusion.py:344-348)
-            is0 = (ts == 0) if spec.get("t0_likelihood", True) else torch.zeros_like(ts, dtype=torch.bool)
-            noise = keepalive[1]
-            target = torch.where(is0[:, None], spec["r1_0"] * bufs.xt[:, : self.I] - x0c, noise)
-            alpha = torch.where(is0, spec["r2_0"], torch.ones((), dtype=torch.float32, device=dev)).float().contiguous()
-            rowdiv = torch.where(is0, 2.0 * self.I, 1.0 * self.I).float().contiguous()
+            target, alpha, rowdiv = self._eps_target(bufs, spec, ts, x0c, keepalive[1])
         else:
             target = x0c
             rowdiv = bufs.rowdiv_mse
@@ -524,9 +536,15 @@ class DenoiserEngine:
     # ------------------------------------------------------------------------------------------
     @_with_precision
     def p_sample_loop(self, x_start, steps, T, tabs32, eps_mode, sampling_noise, noise0=None, step_noise=None,
-                      capture=None):
-        """tabs32: dict of float32 device tables [T] (sqrt_ab, sqrt_1mab, c1, c2, r1, r2, sigma)."""
+                      capture=None, draw_noise=None):
+        """tabs32: dict of float32 device tables [T] (sqrt_ab, sqrt_1mab, c1, c2, r1, r2, sigma).  draw_noise(like) -> [B, I]
+        float32 N(0,1): the reverse loop's th.randn_like(x_t) (reference :210-217); default: gdmcf_randn_f32 on the engine's
+        Philox seed (stream 7, one offset per draw)."""
         m, lib = self.model, self.lib
+        if draw_noise is None:
+            def draw_noise(like):
+                self.offset += 1
+                return _lib.philox_randn(like.shape, like.device, self.seed, self.offset, 7)
         self.flush_weight_waiters()
         B, dev, I = x_start.shape[0], x_start.device, self.I
         layers = self._layers()
@@ -566,7 +584,7 @@ class DenoiserEngine:
                 r1, r2 = stabs["r1"][i], stabs["r2"][i]
             if sampling_noise and i != 0:
                 sg = stabs["sigma"][i]
-                z = step_noise[n] if step_noise is not None else torch.randn(B, I, dtype=torch.float32, device=dev)
+                z = step_noise[n] if step_noise is not None else draw_noise(xt[:, :I])
                 z = z.contiguous()
             pred = torch.empty(B, I, dtype=torch.float32, device=dev) if capture is not None else None
             _lib.check(lib.gdmcf_linear_posterior_fwd_f32(

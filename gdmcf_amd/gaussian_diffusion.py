@@ -111,6 +111,14 @@ class GaussianDiffusion(nn.Module):
     def SNR(self, t):
         return self.alphas_cumprod[t] / (1 - self.alphas_cumprod[t])
 
+    def _draw_noise(self, like, eps_mode=False, stream_id=4):
+        """`th.randn_like(x)` of the reference (:328-331 the eps target, :210-217 / :696-703 the reverse loop's noise) as a device
+        draw: gdmcf_randn_f32 (Philox4x32-10 keyed by torch.initial_seed(), one offset per call) unless rng == "torch"."""
+        if self.rng == "torch":
+            return torch.randn(like.shape, dtype=torch.float32, device=like.device)
+        self._randn_calls = getattr(self, "_randn_calls", 0) + 1
+        return _lib.philox_randn(like.shape, like.device, int(torch.initial_seed()) & (2 ** 63 - 1), self._randn_calls, stream_id)
+
     def _extract_into_tensor(self, arr, timesteps, broadcast_shape):
         res = arr.to(timesteps.device)[timesteps].float()
         while len(res.shape) < len(broadcast_shape):
@@ -234,10 +242,11 @@ class GaussianDiffusion(nn.Module):
         if self.mean_type not in (ModelMeanType.START_X, ModelMeanType.EPSILON):
             raise NotImplementedError(self.mean_type)
         ca = cb = None
+        noise_owned = False
         if self.noise_scale != 0.0:
             ca, cb = self._t32["sqrt_ab"], self._t32["sqrt_1mab"]
             if noise is None and (eps_mode or self.rng == "torch"):
-                noise = torch.randn_like(x_start, dtype=torch.float32)  # eps is the target: must exist in HBM
+                noise, noise_owned = self._draw_noise(x_start, eps_mode), True  # eps is the target: must exist in HBM
         elif eps_mode:
             raise NotImplementedError("noise_scale == 0 with mean_type EPSILON")
         if drop_mask is None and self.rng == "torch" and model.training and model.drop.p > 0:
@@ -252,6 +261,7 @@ class GaussianDiffusion(nn.Module):
             # (for the eps target that also means no x0-likelihood term on the t == 0 rows)
             weight_t = self._weights["one"]
         spec = dict(x_start=None if csr_batch is not None else x_start, csr=csr_batch, ts=ts, pt=pt, ca=ca, cb=cb, noise=noise,
+                    noise_owned=noise_owned,
                     drop_mask=drop_mask, eps_mode=eps_mode,
                     weight_t=weight_t, T=self.steps, H=self.history_num_per_term, Lt_history=self.Lt_history,
                     Lt_count=self.Lt_count, update_history=self.update_history, t0_likelihood=(reweight == True))  # noqa: E712
@@ -280,7 +290,8 @@ class GaussianDiffusion(nn.Module):
         with torch.no_grad():
             return model.engine.p_sample_loop(x_start, steps, self.steps, self._t32,
                                               self.mean_type == ModelMeanType.EPSILON, bool(sampling_noise),
-                                              noise0=noise0, step_noise=step_noise, capture=capture)
+                                              noise0=noise0, step_noise=step_noise, capture=capture,
+                                              draw_noise=lambda like: self._draw_noise(like, stream_id=7))
 
 
 class GaussianDiffusionDiscrete(GaussianDiffusion):
@@ -367,10 +378,11 @@ class GaussianDiffusionDiscrete(GaussianDiffusion):
         if self.mean_type not in (ModelMeanType.START_X, ModelMeanType.EPSILON):
             raise NotImplementedError(self.mean_type)
         ca = cb = None
+        noise_owned = False
         if self.noise_scale != 0.0:
             ca, cb = self._t32["sqrt_ab"], self._t32["sqrt_1mab"]
             if noise is None and (eps_mode or self.rng == "torch"):
-                noise = torch.randn_like(x_start, dtype=torch.float32)
+                noise, noise_owned = self._draw_noise(x_start, eps_mode), True
         elif eps_mode:
             raise NotImplementedError("noise_scale == 0 with mean_type EPSILON")
         if reweight == True:  # noqa: E712
@@ -379,7 +391,8 @@ class GaussianDiffusionDiscrete(GaussianDiffusion):
             weight_t = self._weights["eps" if eps_mode else "x0"]
         else:
             weight_t = self._weights["one"]
-        spec = dict(x_start=x_start, ts=ts, pt=pt, ca=ca, cb=cb, noise=noise, drop_mask=drop_mask, eps_mode=eps_mode,
+        spec = dict(x_start=x_start, ts=ts, pt=pt, ca=ca, cb=cb, noise=noise, noise_owned=noise_owned, drop_mask=drop_mask,
+                    eps_mode=eps_mode,
                     weight_t=weight_t, T=self.steps, H=self.history_num_per_term, Lt_history=self.Lt_history,
                     Lt_count=self.Lt_count, update_history=self.update_history, t0_likelihood=(reweight == True),  # noqa: E712
                     ts_U=ts_U, sampled=sampled, drop_mask_U=drop_mask_U, discrete=self.discrete, index=index)
@@ -452,7 +465,7 @@ class GaussianDiffusionDiscrete(GaussianDiffusion):
                 if eps_mode:
                     po.update(r1=tabs["r1"][i], r2=tabs["r2"][i])
                 if sampling_noise and i != 0:
-                    z = step_noise[n] if step_noise is not None else torch.randn_like(x_t)
+                    z = step_noise[n] if step_noise is not None else self._draw_noise(x_t, stream_id=7)
                     po.update(sigma=tabs["sigma"][i], z=z.float().contiguous())
                 x_in = x_t if (x_t.dtype == torch.float32 and x_t.is_contiguous()) else x_t.float().contiguous()
                 noisy = sampling_noise and i != 0

@@ -18,6 +18,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+from .engine import DenoiserEngine
 
 
 def _ceil64(n):
@@ -45,6 +46,7 @@ class _OneHotTrainLoss(torch.autograd.Function):
 
 
 class OneHotEngine:
+    _eps_target = DenoiserEngine._eps_target  # (target, alpha, rowdiv) of the eps parameterisation: one launch
     supports_grad_sink = True  # parallel.DataParallelStep may install `grad_sink` (overlapped gradient exchange)
     fused_opt = None
 
@@ -228,10 +230,7 @@ class OneHotEngine:
         _, keep2 = self._prep(bufs, bufs.xU, 2 * self.I, bufs.xin2, ts, None, None, None, spec["drop_mask_U"], training)
         alpha = None
         if eps_mode:
-            is0 = (ts == 0) if spec.get("t0_likelihood", True) else torch.zeros_like(ts, dtype=torch.bool)
-            target = torch.where(is0[:, None], spec["r1_0"] * bufs.xt[:, : self.I] - x0, noise)
-            alpha = torch.where(is0, spec["r2_0"], torch.ones((), dtype=torch.float32, device=dev)).float().contiguous()
-            rowdiv = torch.where(is0, 2.0 * self.I, 1.0 * self.I).float().contiguous()
+            target, alpha, rowdiv = self._eps_target(bufs, spec, ts, x0, noise)
         else:
             target, rowdiv = x0, bufs.rowdiv_mse
         return x0, target, alpha, rowdiv, (s8, noise, keep1, keep2)

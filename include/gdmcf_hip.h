@@ -90,7 +90,10 @@ int gdmcf_densify_rows_f32(const int64_t* indptr, const int32_t* indices, const 
  *            2: Philox4x32-10 + Box-Muller N(0,1): element (b,i) is component i&3 of the block with
  *               counter (i>>2, b, stream, offset) and key seed (stream 0 = noise, 1 = dropout),
  *               so any kernel can regenerate it.
- * drop_mode  0: none; 1: explicit keep-mask `keep` (uint8 [B,ldkeep]); 2: Philox Bernoulli(1-p).
+ * drop_mode  0: none; 1: explicit keep-mask `keep` (uint8 [B,ldkeep]); 2: Philox Bernoulli(1-p): element (b,i) is kept iff its
+ *               16-bit uniform < round((1-p) * 65536) (the keep probability is quantised to 2^-16: exact for p = 0.5; the scale
+ *               1/(1-p) is not quantised); the uniform is half (i >> 10) & 1 (low, high) of word i & 3 of the stream-1 block with
+ *               counter ((i & ~1024) >> 2, b, 1, offset): one block serves the eight elements i..i+3 and i+1024..i+1027.
  * normalize != 0 applies F.normalize (L2, eps 1e-12) to the (noised) row before dropout and
  * needs rownorm_ws (float32 [B] scratch).
  * xt_out (optional, [B,ldxt]) receives the pre-normalize/pre-dropout x_t.
@@ -127,6 +130,26 @@ int gdmcf_dnn_prep_input_csr_f32(const int64_t* indptr, const int32_t* indices, 
 int gdmcf_onehot_noise_f32(const float* x0, int64_t ldx, const int64_t* ts, int B, int I, float discrete,
                            const uint8_t* sampled, int64_t lds, uint64_t seed, uint64_t offset,
                            float* xU, int64_t ldu, uint8_t* sampled_out, int64_t ldso, void* stream);
+
+/* ---- N(0,1) fill --------------------------------------------------------------------------------
+ * replaces `noise = th.randn_like(x_start)` where the noise itself is needed in memory: the eps TARGET of
+ * training_losses (gaussian_diffusion.py:328-331, :844-846) and the reverse loop's `noise = th.randn_like(x_t)`
+ * (:210-217, :696-703).  out[b, i] (float32 [rows, ld]) = normal (i & 3) of the Philox4x32-10 block with counter
+ * (i >> 2, b, stream_id, (uint32)offset), key seed: Box-Muller on the block's (x, y) and (z, w) words, hardware log / sqrt /
+ * sin / cos.  stream_id 0 is the stream gdmcf_dnn_prep_input(_csr)_f32 draws in place (noise_mode 2): a buffer filled here
+ * with the same (seed, offset) and handed to it as given noise (noise_mode 1) yields the same x_t bit for bit.  Stream ids
+ * 1-3, 5, 6 belong to dropout / timestep / one-hot / graph draws; 4 and 7 are free for callers (eps target, step noise).  */
+int gdmcf_randn_f32(float* out, int64_t ld, int rows, int cols, int stream_id, uint64_t seed, uint64_t offset, void* stream);
+
+/* ---- loss target of the eps parameterisation ---------------------------------------------------
+ * replaces the element-wise passes of training_losses for ModelMeanType.EPSILON (gaussian_diffusion.py:328-348):
+ *   target[b,:] = noise[b,:]                      alpha[b] = 1       rowdiv[b] = I      (t != 0, or t0_likelihood == 0)
+ *   target[b,:] = r1[0]*x_t[b,:] - x0[b,:]         alpha[b] = r2[0]   rowdiv[b] = 2 I    (t == 0: the x0-likelihood row, :344-348)
+ * (product and difference rounded separately, as torch's mul and sub).  alpha / rowdiv feed gdmcf_linear_loss_fwd_f32 and
+ * gdmcf_row_loss_finish_*.  target may equal noise (same leading dimension): only the t == 0 rows are written then.      */
+int gdmcf_eps_target_f32(const float* noise, int64_t ldn, const float* xt, int64_t ldxt, const float* x0, int64_t ldx0,
+                         const int64_t* ts, const float* r1, const float* r2, int t0_likelihood, int B, int I, float* target,
+                         int64_t ldt, float* alpha, float* rowdiv, void* stream);
 
 /* ---- degree-guided graph of the reverse loop (gaussian_diffusion.py:706-729, inside GaussianDiffusionDiscrete.p_sample) ----
  * One reverse step's update of the accumulated user-item graph, one byte per edge state:

@@ -783,7 +783,7 @@ def test_first_layer_bias_gradient_from_the_ones_column_of_the_input_builder():
 def test_reverse_loop_through_cached_transposed_weights_follows_weight_updates():
     """engine._transposed: the reverse-diffusion loop (reference gaussian_diffusion.py:161-220) runs its hidden layer through a
     cached W^T (gdmcf_linear_fwd_wt_f32 -> dr_kn_kernel).  Yelp shape: predictions with the cache equal the plain path within
-    float32 summation order and give the same top-k lists; after a training step the cache must follow the new weights (version
+    float32 summation order and give the same top-k lists (up to ties inside that noise); after a training step the cache must follow the new weights (version
     check) -- compared with a model that never uses it."""
     import scipy.sparse as sp
     from gdmcf_amd.data_utils import DeviceCSR
@@ -814,7 +814,14 @@ def test_reverse_loop_through_cached_transposed_weights_follows_weight_updates()
         a, b = predict(True), predict(False)
         assert model.engine._wt, "the transposed cache was not used"
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()), round_
-        assert torch.equal(a.topk(20, dim=1).indices, b.topk(20, dim=1).indices), round_
+        # the same top-20 lists up to ties inside the two paths' summation-order noise: every item one path picks scores, in the
+        # OTHER path, no lower than that path's own 20th score minus the noise bound (index-for-index equality would test luck:
+        # scores 1e-9 apart swap places between two float32 summation orders)
+        tol = 2e-5 * float(b.abs().max())
+        ia, ib = a.topk(20, dim=1).indices, b.topk(20, dim=1).indices
+        assert bool((b.gather(1, ia) >= b.topk(20, dim=1).values[:, -1:] - tol).all()), round_
+        assert bool((a.gather(1, ib) >= a.topk(20, dim=1).values[:, -1:] - tol).all()), round_
+        assert float((ia == ib).float().mean()) > 0.98, round_
         torch.manual_seed(5)
         step(dcsr.batch(torch.arange(B, device=dev)), True)  # the weights move: the next prediction must see them
         c = predict(True)

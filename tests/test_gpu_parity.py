@@ -729,6 +729,116 @@ def test_philox_noise_and_dropout_statistics():
     eng.manual_seed(123)
     eng._prep(bufs, ones, ts, None, None, None, None, True)
     assert torch.equal(a, bufs.xin[:, :I])  # counter based: same (seed, offset) -> same mask
+    # p = 0.3: keep fraction 0.7 (16-bit thresholds), exact scale 1/(1-p); the two column groups that share a Philox block
+    # (columns i and i + 1024: low / high halves of the same words) are independent
+    m.drop.p = 0.3
+    eng.manual_seed(5)
+    eng._prep(bufs, ones, ts, None, None, None, None, True)
+    k = bufs.xin[:, :I] > 0
+    assert abs(float(k.float().mean()) - 0.7) < 0.01
+    uq = torch.unique(bufs.xin[:, :I]).tolist()
+    assert len(uq) == 2 and uq[0] == 0.0 and abs(uq[1] - 1.0 / 0.7) < 1e-6
+    lo, hi = k[:, :1024].float(), k[:, 1024:2048].float()
+    corr = float(((lo - lo.mean()) * (hi - hi.mean())).mean() / (lo.std() * hi.std()))
+    assert abs(corr) < 0.02
+    m.drop.p = 0.5
+
+
+def test_randn_kernel_is_the_input_builders_noise_stream():
+    """gdmcf_randn_f32 (stands where the reference calls th.randn_like: gaussian_diffusion.py:328-331, :210-217): stream 0 with
+    the input builder's (seed, offset) IS the noise the builder draws in place -- x_t from the in-kernel draw equals x_t from the
+    filled buffer bit for bit (odd width: 4-byte-aligned rows, ragged last group); moments; counter-based repeatability."""
+    from gdmcf_amd import _lib
+    torch.manual_seed(7)
+    B, I = 48, 4099
+    d = gdmcf_amd.GaussianDiffusion(ModelMeanType.START_X, "linear", 1.0, 0.5, 0.5, 4, DEV)
+    x0 = (torch.rand(B, I, device=DEV) < 0.1).float()
+    ts = torch.randint(0, 4, (B,), device=DEV)
+    a = d.q_sample(x0, ts)  # in-kernel Philox draw: offset (1 << 40) + _q_calls, seed torch.initial_seed()
+    seed = int(torch.initial_seed()) & (2 ** 63 - 1)
+    nz = _lib.philox_randn((B, I), DEV, seed, (1 << 40) + d._q_calls, stream_id=0)
+    b = d.q_sample(x0, ts, noise=nz)
+    assert torch.equal(a, b)
+    # the callers' streams: N(0,1) moments, a different stream / offset gives different numbers, the same ones the same
+    z = _lib.philox_randn((256, 8191), DEV, 99, 1, stream_id=4)
+    assert abs(float(z.mean())) < 0.005 and abs(float(z.std()) - 1.0) < 0.005
+    assert abs(float((z ** 4).mean()) - 3.0) < 0.05 and abs(float((z ** 3).mean())) < 0.02
+    assert float(z.abs().max()) < 7.0 and bool(torch.isfinite(z).all())
+    assert torch.equal(z, _lib.philox_randn((256, 8191), DEV, 99, 1, stream_id=4))
+    assert not torch.equal(z, _lib.philox_randn((256, 8191), DEV, 99, 2, stream_id=4))
+    assert not torch.equal(z, _lib.philox_randn((256, 8191), DEV, 99, 1, stream_id=7))
+    # into a wider buffer: the columns past `cols` are not touched
+    buf = torch.full((5, 40), -1.0, device=DEV)
+    _lib.philox_randn((5, 33), DEV, 3, 3, out=buf[:, :33])
+    assert torch.equal(buf[:, 33:], torch.full((5, 7), -1.0, device=DEV)) and bool((buf[:, :33] != -1.0).all())
+    with pytest.raises(RuntimeError):
+        _lib.philox_randn((4, 4), "cpu", 1, 1)
+
+
+@pytest.mark.parametrize("t0_likelihood", [True, False])
+def test_eps_target_kernel_equals_the_elementwise_expressions(t0_likelihood):
+    """gdmcf_eps_target_f32 against the reference's element-wise passes (gaussian_diffusion.py:344-348: target = eps except the
+    t == 0 rows, whose target is r1[0]*x_t - x0 with weight r2[0] and twice the divisor): bit-exact, out of place and in place."""
+    from gdmcf_amd import _lib
+    torch.manual_seed(3)
+    B, I, ld = 37, 1003, 1024
+    noise = torch.randn(B, I, device=DEV)
+    xt = torch.randn(B, ld, device=DEV)
+    x0 = (torch.rand(B, I, device=DEV) < 0.2).float()
+    ts = torch.randint(0, 3, (B,), device=DEV)
+    ts[0], ts[B - 1] = 0, 0
+    r1 = torch.tensor([1.2345678, 9.0], device=DEV)
+    r2 = torch.tensor([0.7654321, 9.0], device=DEV)
+    is0 = (ts == 0) if t0_likelihood else torch.zeros_like(ts, dtype=torch.bool)
+    want_t = torch.where(is0[:, None], r1[0] * xt[:, :I] - x0, noise)
+    want_a = torch.where(is0, r2[0], torch.ones((), device=DEV))
+    want_d = torch.where(is0, 2.0 * I, 1.0 * I).float()
+    lib = _lib.load()
+    for in_place in (False, True):
+        nz = noise.clone()
+        tgt = nz if in_place else torch.full((B, I), float("nan"), device=DEV)
+        al, rd = torch.empty(B, device=DEV), torch.empty(B, device=DEV)
+        _lib.check(lib.gdmcf_eps_target_f32(nz.data_ptr(), nz.stride(0), xt.data_ptr(), xt.stride(0), x0.data_ptr(), x0.stride(0),
+                                            ts.data_ptr(), r1.data_ptr(), r2.data_ptr(), int(t0_likelihood), B, I, tgt.data_ptr(),
+                                            tgt.stride(0), al.data_ptr(), rd.data_ptr(), _lib.stream_ptr()))
+        assert torch.equal(tgt, want_t) and torch.equal(al, want_a) and torch.equal(rd, want_d)
+
+
+def test_eps_training_on_the_device_noise_draw():
+    """ModelMeanType.EPSILON without injected noise: the target is drawn by gdmcf_randn_f32 (no ATen pass), the x0-likelihood rows
+    are patched in place; the loss equals, bit for bit, the injected-noise path's (pinned to the reference fixtures) on the SAME noise, re-drawn from the
+    stream's (seed, offset); training steps run on it."""
+    torch.manual_seed(11)
+    B, I, T = 64, 515, 5
+    m = gdmcf_amd.DNN([I, 48], [48, I], 10).to(DEV)
+    m.eval()  # no dropout: the oracle sees the same input
+    d = gdmcf_amd.GaussianDiffusion(ModelMeanType.EPSILON, "linear-var", 0.1, 0.001, 0.02, T, DEV)
+    x = (torch.rand(B, I, device=DEV) < 0.05).float()
+    ts = torch.randint(0, T, (B,), device=DEV)
+    ts[:4] = 0
+    pt = torch.full((B,), 1.0 / T, dtype=torch.float64, device=DEV)
+    from gdmcf_amd import _lib
+    calls = getattr(d, "_randn_calls", 0)
+    got = d.training_losses(m, x, True, ts=ts, pt=pt)["loss"]
+    assert d._randn_calls == calls + 1
+    nz = _lib.philox_randn((B, I), DEV, int(torch.initial_seed()) & (2 ** 63 - 1), d._randn_calls, stream_id=4)
+    d2 = gdmcf_amd.GaussianDiffusion(ModelMeanType.EPSILON, "linear-var", 0.1, 0.001, 0.02, T, DEV)
+    want = d2.training_losses(m, x, True, ts=ts, pt=pt, noise=nz)["loss"]  # the injected-noise path (pinned to the fixtures)
+    assert torch.equal(got, want)
+    m.train()
+    opt = gdmcf_amd.FusedAdamW(m.parameters(), lr=1e-3, weight_decay=0.0)
+    w0 = m.out_layers[-1].weight.detach().clone()
+    losses = []
+    for _ in range(20):
+        opt.zero_grad()
+        l = d.training_losses(m, x, True)["loss"].mean()
+        l.backward()
+        opt.step()
+        losses.append(float(l))
+    # (the SNR-weighted eps loss of 20 importance-sampled steps is too noisy to demand a decrease: finite, a fresh draw per step,
+    # and the step reaches the weights)
+    assert all(np.isfinite(losses)) and len(set(losses)) == 20
+    assert d._randn_calls == calls + 21 and not torch.equal(w0, m.out_layers[-1].weight.detach())
 
 
 def test_rng_paths_train_and_decrease_loss():
