@@ -600,13 +600,20 @@ __global__ void emb_cols_kernel(const int64_t* __restrict__ ts, const float* __r
                                 float* __restrict__ temb_out, unsigned short* __restrict__ xin16, int64_t ldxin16) {
     const int b = blockIdx.x;
     const float t = (float)ts[b];
+    // the E sinusoids once per row, one per lane (not E + 1 of them in a serial chain of libm calls per embedding column)
+    __shared__ float s_temb[256];
+    const bool staged = E <= 256;
+    if (staged) {
+        for (int f = threadIdx.x; f < E; f += blockDim.x) s_temb[f] = temb_value(t, f, E);
+        __syncthreads();
+    }
     for (int i = I + threadIdx.x; i < ldxin; i += blockDim.x) {
         float e = 0.f;
         if (i < I + E) {
             const int eo = i - I;
             e = emb_b[eo];
-            for (int f = 0; f < E; ++f) e += emb_w[eo * E + f] * temb_value(t, f, E);
-            if (temb_out) temb_out[(int64_t)b * E + eo] = temb_value(t, eo, E);
+            for (int f = 0; f < E; ++f) e += emb_w[eo * E + f] * (staged ? s_temb[f] : temb_value(t, f, E));
+            if (temb_out) temb_out[(int64_t)b * E + eo] = staged ? s_temb[eo] : temb_value(t, eo, E);
         }
         xin[(int64_t)b * ldxin + i] = e;
         if (xin16 && i < ldxin16) xin16[(int64_t)b * ldxin16 + i] = gd_bf16_bits(e);
@@ -729,35 +736,17 @@ __global__ __launch_bounds__(256) void emb_gather_w_kernel(const float* __restri
     if (idx < N * E) W1e[idx] = W1[(int64_t)(idx / E) * ldw + I + (idx % E)];
 }
 
-// demb[m,e] = sum_n dZ1[m,n] * W1[n, I+e]: one WAVE per row m; a lane reads dZ1[m,n] once and feeds the E accumulators of its n
-// from the weight's embedding columns where they lie (40 contiguous bytes per n at E = 10: no gathered copy, one launch less).
-// Per e the summation order is what it always was: n = lane, lane + 64, ... in a lane, then the xor tree.
+// demb[m,e] = sum_n dZ1[m,n] * W1e[n,e]   (one workgroup per row m, waves stride over e)
 __global__ __launch_bounds__(256) void emb_bwd_demb_kernel(const float* __restrict__ dZ1, int64_t lddz,
-                                                           const float* __restrict__ W1, int64_t ldw, int I, int E, int N, int M,
+                                                           const float* __restrict__ W1e, int E, int N,
                                                            float* __restrict__ demb) {
-    const int lane = threadIdx.x & 63;
-    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (m >= M) return;
-    const float* __restrict__ dz = dZ1 + (int64_t)m * lddz;
-    for (int e0 = 0; e0 < E; e0 += 16) {
-        float acc[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-        for (int n = lane; n < N; n += 64) {
-            const float d = dz[n];
-            const float* __restrict__ w = W1 + (int64_t)n * ldw + I + e0;
-#pragma unroll
-            for (int j = 0; j < 16; ++j)
-                if (e0 + j < E) acc[j] += d * w[j];
-        }
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            if (e0 + j < E) {
-                float s_ = acc[j];
-                for (int o = 32; o > 0; o >>= 1) s_ += __shfl_xor(s_, o);
-                if (lane == 0) demb[(int64_t)m * E + e0 + j] = s_;
-            }
-        }
+    const int m = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int e = wave; e < E; e += 4) {
+        float s = 0.f;
+        for (int n = lane; n < N; n += 64) s += dZ1[(int64_t)m * lddz + n] * W1e[(int64_t)n * E + e];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) demb[(int64_t)m * E + e] = s;
     }
 }
 
@@ -1296,8 +1285,9 @@ int gdmcf_emb_bwd_f32(const float* dZ1, int64_t lddz, const float* W1, int64_t l
                       int M, int N, float* demb_ws, float* dWe, float* dbe, void* stream) {
     GD_CHECK_SHAPE(M > 0 && N > 0 && E > 0 && ldw >= I + E && lddz >= N, "emb_bwd: bad shape");
     hipStream_t s = (hipStream_t)stream;
-    // (demb_ws holds [M*E] demb; the [N*E] floats behind it, once a gathered copy of the embedding columns, are no longer used)
-    hipLaunchKernelGGL(emb_bwd_demb_kernel, dim3(gd_cdiv(M, 4)), dim3(256), 0, s, dZ1, lddz, W1, ldw, I, E, N, M, demb_ws);
+    float* W1e = demb_ws + (size_t)M * E;  // demb_ws holds [M*E] demb followed by [N*E] gathered weights
+    hipLaunchKernelGGL(emb_gather_w_kernel, dim3(gd_cdiv(N * E, 256)), dim3(256), 0, s, W1, ldw, I, E, N, W1e);
+    hipLaunchKernelGGL(emb_bwd_demb_kernel, dim3(M), dim3(256), 0, s, dZ1, lddz, W1e, E, N, demb_ws);
     hipLaunchKernelGGL(emb_bwd_w_kernel, dim3(E * E + E), dim3(64), 0, s, demb_ws, temb, M, E, dWe, dbe);
     return gd_launch_status("emb_bwd");
 }
