@@ -145,6 +145,8 @@ def test_product_path_has_no_cpu_fallback():
         d.p_sample(m, x, 0)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         gdmcf_amd.masked_topk(torch.zeros(2, 8), 2)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):  # the device noise draw (gdmcf_randn_f32) does not become torch.randn
+        gdmcf_amd._lib.philox_randn((2, 8), "cpu", 1, 1)
 
 
 def test_product_never_imports_the_oracle():
