@@ -1334,7 +1334,7 @@ __global__ __launch_bounds__(256, 1) void dr_fat_kernel(const DrArgs d) {
     const int ntiles = d.tiles_m * d.tiles_n;
     const __amdgpu_buffer_rsrc_t srdA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, (int)(((int64_t)(g.M - 1) * g.lda + g.K) * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t srdB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B), 0, (int)(((int64_t)(g.N - 1) * g.ldb + g.K) * 4), 0x00020000);
-    const int NCH = d.ksp;       // chunks of 16 k per tile (even: the loop runs them in pairs)
+    const int NCH = d.ksp;       // chunks of 16 k per tile: ceil(K / 16) -- the loop runs them in pairs, an odd last one alone
     const int c_mask = g.K >> 4;  // first chunk that reaches past K
     // LDS float offsets: write -- piece p = rows 16 p + (lane >> 2), slot lane & 3; read -- block b = rows 16 b + r, slot q
     const int w_off = (lane >> 2) * 16 + (((lane & 3) ^ ((((lane >> 2) >> 2) & 1) << 1)) << 2);
@@ -1407,10 +1407,13 @@ __global__ __launch_bounds__(256, 1) void dr_fat_kernel(const DrArgs d) {
                 __builtin_amdgcn_sched_barrier(0);                                                                    \
             }                                                                                                         \
         }
-        for (int c = 0; c < NCH; c += 2) {
+        for (int c = 0; c + 1 < NCH; c += 2) {
             GD_FAT_CHUNK(0, c);
             GD_FAT_CHUNK(1, c + 1);
         }
+        // an odd number of chunks (K = 1 000: 63, the last one half masked): the last chunk alone, not a pair with an all-zero
+        // partner (1.6 % of the product's matrix instructions at K = 1 000)
+        if (NCH & 1) GD_FAT_CHUNK(0, NCH - 1);
 #undef GD_FAT_CHUNK
 
         // ---- epilogue: the tile goes through the wave's LDS (the chunk images are dead) one block of 16 rows at a time and leaves
@@ -1930,7 +1933,11 @@ int gd_gemm_dr_launch(int layA, int layB, int epi, GdGemm& g, hipStream_t s) {
             d.tiles_m = tiles_m;
             d.tiles_n = gd_cdiv(g.N, 16 * nb);
             d.m_fastest = 1;
-            d.ksp = (gd_cdiv(g.K, 16) + 1) & ~1;  // chunks of 16 k, an even number of them
+            d.ksp = (gd_cdiv(g.K, 16) + 1) & ~1;  // chunks of 16 k
+            {
+                static const int odd_on = getenv("GDMCF_FAT_ODD") ? atoi(getenv("GDMCF_FAT_ODD")) : 1;  // 0: the old even count (A/B)
+                if (odd_on) d.ksp = gd_cdiv(g.K, 16);
+            }
             g.tiles_m = d.tiles_m;
             g.tiles_n = d.tiles_n;
             d.g = g;
