@@ -1407,7 +1407,30 @@ __global__ __launch_bounds__(256, 1) void dr_fat_kernel(const DrArgs d) {
                 __builtin_amdgcn_sched_barrier(0);                                                                    \
             }                                                                                                         \
         }
+        // Reverse step: the epilogue reads the tile's x_t (80 x 16 NB floats per wave, 55 MB per launch at the Yelp shape) in the same
+        // burst in which every wave writes x_{t-1} -- the only HBM-bound stretch of the kernel, while the k loop leaves HBM nearly
+        // idle.  Some chunks (default ten, ~30 us) before the end the wave touches one dword of every 128-byte line of its x_t tile with LDS-DMA
+        // loads (buffer_load_dword ... lds into a scratch line of its own: no registers, nothing waits for them), so the epilogue's
+        // reads find the lines in L2 / the Infinity Cache.
+        const int c_pf = d.stagger > 0 ? ((NCH > d.stagger + 2 ? NCH - d.stagger : 0) & ~1) : -2;  // (d.stagger: chunks before the end; 0 = off)
         for (int c = 0; c + 1 < NCH; c += 2) {
+            if constexpr (EPI == GD_EPI_POST) {
+                if (c == c_pf) {
+                    typedef __attribute__((address_space(3))) void* lds_vp;
+                    constexpr int NJL = (16 * NB * 4 + 127) / 128 + 1;   // touches per row: one per line + the row's last element
+                    constexpr int NPI = (80 * NJL + 63) / 64;
+                    float* const scratch = dr_lds + 4 * (2 * NB * 256) + wave * 64;
+                    const __amdgpu_buffer_rsrc_t srdX = __builtin_amdgcn_make_buffer_rsrc(
+                        const_cast<float*>(g.aux), 0, (int)(((int64_t)(g.M - 1) * g.ldaux + g.N) * 4), 0x00020000);
+#pragma unroll
+                    for (int pi = 0; pi < NPI; ++pi) {
+                        const int t = min(pi * 64 + lane, 80 * NJL - 1);
+                        const int row = min(m0 + t % 80, g.M - 1), j = t / 80;
+                        const int col = min(j < NJL - 1 ? n0 + 32 * j : n0 + 16 * NB - 1, g.N - 1);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(srdX, (lds_vp)scratch, 4, (int)(((int64_t)row * g.ldaux + col) * 4), 0, 0, 0);
+                    }
+                }
+            }
             GD_FAT_CHUNK(0, c);
             GD_FAT_CHUNK(1, c + 1);
         }
@@ -1693,7 +1716,7 @@ __global__ __launch_bounds__(256, 1) void dr_kn_kernel(const DrArgs d) {
 
 template <int NB>
 int dr_fat_go(const DrArgs& d, int epi, int n_cu, hipStream_t s) {
-    const size_t lds = (size_t)4 * 2 * NB * 256 * sizeof(float);
+    const size_t lds = (size_t)4 * 2 * NB * 256 * sizeof(float) + 4 * 64 * sizeof(float);  // chunk images + a scratch line per wave (x_t prefetch)
     void (*kern)(const DrArgs) = epi == GD_EPI_LOSS ? dr_fat_kernel<NB, GD_EPI_LOSS> : dr_fat_kernel<NB, GD_EPI_POST>;
     static bool attr_set[2] = {false, false};
     if (!attr_set[epi == GD_EPI_LOSS] && lds > 48 * 1024) {
@@ -1937,6 +1960,9 @@ int gd_gemm_dr_launch(int layA, int layB, int epi, GdGemm& g, hipStream_t s) {
             {
                 static const int odd_on = getenv("GDMCF_FAT_ODD") ? atoi(getenv("GDMCF_FAT_ODD")) : 1;  // 0: the old even count (A/B)
                 if (odd_on) d.ksp = gd_cdiv(g.K, 16);
+                // x_t prefetch of the reverse step: this many chunks before the end of the k loop (0: off; A/B knob)
+                static const int pf = getenv("GDMCF_FAT_PF") ? atoi(getenv("GDMCF_FAT_PF")) : 10;
+                d.stagger = pf;  // (the field is unused by this kernel otherwise)
             }
             g.tiles_m = d.tiles_m;
             g.tiles_n = d.tiles_n;
