@@ -139,9 +139,11 @@ def parse():
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not measure roofline.traffic with two rocprofv3 --pmc child passes of this command (N = 1 only; ~40 s)")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
-    ap.add_argument("--prof-every", type=int, default=4,
-                    help="bracket the tagged launches of every Nth timed step with HIP events (an event pair keeps the next "
-                         "kernel from starting under the tail of the previous one: every step costs +3 %%, every 4th <1 %%)")
+    ap.add_argument("--prof-every", type=int, default=0,
+                    help="bracket the tagged launches of every Nth timed step with HIP events.  An event pair keeps the next kernel "
+                         "from starting behind the previous one: ~5 us per launch, ~80 us per bracketed step (rocprofv3 kernel "
+                         "trace, profiles/README.md) -- every 4th step still inflates the line by 1.5 %%.  0 (default) = three "
+                         "bracketed steps spread over the timed region (every max(4, ceil(steps / 3))th step)")
     ap.add_argument("--spmm", action="store_true", help="(default on) time the LightGCN SpMM, reported under 'spmm'")
     ap.add_argument("--no-spmm", action="store_true", help="skip the LightGCN SpMM leg")
     ap.add_argument("--spmm-only", action="store_true",
@@ -299,6 +301,13 @@ def cpu_baseline(args, I, x_batches, seconds):
         torch.set_num_threads(threads)
         out["one_thread"] = dict(value=round(Bc / e1, 2), unit="users/s", ms_per_step=round(1e3 * e1, 1), sample="1 train step")
     return out
+
+
+def prof_stride(steps, asked=0):
+    """Which timed steps are bracketed with HIP events: every `asked`-th, or -- 0 -- three of them spread over the region.  The
+    brackets cost ~80 us per step (each event pair holds the next launch back ~5 us); the kernels' averages need a handful of
+    samples, not a quarter of the steps."""
+    return max(1, asked) if asked > 0 else max(4, -(-steps // 3))
 
 
 def physical_cores():
@@ -553,7 +562,7 @@ def main():
         if failed:
             dp_autotune["sharded_error"] = failed
     prof = not args.no_prof
-    every = max(1, args.prof_every)
+    every = prof_stride(args.steps, args.prof_every)
     n_profiled = len(range(0, args.steps, every)) if prof else 0
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -818,9 +827,9 @@ def bench_sampling(gdmcf_amd, lib, model, diffusion, x, indptr, indices, dev, it
         pred = diffusion.p_sample(model, x, 0, False)
         idx = gdmcf_amd.masked_topk(pred, k, ip, ix)
     torch.cuda.synchronize()
-    lib.gdmcf_prof_enable(1)
     t0 = time.perf_counter()
-    for _ in range(iters):
+    for it in range(iters):
+        lib.gdmcf_prof_enable(1 if it % 4 == 0 else 2)  # HIP-event brackets on three of the ten batches (~5 us per launch)
         pred = diffusion.p_sample(model, x, 0, False)
         idx = gdmcf_amd.masked_topk(pred, k, ip, ix)
     torch.cuda.synchronize()
@@ -838,7 +847,7 @@ def bench_sampling(gdmcf_amd, lib, model, diffusion, x, indptr, indices, dev, it
     return out
 
 
-def bench_configs2(gdmcf_amd, lib, dev, steps, warmup, B=400, hid=1000, T=5, prof_every=4):
+def bench_configs2(gdmcf_amd, lib, dev, steps, warmup, B=400, hid=1000, T=5, prof_every=0):
     """BASELINE configs[2] beside the main line: "Amazon-Book_clean batch=400 dims=[1000] steps=5, 1xMI355X, bf16 denoiser GEMM
     on MFMA" -- the same training step (zero_grad -> training_losses -> mean -> backward -> AdamW.step) on synthetic rows of
     the Amazon-Book shape (I = 94 949), dense products with bf16-rounded inputs on v_mfma_f32_16x16x32_bf16, f32 accumulation,
@@ -849,6 +858,7 @@ def bench_configs2(gdmcf_amd, lib, dev, steps, warmup, B=400, hid=1000, T=5, pro
     from gdmcf_amd.data_utils import DeviceCSR
     from gdmcf_amd.parallel import DataParallelStep
     n_pool = 4
+    prof_every = prof_stride(steps, prof_every)
     indptr, indices, I = data.synth_csr("amazon-book", n_rows=n_pool * B, seed=0)
     dcsr = DeviceCSR(sp.csr_matrix((np.ones(len(indices), np.float32), indices, indptr), shape=(n_pool * B, I)), dev)
     row_ids = [torch.arange(i * B, (i + 1) * B, device=dev) for i in range(n_pool)]
