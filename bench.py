@@ -303,6 +303,28 @@ def cpu_baseline(args, I, x_batches, seconds):
     return out
 
 
+def clock_preheat(lib, dev, seconds):
+    """A fixed TIME of dense products on scratch operands (no training step; no model / optimiser / RNG state touched): brings the
+    clock up after an idle period.  Returns the `clock_preheat` record of the line, or None when switched off."""
+    from gdmcf_amd import _lib
+    if seconds <= 0:
+        return None
+    pa = torch.randn(400, 4096, device=dev)
+    pw = torch.randn(4096, 4096, device=dev)
+    pc = torch.empty(400, 4096, device=dev)
+    pws = torch.empty(max(int(lib.gdmcf_linear_ws_bytes(400, 4096, 4096)), 256), dtype=torch.uint8, device=dev)
+    t_ph, n_ph = time.perf_counter(), 0
+    while time.perf_counter() - t_ph < seconds:
+        for _ in range(16):
+            _lib.check(lib.gdmcf_linear_fwd_f32(pa.data_ptr(), 4096, pw.data_ptr(), 4096, None, 0, 400, 4096, 4096,
+                                                pc.data_ptr(), 4096, pws.data_ptr(), pws.numel(), _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        n_ph += 16
+    return dict(seconds=round(time.perf_counter() - t_ph, 3), launches=n_ph,
+                what="untimed dense products on scratch buffers before the warm-up steps (clock ramp after idle); "
+                     "no training step, no model / optimiser / RNG state touched")
+
+
 def prof_stride(steps, asked=0):
     """Which timed steps are bracketed with HIP events: every `asked`-th, or -- 0 -- three of them spread over the region.  The
     brackets cost ~80 us per step (each event pair holds the next launch back ~5 us); the kernels' averages need a handful of
@@ -506,23 +528,7 @@ def main():
     # = 32 ms behind 5 warm-up steps = 8 ms would measure the ramp, which no training run longer than a blink sees.  A fixed
     # TIME of dense products on scratch operands brings the clock up; the model, the optimiser and the random streams are
     # not touched (the W warm-up steps that follow are the only steps before the timed ones).  Reported as `clock_preheat`.
-    preheat = None
-    if args.preheat_seconds > 0:
-        pa = torch.randn(400, 4096, device=dev)
-        pw = torch.randn(4096, 4096, device=dev)
-        pc = torch.empty(400, 4096, device=dev)
-        pws = torch.empty(max(int(lib.gdmcf_linear_ws_bytes(400, 4096, 4096)), 256), dtype=torch.uint8, device=dev)
-        t_ph, n_ph = time.perf_counter(), 0
-        while time.perf_counter() - t_ph < args.preheat_seconds:
-            for _ in range(16):
-                _lib.check(lib.gdmcf_linear_fwd_f32(pa.data_ptr(), 4096, pw.data_ptr(), 4096, None, 0, 400, 4096, 4096,
-                                                    pc.data_ptr(), 4096, pws.data_ptr(), pws.numel(), _lib.stream_ptr()))
-            torch.cuda.synchronize()
-            n_ph += 16
-        preheat = dict(seconds=round(time.perf_counter() - t_ph, 3), launches=n_ph,
-                       what="untimed dense products on scratch buffers before the warm-up steps (clock ramp after idle); "
-                            "no training step, no model / optimiser / RNG state touched")
-        del pa, pw, pc, pws
+    preheat = clock_preheat(lib, dev, args.preheat_seconds)
     loss = None
     trace = os.environ.get("GDMCF_BENCH_TRACE") == "1"  # debugging: the loss of every step on stderr (synchronises each step)
     for i in range(args.warmup):
@@ -761,7 +767,7 @@ def main():
     configs2_leg = None
     if world == 1 and default_line_only(args) and not args.no_configs2_leg:
         try:
-            configs2_leg = bench_configs2(gdmcf_amd, lib, dev, args.steps, max(3, args.warmup // 4))
+            configs2_leg = bench_configs2(gdmcf_amd, lib, dev, args.steps, max(3, args.warmup // 4), preheat_seconds=args.preheat_seconds)
         except Exception as exc:  # reported, never fatal for the main line
             configs2_leg = dict(error=f"{type(exc).__name__}: {exc}"[:300])
 
@@ -847,7 +853,7 @@ def bench_sampling(gdmcf_amd, lib, model, diffusion, x, indptr, indices, dev, it
     return out
 
 
-def bench_configs2(gdmcf_amd, lib, dev, steps, warmup, B=400, hid=1000, T=5, prof_every=0):
+def bench_configs2(gdmcf_amd, lib, dev, steps, warmup, B=400, hid=1000, T=5, prof_every=0, preheat_seconds=0.0):
     """BASELINE configs[2] beside the main line: "Amazon-Book_clean batch=400 dims=[1000] steps=5, 1xMI355X, bf16 denoiser GEMM
     on MFMA" -- the same training step (zero_grad -> training_losses -> mean -> backward -> AdamW.step) on synthetic rows of
     the Amazon-Book shape (I = 94 949), dense products with bf16-rounded inputs on v_mfma_f32_16x16x32_bf16, f32 accumulation,
@@ -887,6 +893,9 @@ def bench_configs2(gdmcf_amd, lib, dev, steps, warmup, B=400, hid=1000, T=5, pro
     # main figure of the leg: AdamW of the two large weights inside their weight-gradient products (the default optimiser
     # placement at N = 1 since round 4); the separate pass is timed beside it
     opt.fuse_into_backward(model)
+    # the leg starts behind the main line's rocprofv3 child passes (tens of seconds without GPU work in this process): the same
+    # untimed clock pre-heat as the main line before its warm-up steps
+    leg_preheat = clock_preheat(lib, dev, preheat_seconds)
     el, kernels, loss = timed(steps, True)
     klist = kernel_table(kernels, "bf16", B, hid, I, steps, len(range(0, steps, prof_every)), el)
     opt.fuse_into_backward(model, min_numel=1 << 62)
@@ -909,7 +918,7 @@ def bench_configs2(gdmcf_amd, lib, dev, steps, warmup, B=400, hid=1000, T=5, pro
                     "the bf16 MFMA (f32 accumulate, f32 master weights and AdamW state), 1 GPU; AdamW of the two large weights inside "
                     "their weight-gradient products (FusedAdamW.fuse_into_backward, the N = 1 default)",
                n_items=I, dtype="bf16", steps=steps, ms_per_step=round(1e3 * el / steps, 4), users_per_s=round(B * steps / el, 1),
-               final_loss=loss, kernels=klist, optimizer="fused into the weight-gradient products", dominant_kernel=dom,
+               clock_preheat=leg_preheat, final_loss=loss, kernels=klist, optimizer="fused into the weight-gradient products", dominant_kernel=dom,
                fused_optimizer=dict(ms_per_step=round(1e3 * el / steps, 4), users_per_s=round(B * steps / el, 1), final_loss=loss,
                                     dominant_kernel=dom, is_main_figure=True),
                separate_optimizer=dict(ms_per_step=round(1e3 * els / steps, 4), users_per_s=round(B * steps / els, 1), final_loss=losss,
